@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the layout iteration (BASELINE.json metric: layout iterations/s at fixed
+n_vertices, with achieved fraction of roofline), one process per GPU.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one layout iteration (spring + KNN + intersection + integrate/normalise) of the
+whole graph.  Default workload: random-regular n=1,000,000 d=8 (E=4,000,000), n_components=3,
+n_neighbors=10, sample_size=256 -- the graph BASELINE.json quotes its target on.  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (kind, n, param, D, k, S)
+    "rr1m": ("rr", 1_000_000, 8, 3, 10, 256),      # the >=10x target case (BASELINE.json north_star)
+    "rr100k": ("rr", 100_000, 8, 3, 10, 256),      # BASELINE configs[1]
+    "er1m": ("er", 1_000_000, 1e-5, 3, 10, 256),   # BASELINE configs[2]
+    "rr4m": ("rr", 4_000_000, 8, 3, 10, 256),      # BASELINE configs[3] (meant for 8 GPUs)
+    "snap16": ("er", 4039, 0.0108, 16, 32, 256),   # BASELINE configs[4] shape (facebook_combined size), D=16 k=32
+    "rr20k": ("rr", 20_000, 8, 3, 10, 256),        # quick self-test
+}
+HBM_PEAK = 8.0e12       # B/s  (MI355X_MICROARCH.md: HBM3E peak, spec)
+FP32_PEAK = 157.3e12    # FLOP/s (fp32 vector peak = dense fp32 MFMA peak)
+
+
+def make_workload(name, seed=0):
+    import graphem_rapids_amd as gra
+    kind, n, prm, D, k, S = WORKLOADS[name]
+    if kind == "rr":
+        edges = gra.random_regular_edges(n, prm, seed=seed)
+    else:
+        edges = gra.erdos_renyi_edges(n, prm, seed=12345)
+    edges = np.ascontiguousarray(edges, dtype=np.int32)
+    rng = np.random.default_rng(seed)
+    pos = (rng.standard_normal((n, D)) * 0.1).astype(np.float32)  # the reference's own random start (pt.py:369)
+    return n, D, k, S, edges, pos
+
+
+def cpu_baseline(n, D, k, S, edges, pos, budget_s=20.0):
+    """The CPU oracle (a port of the reference's algorithm, OpenMP over the KNN queries) timed on
+    this host for a bounded number of iterations of the SAME workload."""
+    import oracle
+    rng = np.random.default_rng(1)
+    p = pos.copy()
+    done, t_total = 0, 0.0
+    while done < 5 and (done == 0 or t_total + t_total / done < budget_s):
+        sampled = rng.permutation(len(edges))[:S].astype(np.int32)
+        t0 = time.perf_counter()
+        p = oracle.step(p, edges, sampled, k)
+        t_total += time.perf_counter() - t0
+        done += 1
+    return {"value": done / t_total, "unit": "iterations/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": f"{done} full iterations of the same workload (oracle/graphem_oracle.c, "
+                      f"KNN phase OpenMP over {oracle.num_threads()} threads, other phases 1 thread)",
+            "ms_per_iter": 1e3 * t_total / done}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="rr1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--sampler", default="device", choices=["device", "host"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+
+    from graphem_rapids_amd import _native
+    n, D, k, S, edges, pos = make_workload(args.workload)
+    E = len(edges)
+
+    if world > 1:
+        import torch.distributed as dist
+        from graphem_rapids_amd.distributed import PartitionedLayout
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, rank=rank, world=world,
+                                device_id=local_rank)
+        lay.set_positions(pos)
+        run = lay.run
+        sync = lay.sync
+        barrier = dist.barrier
+        eng = lay.engine
+    else:
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, device_id=local_rank)
+        eng.set_positions(pos)
+        stream = None
+        if args.sampler == "host":  # ids drawn on the host before the timed region (parity-style stream)
+            rng = np.random.default_rng(3)
+            stream = np.stack([rng.permutation(E)[:S] for _ in range(max(args.steps, args.warmup))]).astype(np.int32)
+
+        def run(iters):
+            eng.run(iters, None if stream is None else stream[:iters])
+        sync = eng.sync
+
+        def barrier():
+            return None
+
+    run(args.warmup)
+    sync()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    sync()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations with HIP events on the launching stream: a second pass of the same K steps
+    eng.timing_enable(True)
+    eng.timing_reset()
+    run(args.steps)
+    sync()
+    timings = eng.timings()
+    eng.timing_enable(False)
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        kern = {name: {"avg_us": 1e3 * tot / cnt, "launches_per_step": cnt / args.steps}
+                for name, (tot, cnt) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
+        E_rank = E // world
+        scan_us = kern.get("knn_scan", {}).get("avg_us")
+        flops_scan = 3.0 * D * S * E_rank                      # F_knn = 3*D*S*E per launch (per rank)
+        roofline = None
+        if scan_us:
+            ach = flops_scan / (scan_us * 1e-6)
+            roofline = {"kernel": "knn_scan", "bound": "mfma", "pipe": "fp32 VALU (peak equals the dense fp32 MFMA peak)",
+                        "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_PEAK,
+                        "traffic": None, "avg_launch_us": scan_us, "algorithmic_flops_per_launch": flops_scan}
+        b_iter = 16.0 * E + 36.0 * n * D                       # B_iter = 16E + 36nD
+        hbm = {"bound": "hbm", "achieved": b_iter / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+               "frac": b_iter / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_iter": b_iter, "traffic": None}
+        su_us = kern.get("spring_update", {}).get("avg_us")
+        if su_us:
+            b_su = 8.0 * E + (4.0 + 16.0 * 2 + 4.0) * n       # pull lists + rowptr + read pos + write new + flag
+            hbm["spring_update"] = {"avg_launch_us": su_us, "algorithmic_bytes": b_su,
+                                    "achieved_GBps": b_su / (su_us * 1e-6) / 1e9,
+                                    "frac": b_su / (su_us * 1e-6) / HBM_PEAK}
+        out = {
+            "metric": "layout iterations/s", "value": args.steps / dt, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "graph": WORKLOADS[args.workload][0], "n_vertices": n,
+                       "n_edges": E, "n_components": D, "n_neighbors": k, "sample_size": S,
+                       "sampler": args.sampler, "parallelism": f"rows/{world}"},
+            "roofline": roofline, "roofline_iter_hbm": hbm, "kernels": kern,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n, D, k, S, edges, pos)
+            out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,252 @@
+"""ctypes binding of libgraphem_hip.so (include/graphem_hip.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible the HIP
+backend raises.  Nothing here imports the oracle.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphem_hip.so")
+
+GH_OK, GH_ERR_INVALID, GH_ERR_RUNTIME, GH_ERR_K_TOO_LARGE, GH_ERR_HIP, GH_ERR_NOMEM = range(6)
+
+# Every symbol include/graphem_hip.h declares.
+SYMBOLS = [
+    "gh_create", "gh_destroy", "gh_last_error", "gh_set_positions", "gh_get_positions", "gh_positions_device",
+    "gh_row_stride", "gh_step", "gh_run", "gh_sync", "gh_spring_forces", "gh_knn_midpoints",
+    "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_step_merge",
+    "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
+    "gh_timing_get", "gh_device_count", "gh_version",
+]
+
+
+class GhParams(ctypes.Structure):
+    _fields_ = [("L_min", ctypes.c_float), ("k_attr", ctypes.c_float), ("k_inter", ctypes.c_float),
+                ("n_neighbors", ctypes.c_int32), ("sample_size", ctypes.c_int32), ("seed", ctypes.c_uint64)]
+
+
+class GhPartition(ctypes.Structure):
+    _fields_ = [("row_lo", ctypes.c_int64), ("row_hi", ctypes.c_int64),
+                ("edge_lo", ctypes.c_int64), ("edge_hi", ctypes.c_int64)]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (does not touch the GPU)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python graphem-rapids_amd/build.py` "
+            "(hipcc --offload-arch=gfx950). The HIP backend has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    L.gh_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, i64, i32, i64, vp, ctypes.POINTER(GhParams),
+                            ctypes.POINTER(GhPartition)]
+    L.gh_create.restype = ctypes.c_int
+    L.gh_destroy.argtypes = [vp]
+    L.gh_destroy.restype = None
+    L.gh_last_error.argtypes = [vp]
+    L.gh_last_error.restype = ctypes.c_char_p
+    for name in ("gh_set_positions", "gh_get_positions", "gh_spring_forces", "gh_step", "gh_step_begin"):
+        getattr(L, name).argtypes = [vp, vp]
+        getattr(L, name).restype = ctypes.c_int
+    L.gh_positions_device.argtypes = [vp]
+    L.gh_positions_device.restype = vp
+    L.gh_row_stride.argtypes = [vp]
+    L.gh_row_stride.restype = i32
+    L.gh_run.argtypes = [vp, i32, vp]
+    L.gh_run.restype = ctypes.c_int
+    for name in ("gh_sync", "gh_step_finish", "gh_timing_reset"):
+        getattr(L, name).argtypes = [vp]
+        getattr(L, name).restype = ctypes.c_int
+    L.gh_knn_midpoints.argtypes = [vp, vp, vp]
+    L.gh_knn_midpoints.restype = ctypes.c_int
+    L.gh_intersection_forces.argtypes = [vp, vp, vp, vp]
+    L.gh_intersection_forces.restype = ctypes.c_int
+    L.gh_integrate_normalise.argtypes = [vp, vp, vp, vp]
+    L.gh_integrate_normalise.restype = ctypes.c_int
+    L.gh_knn_partial_device.argtypes = [vp]
+    L.gh_knn_partial_device.restype = vp
+    L.gh_step_merge.argtypes = [vp, vp, i32]
+    L.gh_step_merge.restype = ctypes.c_int
+    L.gh_stats_partial_device.argtypes = [vp]
+    L.gh_stats_partial_device.restype = vp
+    L.gh_timing_enable.argtypes = [vp, i32]
+    L.gh_timing_enable.restype = ctypes.c_int
+    L.gh_timing_count.argtypes = [vp]
+    L.gh_timing_count.restype = i32
+    L.gh_timing_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double),
+                                ctypes.POINTER(i64)]
+    L.gh_timing_get.restype = ctypes.c_int
+    L.gh_device_count.argtypes = []
+    L.gh_device_count.restype = i32
+    L.gh_version.argtypes = []
+    L.gh_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def raise_for(status, handle):
+    """Map a gh_status to the exception type the reference raises for the same condition."""
+    if status == GH_OK:
+        return
+    msg = load().gh_last_error(handle)
+    msg = msg.decode() if msg else f"gh_status {status}"
+    if status == GH_ERR_INVALID:
+        raise ValueError(msg)
+    if status == GH_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Engine:
+    """Thin RAII wrapper over a gh_handle."""
+
+    def __init__(self, n, D, edges, L_min, k_attr, k_inter, n_neighbors, sample_size, seed=0, device_id=0,
+                 partition=None):
+        self.lib = load()
+        self.handle = ctypes.c_void_p()
+        self.n, self.D = int(n), int(D)
+        edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        self.E = edges.shape[0]
+        prm = GhParams(float(L_min), float(k_attr), float(k_inter), int(n_neighbors), int(sample_size),
+                       int(seed) & 0xFFFFFFFFFFFFFFFF)
+        part = None
+        if partition is not None:
+            part = ctypes.pointer(GhPartition(*[int(x) for x in partition]))
+        st = self.lib.gh_create(ctypes.byref(self.handle), int(device_id), self.n, self.D, self.E, ptr(edges),
+                                ctypes.byref(prm), part)
+        if st != GH_OK:
+            self.handle = ctypes.c_void_p()
+            raise_for(st, None)
+        self.k = int(n_neighbors)
+        self.S = min(int(sample_size), self.E)
+        self.ld = self.lib.gh_row_stride(self.handle)
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.gh_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pylint: disable=broad-exception-caught
+            pass
+
+    def _chk(self, st):
+        raise_for(st, self.handle)
+
+    def set_positions(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.float32)
+        if pos.shape != (self.n, self.D):
+            raise ValueError(f"positions must have shape {(self.n, self.D)}, got {pos.shape}")
+        self._chk(self.lib.gh_set_positions(self.handle, ptr(pos)))
+
+    def get_positions(self):
+        out = np.empty((self.n, self.D), dtype=np.float32)
+        self._chk(self.lib.gh_get_positions(self.handle, ptr(out)))
+        return out
+
+    def _ids(self, sampled):
+        if sampled is None:
+            return None
+        sampled = np.ascontiguousarray(sampled, dtype=np.int32).ravel()
+        if self.S < self.E and sampled.shape[0] != self.S:
+            raise ValueError(f"expected {self.S} sampled edge ids, got {sampled.shape[0]}")
+        return sampled
+
+    def step(self, sampled=None):
+        s = self._ids(sampled)
+        self._chk(self.lib.gh_step(self.handle, ptr(s)))
+
+    def run(self, iters, sample_stream=None):
+        ss = None
+        if sample_stream is not None:
+            ss = np.ascontiguousarray(sample_stream, dtype=np.int32)
+            if self.S < self.E and ss.shape != (iters, self.S):
+                raise ValueError(f"sample_stream must have shape {(iters, self.S)}, got {ss.shape}")
+        self._chk(self.lib.gh_run(self.handle, int(iters), ptr(ss)))
+
+    def sync(self):
+        self._chk(self.lib.gh_sync(self.handle))
+
+    def spring_forces(self):
+        F = np.empty((self.n, self.D), dtype=np.float32)
+        self._chk(self.lib.gh_spring_forces(self.handle, ptr(F)))
+        return F
+
+    def knn_midpoints(self, sampled=None):
+        s = self._ids(sampled)
+        knn = np.empty((self.S, self.k), dtype=np.int32)
+        self._chk(self.lib.gh_knn_midpoints(self.handle, ptr(s), ptr(knn)))
+        return knn
+
+    def intersection_forces(self, sampled, knn):
+        s = self._ids(sampled)
+        knn = np.ascontiguousarray(knn, dtype=np.int32)
+        if knn.shape != (self.S, self.k):
+            raise ValueError(f"knn must have shape {(self.S, self.k)}, got {knn.shape}")
+        F = np.empty((self.n, self.D), dtype=np.float32)
+        self._chk(self.lib.gh_intersection_forces(self.handle, ptr(s), ptr(knn), ptr(F)))
+        return F
+
+    def integrate_normalise(self, Fs, Fi):
+        Fs = np.ascontiguousarray(Fs, dtype=np.float32)
+        Fi = np.ascontiguousarray(Fi, dtype=np.float32)
+        if Fs.shape != (self.n, self.D) or Fi.shape != (self.n, self.D):
+            raise ValueError("force arrays must have the shape of positions")
+        out = np.empty((self.n, self.D), dtype=np.float32)
+        self._chk(self.lib.gh_integrate_normalise(self.handle, ptr(Fs), ptr(Fi), ptr(out)))
+        return out
+
+    # multi-GPU split step
+    def step_begin(self, sampled=None):
+        s = self._ids(sampled)
+        self._chk(self.lib.gh_step_begin(self.handle, ptr(s)))
+
+    def step_merge(self, gathered_ptr, world):
+        self._chk(self.lib.gh_step_merge(self.handle, ctypes.c_void_p(gathered_ptr), int(world)))
+
+    def step_finish(self):
+        self._chk(self.lib.gh_step_finish(self.handle))
+
+    def positions_device_ptr(self):
+        return self.lib.gh_positions_device(self.handle)
+
+    def knn_partial_device_ptr(self):
+        return self.lib.gh_knn_partial_device(self.handle)
+
+    def stats_partial_device_ptr(self):
+        return self.lib.gh_stats_partial_device(self.handle)
+
+    # instrumentation
+    def timing_enable(self, on=True):
+        self._chk(self.lib.gh_timing_enable(self.handle, 1 if on else 0))
+
+    def timing_reset(self):
+        self._chk(self.lib.gh_timing_reset(self.handle))
+
+    def timings(self):
+        """{kernel name: (total_ms, launches)} since the last reset."""
+        out = {}
+        for i in range(self.lib.gh_timing_count(self.handle)):
+            name, ms, cnt = ctypes.c_char_p(), ctypes.c_double(), ctypes.c_int64()
+            self._chk(self.lib.gh_timing_get(self.handle, i, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(cnt)))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+
+def device_count():
+    return int(load().gh_device_count())

@@ -1,0 +1,59 @@
+"""Backend names and selection for the HIP drop-in (counterpart of the reference's
+graphem_rapids/utils/backend_selection.py:16-29, 142-206; heuristics are out of scope,
+SURVEY.md section 2 row 5: this package ships exactly one backend, 'hip')."""
+from dataclasses import dataclass
+
+from . import _native
+
+VALID_BACKENDS = ["pytorch", "cuvs", "cpu", "auto", "hip"]
+
+
+@dataclass
+class BackendConfig:
+    """Same fields as the reference's BackendConfig, with 'hip' accepted as a backend name."""
+    n_vertices: int
+    n_components: int = 2
+    force_backend: str = None
+    prefer_gpu: bool = True
+    memory_limit: float = None  # GB
+    verbose: bool = True
+
+    def __post_init__(self):
+        if self.force_backend and self.force_backend not in VALID_BACKENDS:
+            raise ValueError(f"Invalid backend: {self.force_backend}")
+
+
+def check_hip_availability():
+    """Is the native library built and is a GPU visible?  Never raises."""
+    info = {"library": False, "device_count": 0, "version": None}
+    try:
+        lib = _native.load()
+        info["library"] = True
+        info["version"] = lib.gh_version().decode()
+        import torch
+        info["device_count"] = torch.cuda.device_count()  # does not initialise the GPU
+    except Exception:  # pylint: disable=broad-exception-caught
+        pass
+    return info
+
+
+def get_optimal_backend(config):
+    """'hip' whenever it is asked for or left to choose; the reference's own backends are not
+    part of this package."""
+    forced = config.force_backend
+    if forced in (None, "auto", "hip"):
+        return "hip"
+    if forced not in VALID_BACKENDS:
+        raise ValueError(f"Invalid backend: {forced}")
+    raise ValueError(f"backend '{forced}' belongs to graphem_rapids itself; graphem_rapids_amd provides 'hip'")
+
+
+def estimate_memory_usage(n_vertices, n_components, n_edges=None, n_neighbors=10, sample_size=256):
+    """Bytes of HBM the engine allocates (DESIGN.md 'Data layout')."""
+    ld = 4 if n_components <= 4 else 8 if n_components <= 8 else 16 if n_components <= 16 else (n_components + 3) // 4 * 4
+    e = n_edges if n_edges is not None else 5 * n_vertices
+    s = min(sample_size, e)
+    per_vertex = ld * 4 * 4 + n_components * 4 + ld * 8 + 4   # pos, new, 2 scratch, io, fp64 accumulators, flag
+    per_edge = 8 + 8                                           # edge list + pull lists
+    per_query = 4096 * 8 + (n_neighbors + 1) * 8 + n_neighbors * (4 + 4 * ld) + 16 * n_neighbors
+    return n_vertices * per_vertex + e * per_edge + s * per_query

@@ -1,0 +1,434 @@
+// C ABI of libgraphem_hip.so (include/graphem_hip.h): handle lifetime, host<->device
+// copies, the iteration driver and the per-phase entry points.
+#include "common.h"
+#include "engine.h"
+
+#include <algorithm>
+#include <new>
+#include <string.h>
+
+static thread_local std::string g_create_error;
+
+// ---- timing ------------------------------------------------------------------------
+gh_scope::gh_scope(gh_engine *h_, const char *name) : h(h_) {
+    if (!h->timing) return;
+    for (size_t i = 0; i < h->timers.size(); ++i)
+        if (h->timers[i].name == name) slot = (int)i;
+    if (slot < 0) {
+        h->timers.emplace_back();
+        h->timers.back().name = name;
+        slot = (int)h->timers.size() - 1;
+    }
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    hipEventRecord(a, h->stream);
+}
+gh_scope::~gh_scope() {
+    if (slot < 0) return;
+    hipEventRecord(b, h->stream);
+    h->timers[slot].pending.emplace_back(a, b);
+}
+
+static void resolve_timers(gh_engine *h) {
+    for (auto &t : h->timers) {
+        for (auto &p : t.pending) {
+            float ms = 0.f;
+            hipEventSynchronize(p.second);
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t.total_ms += ms; t.launches += 1; }
+            hipEventDestroy(p.first);
+            hipEventDestroy(p.second);
+        }
+        t.pending.clear();
+    }
+}
+
+// ---- helpers -----------------------------------------------------------------------
+template <typename T>
+static gh_status dev_alloc(gh_engine *h, T **p, size_t count, bool zero) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+    if (e != hipSuccess) {
+        h->err = std::string("hipMalloc failed: ") + hipGetErrorString(e);
+        return GH_ERR_NOMEM;
+    }
+    if (zero) GH_HIP(hipMemsetAsync(*p, 0, count * sizeof(T), h->stream));
+    return GH_OK;
+}
+
+#define GH_TRY(x)                        \
+    do {                                 \
+        gh_status st_ = (x);             \
+        if (st_ != GH_OK) return st_;    \
+    } while (0)
+
+static gh_status check_handle(gh_engine *h) {
+    if (!h) return GH_ERR_INVALID;
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) {
+        h->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return GH_ERR_HIP;
+    }
+    return GH_OK;
+}
+
+static void free_all(gh_engine *h) {
+    void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_new, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
+                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_tau, h->d_cand, h->d_cnt,
+                    h->d_ovf, h->d_partial, h->d_knn, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
+    for (void *p : ptrs)
+        if (p) hipFree(p);
+    if (h->stream) hipStreamDestroy(h->stream);
+}
+
+// ---- lifetime ----------------------------------------------------------------------
+extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t D, int64_t E, const int32_t *edges,
+                               const gh_params *params, const gh_partition *part) {
+    if (!out) return GH_ERR_INVALID;
+    *out = nullptr;
+    auto fail = [&](gh_status st, const std::string &msg) { g_create_error = msg; return st; };
+    if (n <= 0) return fail(GH_ERR_INVALID, "Adjacency matrix cannot be empty");
+    if (D <= 0) return fail(GH_ERR_INVALID, "Number of components must be positive, got " + std::to_string(D));
+    if (!params) return fail(GH_ERR_INVALID, "params is NULL");
+    if (params->k_attr < 0) return fail(GH_ERR_INVALID, "Attractive force constant k_attr must be non-negative");
+    if (E < 0 || (E > 0 && !edges)) return fail(GH_ERR_INVALID, "edges is NULL");
+    if (params->n_neighbors < 0 || params->sample_size < 0) return fail(GH_ERR_INVALID, "negative n_neighbors / sample_size");
+    if (E >= ((int64_t)1 << 30) || n >= ((int64_t)1 << 31)) return fail(GH_ERR_INVALID, "graph too large for int32 ids");
+    if ((int64_t)params->n_neighbors + 1 > GH_SEL_BUF - GH_SEL_CHUNK)
+        return fail(GH_ERR_INVALID, "n_neighbors too large for the HIP backend (max 2047)");
+    for (int64_t e = 0; e < E; ++e) {
+        const int32_t u = edges[2 * e], v = edges[2 * e + 1];
+        if (u < 0 || v < 0 || u >= n || v >= n) return fail(GH_ERR_INVALID, "edge endpoint out of range");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GH_ERR_HIP, "no HIP device available");
+    if (device_id < 0 || device_id >= ndev) return fail(GH_ERR_RUNTIME, "invalid device ordinal " + std::to_string(device_id));
+
+    gh_engine *h = new (std::nothrow) gh_engine();
+    if (!h) return fail(GH_ERR_NOMEM, "out of host memory");
+    h->device = device_id;
+    h->n = n; h->E = E; h->D = D; h->LD = gh_ld(D);
+    h->prm = *params;
+    h->k = params->n_neighbors; h->K = h->k + 1;
+    h->S = std::min<int64_t>(params->sample_size, E);
+    if (part) h->part = *part;
+    else h->part = gh_partition{0, n, 0, E};
+    if (h->part.row_lo < 0 || h->part.row_hi > n || h->part.row_lo > h->part.row_hi || h->part.edge_lo < 0 ||
+        h->part.edge_hi > E || h->part.edge_lo > h->part.edge_hi) {
+        delete h;
+        return fail(GH_ERR_INVALID, "partition out of range");
+    }
+    h->rows = h->part.row_hi - h->part.row_lo;
+
+    auto bail = [&](gh_status st) { g_create_error = h->err; free_all(h); delete h; return st; };
+    if (hipSetDevice(device_id) != hipSuccess) return bail(GH_ERR_HIP);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(GH_ERR_HIP); }
+
+    // Pull lists of the own rows in the reference's summation order (pt.py:633-634):
+    // first the edges where the vertex is endpoint 0, then those where it is endpoint 1,
+    // each in edge-list order.
+    std::vector<int32_t> rowptr((size_t)h->rows + 1, 0);
+    const int64_t lo = h->part.row_lo, hi = h->part.row_hi;
+    for (int64_t e = 0; e < E; ++e) {
+        const int32_t u = edges[2 * e], v = edges[2 * e + 1];
+        if (u >= lo && u < hi) rowptr[(size_t)(u - lo) + 1]++;
+        if (v >= lo && v < hi) rowptr[(size_t)(v - lo) + 1]++;
+    }
+    for (int64_t i = 0; i < h->rows; ++i) rowptr[(size_t)i + 1] += rowptr[(size_t)i];
+    h->adj_len = rowptr[(size_t)h->rows];
+    std::vector<int32_t> adj((size_t)std::max<int64_t>(h->adj_len, 1));
+    {
+        std::vector<int32_t> cur(rowptr.begin(), rowptr.end() - 1);
+        for (int64_t e = 0; e < E; ++e) {
+            const int32_t u = edges[2 * e], v = edges[2 * e + 1];
+            if (u >= lo && u < hi) adj[(size_t)cur[(size_t)(u - lo)]++] = v;
+        }
+        for (int64_t e = 0; e < E; ++e) {
+            const int32_t u = edges[2 * e], v = edges[2 * e + 1];
+            if (v >= lo && v < hi) adj[(size_t)cur[(size_t)(v - lo)]++] = u;
+        }
+    }
+
+    const size_t nLD = (size_t)n * h->LD, S = (size_t)h->S;
+    gh_status st;
+#define GH_A(p, count, zero) if ((st = dev_alloc(h, &h->p, (count), (zero))) != GH_OK) return bail(st)
+    GH_A(d_edges, (size_t)E * 2, false);
+    GH_A(d_rowptr, (size_t)h->rows + 1, false);
+    GH_A(d_adj, (size_t)h->adj_len, false);
+    GH_A(d_pos, nLD, true);
+    GH_A(d_new, (size_t)h->rows * h->LD, true);
+    GH_A(d_tmpF, nLD, true);
+    GH_A(d_tmpF2, nLD, true);
+    GH_A(d_io, (size_t)n * D, false);
+    GH_A(d_acc, nLD, true);
+    GH_A(d_tflag, (size_t)n, true);
+    GH_A(d_touched, 4 * S * (size_t)h->k, false);
+    GH_A(d_tcount, 1, true);
+    GH_A(d_sampled, S, true);
+    GH_A(d_q, S * h->LD, true);
+    GH_A(d_tau, S, true);
+    GH_A(d_cand, S * GH_CAND_CAP, false);
+    GH_A(d_cnt, S, true);
+    GH_A(d_ovf, S, true);
+    GH_A(d_partial, S * (size_t)h->K, true);
+    GH_A(d_knn, S * (size_t)h->k, true);
+    GH_A(d_iscratch, S * (size_t)h->k * h->LD, false);
+    h->nblocks_update = (int)((h->rows + 255) / 256);
+    GH_A(d_blockstats, (size_t)std::max(h->nblocks_update, 1) * 2 * h->LD, true);
+    GH_A(d_stats, (size_t)2 * h->LD, true);
+#undef GH_A
+    h->d_sampled_cur = h->d_sampled;
+    auto up = [&](void *dst, const void *src, size_t bytes) {
+        return bytes == 0 || hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+    };
+    if (!up(h->d_edges, edges, sizeof(int32_t) * 2 * (size_t)E) ||
+        !up(h->d_rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size()) ||
+        !up(h->d_adj, adj.data(), sizeof(int32_t) * (size_t)h->adj_len) ||
+        hipStreamSynchronize(h->stream) != hipSuccess) {
+        h->err = "upload of the graph failed";
+        return bail(GH_ERR_HIP);
+    }
+    *out = h;
+    return GH_OK;
+}
+
+extern "C" void gh_destroy(gh_handle h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    resolve_timers(h);
+    free_all(h);
+    delete h;
+}
+
+extern "C" const char *gh_last_error(gh_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+// ---- positions ---------------------------------------------------------------------
+extern "C" gh_status gh_set_positions(gh_handle h, const float *pos) {
+    GH_TRY(check_handle(h));
+    if (!pos) { h->err = "positions is NULL"; return GH_ERR_INVALID; }
+    GH_HIP(hipMemcpyAsync(h->d_io, pos, sizeof(float) * (size_t)h->n * h->D, hipMemcpyHostToDevice, h->stream));
+    GH_TRY(gh_launch_pad(h, h->d_io, h->d_pos));
+    GH_HIP(hipStreamSynchronize(h->stream));  // the host buffer may be released by the caller
+    return GH_OK;
+}
+
+static gh_status download_padded(gh_engine *h, const float *d_src, float *host) {
+    GH_TRY(gh_launch_unpad(h, d_src, h->d_io));
+    GH_HIP(hipMemcpyAsync(host, h->d_io, sizeof(float) * (size_t)h->n * h->D, hipMemcpyDeviceToHost, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    return GH_OK;
+}
+
+extern "C" gh_status gh_get_positions(gh_handle h, float *pos) {
+    GH_TRY(check_handle(h));
+    if (!pos) { h->err = "positions is NULL"; return GH_ERR_INVALID; }
+    return download_padded(h, h->d_pos, pos);
+}
+
+extern "C" float *gh_positions_device(gh_handle h) { return h ? h->d_pos : nullptr; }
+extern "C" int32_t gh_row_stride(gh_handle h) { return h ? h->LD : 0; }
+
+// ---- the loop ----------------------------------------------------------------------
+static gh_status check_k(gh_engine *h) {
+    if ((int64_t)h->K > h->E) {
+        h->err = "selected index k out of range";  // torch.topk's message (pt.py:583)
+        return GH_ERR_K_TOO_LARGE;
+    }
+    return GH_OK;
+}
+
+// Chooses this iteration's sample ids: caller's ids, arange (S >= E, pt.py:412) or the sampler.
+static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t *dev_ids) {
+    if (h->S >= h->E) {  // no randomness consumed
+        h->d_sampled_cur = h->d_sampled;
+        return gh_launch_arange(h);
+    }
+    if (dev_ids) { h->d_sampled_cur = const_cast<int32_t *>(dev_ids); return GH_OK; }
+    h->d_sampled_cur = h->d_sampled;
+    if (host_ids) {
+        for (int64_t i = 0; i < h->S; ++i)
+            if (host_ids[i] < 0 || host_ids[i] >= h->E) { h->err = "sampled edge id out of range"; return GH_ERR_INVALID; }
+        GH_HIP(hipMemcpyAsync(h->d_sampled, host_ids, sizeof(int32_t) * (size_t)h->S, hipMemcpyHostToDevice, h->stream));
+        GH_HIP(hipStreamSynchronize(h->stream));
+        return GH_OK;
+    }
+    return gh_launch_sample(h);
+}
+
+static gh_status step_begin(gh_engine *h) { return gh_knn_local(h); }
+
+static gh_status step_merge(gh_engine *h, const uint64_t *gathered, int world) {
+    GH_TRY(gh_knn_merge(h, gathered, world));
+    GH_TRY(gh_launch_intersect(h));
+    GH_TRY(gh_launch_spring_update(h));
+    GH_TRY(gh_launch_inter_cleanup(h));
+    return GH_OK;
+}
+
+static gh_status step_finish(gh_engine *h) {
+    GH_TRY(gh_launch_normalise(h));
+    h->iter += 1;
+    return GH_OK;
+}
+
+extern "C" gh_status gh_step(gh_handle h, const int32_t *sampled) {
+    GH_TRY(check_handle(h));
+    GH_TRY(check_k(h));
+    GH_TRY(set_sample(h, sampled, nullptr));
+    GH_TRY(step_begin(h));
+    GH_TRY(step_merge(h, h->d_partial, 1));
+    return step_finish(h);
+}
+
+extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_stream) {
+    GH_TRY(check_handle(h));
+    if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
+    if (iters == 0) return GH_OK;
+    GH_TRY(check_k(h));
+    const bool use_stream = sample_stream && h->S < h->E;
+    if (use_stream) {
+        const size_t cnt = (size_t)iters * (size_t)h->S;
+        for (size_t i = 0; i < cnt; ++i)
+            if (sample_stream[i] < 0 || sample_stream[i] >= h->E) { h->err = "sampled edge id out of range"; return GH_ERR_INVALID; }
+        if (cnt > h->stream_ids_cap) {
+            if (h->d_stream_ids) { GH_HIP(hipStreamSynchronize(h->stream)); GH_HIP(hipFree(h->d_stream_ids)); h->d_stream_ids = nullptr; }
+            GH_TRY(dev_alloc(h, &h->d_stream_ids, cnt, false));
+            h->stream_ids_cap = cnt;
+        }
+        GH_HIP(hipMemcpyAsync(h->d_stream_ids, sample_stream, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, h->stream));
+        GH_HIP(hipStreamSynchronize(h->stream));
+    }
+    for (int32_t t = 0; t < iters; ++t) {
+        GH_TRY(set_sample(h, nullptr, use_stream ? h->d_stream_ids + (size_t)t * h->S : nullptr));
+        GH_TRY(step_begin(h));
+        GH_TRY(step_merge(h, h->d_partial, 1));
+        GH_TRY(step_finish(h));
+    }
+    h->d_sampled_cur = h->d_sampled;
+    return GH_OK;
+}
+
+extern "C" gh_status gh_sync(gh_handle h) {
+    GH_TRY(check_handle(h));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    resolve_timers(h);
+    return GH_OK;
+}
+
+// ---- multi-GPU split step ----------------------------------------------------------
+extern "C" gh_status gh_step_begin(gh_handle h, const int32_t *sampled) {
+    GH_TRY(check_handle(h));
+    GH_TRY(check_k(h));
+    GH_TRY(set_sample(h, sampled, nullptr));
+    return step_begin(h);
+}
+extern "C" uint64_t *gh_knn_partial_device(gh_handle h) { return h ? h->d_partial : nullptr; }
+extern "C" gh_status gh_step_merge(gh_handle h, const uint64_t *gathered, int32_t world) {
+    GH_TRY(check_handle(h));
+    if (!gathered || world < 1) { h->err = "bad gathered buffer / world size"; return GH_ERR_INVALID; }
+    return step_merge(h, gathered, world);
+}
+extern "C" double *gh_stats_partial_device(gh_handle h) { return h ? h->d_stats : nullptr; }
+extern "C" gh_status gh_step_finish(gh_handle h) {
+    GH_TRY(check_handle(h));
+    return step_finish(h);
+}
+
+// ---- per-phase entry points --------------------------------------------------------
+static bool whole_graph(gh_engine *h) {
+    return h->part.row_lo == 0 && h->part.row_hi == h->n && h->part.edge_lo == 0 && h->part.edge_hi == h->E;
+}
+
+extern "C" gh_status gh_spring_forces(gh_handle h, float *F) {
+    GH_TRY(check_handle(h));
+    if (!F) { h->err = "F is NULL"; return GH_ERR_INVALID; }
+    GH_TRY(gh_launch_spring_only(h, h->d_tmpF));
+    return download_padded(h, h->d_tmpF, F);
+}
+
+extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32_t *knn) {
+    GH_TRY(check_handle(h));
+    if (!knn) { h->err = "knn is NULL"; return GH_ERR_INVALID; }
+    if (!whole_graph(h)) { h->err = "per-phase entry points need the whole graph on one rank"; return GH_ERR_INVALID; }
+    GH_TRY(check_k(h));
+    if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
+    GH_TRY(set_sample(h, sampled, nullptr));
+    GH_TRY(gh_knn_local(h));
+    GH_TRY(gh_knn_merge(h, h->d_partial, 1));
+    GH_HIP(hipMemcpyAsync(knn, h->d_knn, sizeof(int32_t) * (size_t)h->S * h->k, hipMemcpyDeviceToHost, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    return GH_OK;
+}
+
+extern "C" gh_status gh_intersection_forces(gh_handle h, const int32_t *sampled, const int32_t *knn, float *F) {
+    GH_TRY(check_handle(h));
+    if (!knn || !F) { h->err = "NULL argument"; return GH_ERR_INVALID; }
+    if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
+    for (int64_t i = 0; i < h->S * h->k; ++i)
+        if (knn[i] < 0 || knn[i] >= h->E) { h->err = "neighbour edge id out of range"; return GH_ERR_INVALID; }
+    GH_TRY(set_sample(h, sampled, nullptr));
+    GH_HIP(hipMemcpyAsync(h->d_knn, knn, sizeof(int32_t) * (size_t)h->S * h->k, hipMemcpyHostToDevice, h->stream));
+    GH_TRY(gh_launch_intersect(h));
+    GH_TRY(gh_launch_inter_to_dense(h, h->d_tmpF));
+    GH_TRY(gh_launch_inter_cleanup(h));
+    return download_padded(h, h->d_tmpF, F);
+}
+
+extern "C" gh_status gh_integrate_normalise(gh_handle h, const float *Fs, const float *Fi, float *out) {
+    GH_TRY(check_handle(h));
+    if (!Fs || !Fi || !out) { h->err = "NULL argument"; return GH_ERR_INVALID; }
+    if (!whole_graph(h)) { h->err = "per-phase entry points need the whole graph on one rank"; return GH_ERR_INVALID; }
+    const size_t bytes = sizeof(float) * (size_t)h->n * h->D;
+    GH_HIP(hipMemcpyAsync(h->d_io, Fs, bytes, hipMemcpyHostToDevice, h->stream));
+    GH_TRY(gh_launch_pad(h, h->d_io, h->d_tmpF));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    GH_HIP(hipMemcpyAsync(h->d_io, Fi, bytes, hipMemcpyHostToDevice, h->stream));
+    GH_TRY(gh_launch_pad(h, h->d_io, h->d_tmpF2));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    GH_TRY(gh_launch_integrate_given(h, h->d_tmpF, h->d_tmpF2));
+    // normalise into scratch so the current positions stay unchanged
+    GH_HIP(hipMemcpyAsync(h->d_tmpF, h->d_pos, sizeof(float) * (size_t)h->n * h->LD, hipMemcpyDeviceToDevice, h->stream));
+    GH_TRY(gh_launch_normalise(h));
+    GH_TRY(gh_launch_unpad(h, h->d_pos, h->d_io));
+    GH_HIP(hipMemcpyAsync(out, h->d_io, bytes, hipMemcpyDeviceToHost, h->stream));
+    GH_HIP(hipMemcpyAsync(h->d_pos, h->d_tmpF, sizeof(float) * (size_t)h->n * h->LD, hipMemcpyDeviceToDevice, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    return GH_OK;
+}
+
+// ---- instrumentation ---------------------------------------------------------------
+extern "C" gh_status gh_timing_enable(gh_handle h, int32_t on) {
+    GH_TRY(check_handle(h));
+    h->timing = on != 0;
+    return GH_OK;
+}
+extern "C" gh_status gh_timing_reset(gh_handle h) {
+    GH_TRY(check_handle(h));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    resolve_timers(h);
+    h->timers.clear();
+    return GH_OK;
+}
+extern "C" int32_t gh_timing_count(gh_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    resolve_timers(h);
+    return (int32_t)h->timers.size();
+}
+extern "C" gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, double *total_ms, int64_t *launches) {
+    if (!h) return GH_ERR_INVALID;
+    if (i < 0 || i >= (int32_t)h->timers.size()) { h->err = "timer index out of range"; return GH_ERR_INVALID; }
+    if (name) *name = h->timers[(size_t)i].name.c_str();
+    if (total_ms) *total_ms = h->timers[(size_t)i].total_ms;
+    if (launches) *launches = h->timers[(size_t)i].launches;
+    return GH_OK;
+}
+
+extern "C" int32_t gh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" const char *gh_version(void) { return "graphem_hip 0.1 (gfx950)"; }

@@ -1,0 +1,95 @@
+// Shared device helpers for the gfx950 layout engine.  Compiled with
+// -ffp-contract=off: every fused multiply-add below is an explicit fmaf, so the
+// arithmetic matches the reference's op-by-op fp32 rounding ("Numerics").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GH_WAVE 64
+
+// Row stride (floats) of the padded position array for an embedding dimension D:
+// rows are 16-byte aligned so a vertex is fetched with dwordx4 loads.
+__host__ __device__ inline int gh_ld(int D) {
+    return D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : ((D + 3) & ~3);
+}
+
+// torch.norm(x, dim=1) reduction order of the reference's CPU backend (pt.py:623,
+// pt.py:731), squared: full groups of 8 -> eight fma lane accumulators summed left
+// to right; groups of 4 -> s + x*x; last D%4 -> fma chain.  D <= 3 is a plain fma
+// chain.  Bit-identical to oracle/graphem_oracle.c:go_norm2 (before the sqrt).
+template <int D>
+__device__ __forceinline__ float gh_sumsq(const float *x) {
+    float s = 0.0f;
+    int d = 0;
+    if constexpr (D >= 8) {
+        float acc[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = 0.0f;
+#pragma unroll
+        for (d = 0; d + 8 <= D; d += 8) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) acc[l] = fmaf(x[d + l], x[d + l], acc[l]);
+        }
+        s = acc[0];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) s = s + acc[l];
+        d = D & ~7;
+    }
+#pragma unroll
+    for (; d + 4 <= D; d += 4) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) s = s + x[d + l] * x[d + l];
+    }
+#pragma unroll
+    for (; d < D; ++d) s = fmaf(x[d], x[d], s);
+    return s;
+}
+
+// Same order with a runtime D and x in memory (generic-dimension kernels).
+__device__ inline float gh_sumsq_rt(const float *x, int D) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int d = 0;
+    for (; d + 8 <= D; d += 8)
+        for (int l = 0; l < 8; ++l) acc[l] = fmaf(x[d + l], x[d + l], acc[l]);
+    float s = acc[0];
+    for (int l = 1; l < 8; ++l) s = s + acc[l];
+    for (; d + 4 <= D; d += 4)
+        for (int l = 0; l < 4; ++l) s = s + x[d + l] * x[d + l];
+    for (; d < D; ++d) s = fmaf(x[d], x[d], s);
+    return s;
+}
+
+// Load one padded position row (LD floats, 16-byte aligned) with dwordx4 loads.
+template <int LD>
+__device__ __forceinline__ void gh_load_row(const float *__restrict__ pos, int64_t v, float *out) {
+    const float4 *p = reinterpret_cast<const float4 *>(pos + v * LD);
+#pragma unroll
+    for (int i = 0; i < LD / 4; ++i) {
+        const float4 t = p[i];
+        out[4 * i + 0] = t.x; out[4 * i + 1] = t.y; out[4 * i + 2] = t.z; out[4 * i + 3] = t.w;
+    }
+}
+
+template <int LD>
+__device__ __forceinline__ void gh_store_row(float *__restrict__ dst, int64_t v, const float *in) {
+    float4 *p = reinterpret_cast<float4 *>(dst + v * LD);
+#pragma unroll
+    for (int i = 0; i < LD / 4; ++i) p[i] = make_float4(in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]);
+}
+
+// (dist2, edge id) packed so that unsigned comparison orders by distance, then id.
+// dist2 >= +0 always (fma chain from +0), so its bit pattern is monotone.
+__device__ __forceinline__ uint64_t gh_key(float d2, uint32_t id) {
+    return (static_cast<uint64_t>(__float_as_uint(d2)) << 32) | id;
+}
+__device__ __forceinline__ float gh_key_d2(uint64_t k) { return __uint_as_float(static_cast<uint32_t>(k >> 32)); }
+__device__ __forceinline__ uint32_t gh_key_id(uint64_t k) { return static_cast<uint32_t>(k); }
+
+#define GH_KEY_INF 0xFFFFFFFFFFFFFFFFull
+
+// Wave-level sum of a double over 64 lanes (result valid in lane 0).
+__device__ __forceinline__ double gh_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, GH_WAVE);
+    return v;
+}

@@ -1,0 +1,121 @@
+// Internal engine state shared by the translation units of libgraphem_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/graphem_hip.h"
+
+// Candidate-list capacity per query in the filtered KNN scan, and the LDS sort size.
+#define GH_CAND_CAP 4096
+#define GH_SEL_BUF 4096
+#define GH_SEL_CHUNK 2048
+// Below this many reference edges the per-query block kernel scans everything itself.
+#define GH_SCAN_MIN_EDGES 16384
+
+struct gh_timer_slot {
+    std::string name;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct gh_engine {
+    int device = 0;
+    int64_t n = 0, E = 0;
+    int D = 0, LD = 0, k = 0, K = 0;
+    int64_t S = 0;
+    gh_params prm{};
+    gh_partition part{};
+    int64_t rows = 0;       // part.row_hi - part.row_lo
+    uint64_t iter = 0;      // iterations done (device sampler counter)
+    std::string err;
+
+    hipStream_t stream = nullptr;
+
+    // graph
+    int32_t *d_edges = nullptr;   // (E, 2)
+    int32_t *d_rowptr = nullptr;  // (rows + 1) pull lists of own rows, reference summation order
+    int32_t *d_adj = nullptr;     // neighbours
+    int64_t adj_len = 0;
+
+    // state
+    float *d_pos = nullptr;       // (n, LD)
+    float *d_new = nullptr;       // (rows, LD) un-normalised update of own rows
+    float *d_tmpF = nullptr;      // (n, LD) scratch for the per-phase entry points
+    float *d_tmpF2 = nullptr;
+    float *d_io = nullptr;        // (n, D) staging for unpadded host copies
+
+    // intersection accumulators
+    double *d_acc = nullptr;      // (n, LD) zero between iterations
+    int32_t *d_tflag = nullptr;   // (n) zero between iterations
+    int32_t *d_touched = nullptr; // (4 * S * k)
+    int32_t *d_tcount = nullptr;  // (1)
+
+    // knn
+    int32_t *d_sampled = nullptr; // (S) owned buffer
+    int32_t *d_sampled_cur = nullptr; // ids of the current iteration (d_sampled or a row of d_stream_ids)
+    int32_t *d_stream_ids = nullptr;  // (iters, S) uploaded sample stream of gh_run
+    size_t stream_ids_cap = 0;
+    float *d_iscratch = nullptr;  // (S * k, LD) per-pair scratch of the intersection kernel
+    float *d_q = nullptr;         // (S, LD) query midpoints
+    float *d_tau = nullptr;       // (S) squared-distance thresholds
+    uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
+    int32_t *d_cnt = nullptr;     // (S)
+    int32_t *d_ovf = nullptr;     // (S)
+    uint64_t *d_partial = nullptr;// (S, K) this rank's best keys, ascending
+    int32_t *d_knn = nullptr;     // (S, k)
+
+    // normalisation
+    double *d_blockstats = nullptr; // (nblocks, 2, LD)
+    int nblocks_update = 0;
+    double *d_stats = nullptr;      // (2, LD): sum, sum of squares (all-reduced by the caller when partitioned)
+
+    // timing
+    bool timing = false;
+    std::vector<gh_timer_slot> timers;
+};
+
+// RAII-free helper: records start/stop events around a launch when timing is on.
+struct gh_scope {
+    gh_engine *h;
+    int slot = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    gh_scope(gh_engine *h_, const char *name);
+    ~gh_scope();
+};
+
+// knn.hip
+gh_status gh_knn_local(gh_engine *h);                      // d_sampled -> d_partial
+gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -> d_knn
+// forces.hip
+gh_status gh_launch_intersect(gh_engine *h);               // d_sampled, d_knn -> d_acc/d_touched
+gh_status gh_launch_inter_cleanup(gh_engine *h);
+gh_status gh_launch_spring_update(gh_engine *h);           // -> d_new, d_stats
+gh_status gh_launch_spring_only(gh_engine *h, float *d_F); // F (n, LD), own rows
+gh_status gh_launch_inter_to_dense(gh_engine *h, float *d_F);
+gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi);
+gh_status gh_launch_normalise(gh_engine *h);               // d_new, d_stats -> d_pos rows
+gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD);
+gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD);
+gh_status gh_launch_sample(gh_engine *h);                  // device sampler -> d_sampled
+gh_status gh_launch_arange(gh_engine *h);
+
+#define GH_HIP(call)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            h->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
+            return GH_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+#define GH_LAUNCH_CHECK()                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) {                                                             \
+            h->err = std::string("kernel launch: ") + hipGetErrorString(e_);                \
+            return GH_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)

@@ -1,0 +1,446 @@
+// Spring attraction, intersection repulsion, integration and normalisation: the work of
+// _compute_spring_forces (reference pt.py:595-636), _compute_intersection_forces +
+// _check_line_intersections (pt.py:638-774) and the tail of update_positions
+// (pt.py:796-804), plus the sampler that stands in for torch.randperm (pt.py:409).
+#include "common.h"
+#include "engine.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------
+// Spring force on one vertex, pull style: the vertex walks its own neighbour list and
+// nobody else writes its row, so there are no atomics and the sum is reproducible.
+// The list is stored in the reference's summation order (all edges where the vertex
+// is the first endpoint, then all where it is the second, each in edge order:
+// the two sequential index_add_ calls of pt.py:633-634).  For a neighbour y of x
+//   diff = p_y - p_x,  dist = |diff| + 1e-6,  f = (-k_attr * (dist - L_min)) * (diff / dist)
+// which equals +f of pt.py:629 when x is the first endpoint and -f when it is the
+// second, bit for bit (negation commutes with every rounding involved).
+template <int D, int LD>
+__device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const int32_t *__restrict__ adj,
+                                            int beg, int end, const float *px, float L_min, float neg_k, float *F) {
+#pragma unroll
+    for (int d = 0; d < LD; ++d) F[d] = 0.0f;
+    for (int j = beg; j < end; ++j) {
+        const int64_t y = adj[j];
+        float py[LD], diff[D];
+        gh_load_row<LD>(pos, y, py);
+#pragma unroll
+        for (int d = 0; d < D; ++d) diff[d] = py[d] - px[d];
+        const float dist = sqrtf(gh_sumsq<D>(diff)) + 1e-6f;
+        const float fm = neg_k * (dist - L_min);
+#pragma unroll
+        for (int d = 0; d < D; ++d) F[d] = F[d] + fm * (diff[d] / dist);
+    }
+}
+
+// Fused spring + combine (pt.py:782, 796-799): new = pos + (F_spring + F_inter) for the
+// rows [row_lo, row_lo + rows), and per-workgroup column sums / sums of squares in fp64.
+// MODE 0: fused update.  MODE 1: only write the spring forces (per-phase entry point).
+template <int D, int LD, int MODE>
+__global__ __launch_bounds__(256) void spring_update_kernel(
+    const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
+    int64_t row_lo, int64_t rows, float L_min, float neg_k, const double *__restrict__ acc,
+    const int32_t *__restrict__ tflag, float *__restrict__ out, double *__restrict__ blockstats) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double sx[LD], sxx[LD];
+#pragma unroll
+    for (int d = 0; d < LD; ++d) { sx[d] = 0.0; sxx[d] = 0.0; }
+    if (i < rows) {
+        const int64_t x = row_lo + i;
+        float px[LD], F[LD];
+        gh_load_row<LD>(pos, x, px);
+        spring_pull<D, LD>(pos, adj, rowptr[i], rowptr[i + 1], px, L_min, neg_k, F);
+        if (MODE == 1) {
+            gh_store_row<LD>(out, x, F);
+        } else {
+            float nw[LD];
+            const bool touched = tflag[x] != 0;
+#pragma unroll
+            for (int d = 0; d < LD; ++d) {
+                const float fi = touched ? (float)acc[x * LD + d] : 0.0f;
+                const float tot = F[d] + fi;
+                nw[d] = px[d] + tot;
+                sx[d] = (double)nw[d];
+                sxx[d] = (double)nw[d] * (double)nw[d];
+            }
+            gh_store_row<LD>(out, i, nw);
+        }
+    }
+    if (MODE == 0) {
+        __shared__ double red[4][2 * LD];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+        for (int d = 0; d < LD; ++d) {
+            const double a = gh_wave_sum(sx[d]), b = gh_wave_sum(sxx[d]);
+            if (lane == 0) { red[w][d] = a; red[w][LD + d] = b; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * LD) {
+            const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+            blockstats[(int64_t)blockIdx.x * 2 * LD + threadIdx.x] = v;
+        }
+    }
+}
+
+// Any D: one thread per vertex, rows in global memory, same arithmetic and order.
+template <int MODE>
+__global__ __launch_bounds__(256) void spring_update_generic_kernel(
+    const float *__restrict__ pos, int D, int LD, const int32_t *__restrict__ rowptr,
+    const int32_t *__restrict__ adj, int64_t row_lo, int64_t rows, float L_min, float neg_k,
+    const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out,
+    float *__restrict__ scratch /* (rows, LD) diff scratch */) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const int64_t x = row_lo + i;
+    float *diff = scratch + i * LD;
+    float *dst = MODE == 1 ? out + x * LD : out + i * LD;
+    for (int d = 0; d < LD; ++d) dst[d] = 0.0f;
+    for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+        const int64_t y = adj[j];
+        for (int d = 0; d < D; ++d) diff[d] = pos[y * LD + d] - pos[x * LD + d];
+        const float dist = sqrtf(gh_sumsq_rt(diff, D)) + 1e-6f;
+        const float fm = neg_k * (dist - L_min);
+        for (int d = 0; d < D; ++d) dst[d] = dst[d] + fm * (diff[d] / dist);
+    }
+    if (MODE == 0) {
+        const bool touched = tflag[x] != 0;
+        for (int d = 0; d < D; ++d) {
+            const float fi = touched ? (float)acc[x * LD + d] : 0.0f;
+            const float tot = dst[d] + fi;
+            dst[d] = pos[x * LD + d] + tot;
+        }
+    }
+}
+
+// Column sums for the generic path: one workgroup per column chunk, fixed order.
+__global__ __launch_bounds__(256) void column_stats_kernel(const float *__restrict__ x, int64_t rows, int D, int LD,
+                                                          double *__restrict__ stats) {
+    const int d = blockIdx.x;
+    double sx = 0.0, sxx = 0.0;
+    for (int64_t i = threadIdx.x; i < rows; i += blockDim.x) {
+        const double v = (double)x[i * LD + d];
+        sx += v;
+        sxx += v * v;
+    }
+    __shared__ double red[2][4];
+    const double a = gh_wave_sum(sx), b = gh_wave_sum(sxx);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        stats[d] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        stats[LD + d] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    }
+    if (d == 0 && threadIdx.x == 0)
+        for (int p = D; p < LD; ++p) { stats[p] = 0.0; stats[LD + p] = 0.0; }
+}
+
+// Fixed-order reduction of the per-workgroup partials -> (2, LD) sums.
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const double *__restrict__ blockstats, int nblocks, int LD,
+                                                          double *__restrict__ stats) {
+    const int c = blockIdx.x;  // column of the (2*LD) record
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += blockstats[(int64_t)b * 2 * LD + c];
+    __shared__ double red[4];
+    const double a = gh_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) stats[c] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// pt.py:802-804: centre by the column mean, divide by (unbiased std + 1e-6).
+// stats = global (sum, sum of squares) over all n rows; every thread derives the same
+// mean / std from them.  Writes rows [row_lo, row_lo+rows) of pos.
+__global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict__ nw, int64_t rows, int64_t row_lo,
+                                                       int D, int LD, int64_t n, const double *__restrict__ stats,
+                                                       float *__restrict__ pos) {
+    extern __shared__ float ms[];  // mean[LD], std[LD]
+    for (int d = threadIdx.x; d < LD; d += blockDim.x) {
+        float mean = 0.0f, sd = 1.0f;
+        if (d < D) {
+            const double sum = stats[d], sq = stats[LD + d];
+            const double m = sum / (double)n;
+            double var = (sq - sum * m) / (double)(n - 1);
+            if (var < 0.0) var = 0.0;
+            mean = (float)m;
+            sd = (float)sqrt(var) + 1e-6f;
+        }
+        ms[d] = mean;
+        ms[LD + d] = sd;
+    }
+    __syncthreads();
+    const int64_t total = rows * LD;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(t % LD);
+        const float c = nw[t] - ms[d];
+        pos[row_lo * LD + t] = d < D ? c / ms[LD + d] : 0.0f;
+    }
+}
+
+// pt.py:796-799 with given force arrays (per-phase entry point gh_integrate_normalise).
+__global__ __launch_bounds__(256) void integrate_given_kernel(const float *__restrict__ pos,
+                                                             const float *__restrict__ Fs,
+                                                             const float *__restrict__ Fi, int64_t total,
+                                                             float *__restrict__ nw) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const float tot = Fs[t] + Fi[t];
+    nw[t] = pos[t] + tot;
+}
+
+// ---------------------------------------------------------------------------------
+// Intersection repulsion (pt.py:638-774).  One thread per candidate pair
+// (i = sampled[r], j = knn[r][c]): keep i < j (pt.py:672), drop pairs sharing a vertex
+// (pt.py:685-692), keep pairs whose projections on coordinates 0,1 strictly cross
+// (pt.py:760-772); then each of the four endpoints x gets
+//   k_inter * (x - c) / (|x - c| + 1e-6)^2,   c = (((p1 + p2) + q1) + q2) / 4
+// (pt.py:722-734).  Contributions are summed in fp64 atomics: with the handful of terms
+// a vertex receives the fp64 sum is exact, hence independent of arrival order.
+__device__ __forceinline__ float orient2d(const float *a, const float *b, const float *c) {
+    return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
+}
+
+__global__ __launch_bounds__(256) void intersect_kernel(const float *__restrict__ pos, int D, int LD,
+                                                       const int32_t *__restrict__ edges,
+                                                       const int32_t *__restrict__ sampled,
+                                                       const int32_t *__restrict__ knn, int64_t S, int k,
+                                                       float k_inter, double *__restrict__ acc,
+                                                       int32_t *__restrict__ tflag, int32_t *__restrict__ touched,
+                                                       int32_t *__restrict__ tcount, float *__restrict__ scratch) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= S * k) return;
+    const int64_t r = t / k;
+    const int32_t i = sampled[r], j = knn[t];
+    if (!(i < j)) return;
+    const int32_t v[4] = {edges[2 * (int64_t)i], edges[2 * (int64_t)i + 1], edges[2 * (int64_t)j], edges[2 * (int64_t)j + 1]};
+    if (v[0] == v[2] || v[0] == v[3] || v[1] == v[2] || v[1] == v[3]) return;
+    if (D < 2) return;
+    const float *p1 = pos + (int64_t)v[0] * LD, *p2 = pos + (int64_t)v[1] * LD;
+    const float *q1 = pos + (int64_t)v[2] * LD, *q2 = pos + (int64_t)v[3] * LD;
+    const float o1 = orient2d(p1, p2, q1), o2 = orient2d(p1, p2, q2);
+    const float o3 = orient2d(q1, q2, p1), o4 = orient2d(q1, q2, p2);
+    if (!(o1 * o2 < 0.0f && o3 * o4 < 0.0f)) return;
+    float *diff = scratch + t * LD;  // per-thread scratch row (any D)
+    for (int role = 0; role < 4; ++role) {
+        const float *x = pos + (int64_t)v[role] * LD;
+        for (int d = 0; d < D; ++d) {
+            const float cen = (((p1[d] + p2[d]) + q1[d]) + q2[d]) / 4.0f;
+            diff[d] = x[d] - cen;
+        }
+        const float dist = sqrtf(gh_sumsq_rt(diff, D)) + 1e-6f;
+        const float dd = dist * dist;
+        for (int d = 0; d < D; ++d) atomicAdd(&acc[(int64_t)v[role] * LD + d], (double)((k_inter * diff[d]) / dd));
+        if (atomicExch(&tflag[v[role]], 1) == 0) touched[atomicAdd(tcount, 1)] = v[role];
+    }
+}
+
+// acc (double) -> dense fp32 F for the touched vertices (per-phase entry point).
+__global__ void inter_to_dense_kernel(const double *__restrict__ acc, const int32_t *__restrict__ touched,
+                                      const int32_t *__restrict__ tcount, int LD, float *__restrict__ F) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= (int64_t)(*tcount) * LD) return;
+    const int64_t x = touched[t / LD];
+    const int d = (int)(t % LD);
+    F[x * LD + d] = (float)acc[x * LD + d];
+}
+
+// Zero what the intersection phase touched (keeps acc / tflag all-zero between iterations).
+__global__ void inter_cleanup_kernel(double *__restrict__ acc, int32_t *__restrict__ tflag,
+                                     const int32_t *__restrict__ touched, const int32_t *__restrict__ tcount, int LD) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= (int64_t)(*tcount) * LD) return;
+    const int64_t x = touched[t / LD];
+    const int d = (int)(t % LD);
+    acc[x * LD + d] = 0.0;
+    if (d == 0) tflag[x] = 0;
+}
+
+__global__ void reset_counter_kernel(int32_t *c) { *c = 0; }
+
+// ---------------------------------------------------------------------------------
+// (n, D) <-> (n, LD) copies for the host boundary.
+__global__ void pad_kernel(const float *__restrict__ src, int64_t n, int D, int LD, float *__restrict__ dst) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * LD) return;
+    const int64_t i = t / LD;
+    const int d = (int)(t % LD);
+    dst[t] = d < D ? src[i * D + d] : 0.0f;
+}
+__global__ void unpad_kernel(const float *__restrict__ src, int64_t n, int D, int LD, float *__restrict__ dst) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= n * D) return;
+    const int64_t i = t / D;
+    const int d = (int)(t % D);
+    dst[t] = src[i * LD + d];
+}
+
+// ---------------------------------------------------------------------------------
+// Device sampler: S distinct edge ids, the first S values of a keyed pseudo-random
+// permutation of [0, E) (stands in for torch.randperm(E)[:S], pt.py:409).  A 4-round
+// Feistel network on ceil(log2 E) bits with cycle walking: every thread computes its
+// own id, no dedupe pass, same ids on every rank for the same (seed, iteration).
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__global__ void sample_kernel(int64_t E, int64_t S, uint64_t seed, uint64_t iter, int32_t *__restrict__ sampled) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= S) return;
+    int bits = 1;
+    while (((int64_t)1 << bits) < E) ++bits;
+    const int lb = bits / 2, hb = bits - lb;  // low / high half widths
+    const uint64_t lmask = ((uint64_t)1 << lb) - 1, hmask = ((uint64_t)1 << hb) - 1;
+    const uint64_t key = seed * 0x9E3779B97F4A7C15ull + iter * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull;
+    uint64_t x = (uint64_t)t;
+    do {
+        uint64_t lo = x & lmask, hi = (x >> lb) & hmask;
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            // alternate which half is modified so unequal widths stay a bijection
+            if ((rnd & 1) == 0) hi = (hi ^ mix32(key + ((uint64_t)rnd << 56) + lo)) & hmask;
+            else lo = (lo ^ mix32(key + ((uint64_t)rnd << 56) + hi)) & lmask;
+        }
+        x = (hi << lb) | lo;
+    } while ((int64_t)x >= E);
+    sampled[t] = (int32_t)x;
+}
+__global__ void arange_kernel(int64_t S, int32_t *__restrict__ sampled) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < S) sampled[t] = (int32_t)t;
+}
+
+inline unsigned grid_for(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
+
+template <int MODE>
+gh_status launch_spring(gh_engine *h, float *out) {
+    const unsigned grid = grid_for(h->rows, 256);
+    const float neg_k = -h->prm.k_attr;
+#define GH_SPRING_CASE(DD, LL)                                                                               \
+    spring_update_kernel<DD, LL, MODE><<<dim3(grid), dim3(256), 0, h->stream>>>(                             \
+        h->d_pos, h->d_rowptr, h->d_adj, h->part.row_lo, h->rows, h->prm.L_min, neg_k, h->d_acc, h->d_tflag, \
+        out, h->d_blockstats)
+    switch (h->D) {
+        case 2: GH_SPRING_CASE(2, 4); break;
+        case 3: GH_SPRING_CASE(3, 4); break;
+        case 4: GH_SPRING_CASE(4, 4); break;
+        case 8: GH_SPRING_CASE(8, 8); break;
+        case 16: GH_SPRING_CASE(16, 16); break;
+        default:
+            spring_update_generic_kernel<MODE><<<dim3(grid), dim3(256), 0, h->stream>>>(
+                h->d_pos, h->D, h->LD, h->d_rowptr, h->d_adj, h->part.row_lo, h->rows, h->prm.L_min, neg_k,
+                h->d_acc, h->d_tflag, out, h->d_tmpF2);
+    }
+#undef GH_SPRING_CASE
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+bool spring_is_templated(int D) { return D == 2 || D == 3 || D == 4 || D == 8 || D == 16; }
+
+}  // namespace
+
+gh_status gh_launch_spring_update(gh_engine *h) {
+    if (h->rows == 0) {
+        GH_HIP(hipMemsetAsync(h->d_stats, 0, sizeof(double) * 2 * h->LD, h->stream));
+        return GH_OK;
+    }
+    {
+        gh_scope t(h, "spring_update");
+        gh_status st = launch_spring<0>(h, h->d_new);
+        if (st) return st;
+    }
+    gh_scope t(h, "stats_reduce");
+    if (spring_is_templated(h->D)) {
+        stats_reduce_kernel<<<dim3(2 * h->LD), dim3(256), 0, h->stream>>>(h->d_blockstats, h->nblocks_update, h->LD,
+                                                                          h->d_stats);
+    } else {
+        column_stats_kernel<<<dim3(h->D), dim3(256), 0, h->stream>>>(h->d_new, h->rows, h->D, h->LD, h->d_stats);
+    }
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_spring_only(gh_engine *h, float *d_F) {
+    GH_HIP(hipMemsetAsync(d_F, 0, sizeof(float) * h->n * h->LD, h->stream));
+    if (h->rows == 0) return GH_OK;
+    gh_scope t(h, "spring_only");
+    return launch_spring<1>(h, d_F);
+}
+
+gh_status gh_launch_intersect(gh_engine *h) {
+    const int64_t P = h->S * h->k;
+    if (P == 0) return GH_OK;
+    gh_scope t(h, "intersect");
+    intersect_kernel<<<dim3(grid_for(P, 256)), dim3(256), 0, h->stream>>>(
+        h->d_pos, h->D, h->LD, h->d_edges, h->d_sampled_cur, h->d_knn, h->S, h->k, h->prm.k_inter, h->d_acc,
+        h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_inter_to_dense(gh_engine *h, float *d_F) {
+    GH_HIP(hipMemsetAsync(d_F, 0, sizeof(float) * h->n * h->LD, h->stream));
+    const int64_t maxT = 4 * h->S * h->k * h->LD;
+    if (maxT == 0) return GH_OK;
+    inter_to_dense_kernel<<<dim3(grid_for(maxT, 256)), dim3(256), 0, h->stream>>>(h->d_acc, h->d_touched, h->d_tcount,
+                                                                                  h->LD, d_F);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_inter_cleanup(gh_engine *h) {
+    const int64_t maxT = 4 * h->S * h->k * h->LD;
+    if (maxT == 0) return GH_OK;
+    gh_scope t(h, "inter_cleanup");
+    inter_cleanup_kernel<<<dim3(grid_for(maxT, 256)), dim3(256), 0, h->stream>>>(h->d_acc, h->d_tflag, h->d_touched,
+                                                                                 h->d_tcount, h->LD);
+    reset_counter_kernel<<<dim3(1), dim3(1), 0, h->stream>>>(h->d_tcount);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi) {
+    // whole graph on one rank only (per-phase entry point)
+    const int64_t total = h->n * h->LD;
+    integrate_given_kernel<<<dim3(grid_for(total, 256)), dim3(256), 0, h->stream>>>(h->d_pos, d_Fs, d_Fi, total,
+                                                                                    h->d_new);
+    column_stats_kernel<<<dim3(h->D), dim3(256), 0, h->stream>>>(h->d_new, h->n, h->D, h->LD, h->d_stats);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_normalise(gh_engine *h) {
+    if (h->rows == 0) return GH_OK;
+    gh_scope t(h, "normalise");
+    const int64_t total = h->rows * h->LD;
+    unsigned grid = grid_for(total, 256);
+    if (grid > 2048) grid = 2048;
+    normalise_kernel<<<dim3(grid), dim3(256), sizeof(float) * 2 * h->LD, h->stream>>>(
+        h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD) {
+    pad_kernel<<<dim3(grid_for(h->n * h->LD, 256)), dim3(256), 0, h->stream>>>(d_src_nD, h->n, h->D, h->LD, d_dst_nLD);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD) {
+    unpad_kernel<<<dim3(grid_for(h->n * h->D, 256)), dim3(256), 0, h->stream>>>(d_src_nLD, h->n, h->D, h->LD, d_dst_nD);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_sample(gh_engine *h) {
+    gh_scope t(h, "sample");
+    sample_kernel<<<dim3(grid_for(h->S, 256)), dim3(256), 0, h->stream>>>(h->E, h->S, h->prm.seed, h->iter, h->d_sampled);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+gh_status gh_launch_arange(gh_engine *h) {
+    arange_kernel<<<dim3(grid_for(h->S, 256)), dim3(256), 0, h->stream>>>(h->S, h->d_sampled);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}

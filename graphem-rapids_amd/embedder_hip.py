@@ -1,0 +1,254 @@
+"""GraphEmbedderHIP: host-side mirror of the reference's GraphEmbedderPyTorch
+(graphem_rapids/backends/embedder_pytorch.py, "pt.py") whose layout loop runs in
+hand-written HIP kernels on MI355X through the C ABI of include/graphem_hip.h.
+
+Same constructor arguments, attributes, methods and exception types as pt.py:51-67,
+776-844.  The loop body never touches PyTorch: torch is used for the
+device handle, the zero-copy tensor view of the positions and the parity sampler.
+"""
+import logging
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _native
+
+logger = logging.getLogger(__name__)
+
+
+class _DeviceArray:
+    """Zero-copy description of engine memory for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner  # keeps the engine alive while a view exists
+
+
+def device_view(ptr, shape, dtype, device, owner):
+    typestr = {torch.float32: "<f4", torch.float64: "<f8", torch.int32: "<i4", torch.int64: "<i8",
+               torch.uint8: "|u1"}[dtype]
+    return torch.as_tensor(_DeviceArray(ptr, shape, typestr, owner), device=device)
+
+
+class GraphEmbedderHIP:
+    """Force-directed graph embedder; drop-in for GraphEmbedderPyTorch (pt.py:27-49)."""
+
+    def __init__(
+        self,
+        adjacency,
+        n_components=2,
+        device=None,
+        dtype=torch.float32,
+        L_min=1.0,
+        k_attr=0.2,
+        k_inter=0.5,
+        n_neighbors=10,
+        sample_size=256,
+        batch_size=None,
+        memory_efficient=True,
+        verbose=True,
+        logger_instance=None,
+        seed=None,
+        *,
+        sampler="auto",
+        init="laplacian",
+    ):
+        """Arguments as pt.py:51-104.  Extra keyword-only arguments:
+
+        sampler : 'torch' draws each iteration's sample with torch.randperm(E)[:S] from the
+            global CPU generator exactly as the reference's CPU backend does (pt.py:409);
+            'device' uses the engine's on-GPU sampler (no host work in the loop);
+            'auto' = 'torch' up to 2**20 edges, 'device' above.
+        init : 'laplacian' (pt.py:337-379) or 'random' (the reference's own fallback,
+            pt.py:369) for graphs where eigsh is impractical.
+        """
+        if seed is not None:  # pt.py:106-111
+            np.random.seed(seed)
+            torch.manual_seed(seed)
+        self.seed = seed
+
+        # device plumbing (pt.py:113-117): the HIP engine has no CPU path
+        dev = torch.device("cuda" if device is None else device)  # invalid strings raise RuntimeError here
+        if dev.type != "cuda":
+            raise RuntimeError(f"GraphEmbedderHIP needs a GPU device, got '{dev}' (no CPU fallback)")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else 0)
+
+        if logger_instance is not None:
+            self.logger = logger_instance
+        else:
+            self.logger = logger
+            if verbose:
+                logging.basicConfig(level=logging.INFO)
+
+        adjacency = self._validate_adjacency(adjacency)
+        self.adjacency = adjacency
+        self.n = adjacency.shape[0]
+        self.n_components = n_components
+        if dtype not in (torch.float32, torch.float64, torch.float16):
+            raise ValueError(f"unsupported dtype {dtype}")
+        self.dtype = dtype  # storage dtype of the tensor views; the kernels compute in float32
+        self.L_min = L_min
+        self.k_attr = k_attr
+        self.k_inter = k_inter
+        self.n_neighbors = n_neighbors
+        self.memory_efficient = memory_efficient
+        self.batch_size = batch_size
+
+        if n_components <= 0:  # pt.py:143-146
+            raise ValueError(f"Number of components must be positive, got {n_components}")
+        if k_attr < 0:
+            raise ValueError(f"Attractive force constant k_attr must be non-negative, got {k_attr}")
+        self.verbose = verbose
+
+        edges = self._extract_edges_from_adjacency(adjacency)
+        self.n_edges = len(edges)
+        self.sample_size = min(sample_size, self.n_edges)  # pt.py:156
+        self._edges_np = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        self.edges = torch.from_numpy(self._edges_np.astype(np.int64))  # (E, 2) integer tensor like pt.py:159
+        self._has_pykeops = False  # attribute read by callers (pt.py:162); KeOps is never used here
+        if self.batch_size is None:
+            self.batch_size = self.n  # the engine never chunks the query set
+
+        if sampler not in ("auto", "torch", "device"):
+            raise ValueError(f"Invalid sampler: {sampler}")
+        if sampler == "auto":
+            sampler = "torch" if self.n_edges <= (1 << 20) else "device"
+        self.sampler = sampler
+
+        self._engine = _native.Engine(
+            self.n, n_components, self._edges_np, L_min, k_attr, k_inter, n_neighbors, self.sample_size,
+            seed=0 if seed is None else seed, device_id=self.device.index)
+        if self.verbose:
+            self.logger.info("Initialized GraphEmbedderHIP on %s", self.device)
+            self.logger.info("Graph: %d vertices, %d edges, %dD", self.n, self.n_edges, self.n_components)
+
+        if init == "laplacian":
+            p0 = self._compute_laplacian_embedding()
+        elif init == "random":
+            p0 = (np.random.randn(self.n, self.n_components) * 0.1).astype(np.float32)
+        else:
+            raise ValueError(f"Invalid init: {init}")
+        self._engine.set_positions(p0)
+
+    # ---- construction helpers (boundary, host side) -----------------------------------
+    @staticmethod
+    def _validate_adjacency(adjacency):
+        """Any sparse / dense / array-like square matrix -> CSR (contract of pt.py:182-218)."""
+        if sp.issparse(adjacency):
+            adjacency = adjacency.tocsr()
+        elif not isinstance(adjacency, np.ndarray):
+            adjacency = np.asarray(adjacency)
+        if adjacency.ndim != 2 or adjacency.shape[0] != adjacency.shape[1]:
+            raise ValueError(f"Adjacency matrix must be square, got shape {adjacency.shape}")
+        if adjacency.shape[0] == 0:
+            raise ValueError("Adjacency matrix cannot be empty")
+        if not sp.issparse(adjacency):
+            adjacency = sp.csr_matrix(adjacency)
+        return adjacency
+
+    def _extract_edges_from_adjacency(self, adjacency):
+        """Upper triangle of the nonzero pattern as given, in CSR row order (pt.py:220-245)."""
+        rows, cols = adjacency.nonzero()
+        keep = rows < cols
+        edges = np.column_stack([rows[keep], cols[keep]])
+        if self.verbose and len(edges) == 0:
+            self.logger.warning("No edges found in adjacency matrix")
+        return edges
+
+    def _compute_laplacian_embedding(self):
+        """Spectral start: eigenvectors 1..D of the normalised Laplacian of the symmetrised,
+        unweighted graph; random fallback if the eigensolver fails (contract of pt.py:337-379)."""
+        import scipy.sparse.linalg as spla
+        from scipy.sparse.csgraph import laplacian
+        sym = sp.csr_matrix(self.adjacency + self.adjacency.transpose())
+        sym.data = np.ones_like(sym.data)
+        lap = laplacian(sym, normed=True)
+        want = self.n_components + 1
+        try:
+            _, vecs = spla.eigsh(lap, want, which="SM")
+            emb = vecs[:, 1:want]
+        except Exception as exc:  # pylint: disable=broad-exception-caught
+            self.logger.warning("Eigendecomposition failed: %s", exc)
+            emb = np.random.randn(self.n, self.n_components) * 0.1
+        return np.ascontiguousarray(emb, dtype=np.float32)
+
+    # ---- positions accessors (pt.py:324-335, 835-844) -----------------------------------
+    @property
+    def positions(self):
+        """Host numpy copy of the positions, shape (n, D)."""
+        out = self._engine.get_positions()
+        return out if self.dtype == torch.float32 else out.astype(
+            {torch.float64: np.float64, torch.float16: np.float16}[self.dtype])
+
+    @positions.setter
+    def positions(self, value):
+        if isinstance(value, torch.Tensor):
+            value = value.detach().to("cpu", torch.float32).numpy()
+        self._engine.set_positions(np.asarray(value, dtype=np.float32))
+
+    @property
+    def _positions(self):
+        """Device tensor of the positions (callers and tests read .device / .dtype / values)."""
+        self._engine.sync()
+        full = device_view(self._engine.positions_device_ptr(), (self.n, self._engine.ld), torch.float32,
+                           self.device, self._engine)
+        view = full[:, :self.n_components]
+        return view if self.dtype == torch.float32 else view.to(self.dtype)
+
+    def get_positions(self):
+        return self.positions
+
+    # ---- the loop (pt.py:776-833) -------------------------------------------------------
+    def _draw_samples(self, iterations):
+        """Sample ids for `iterations` iterations, consuming the global torch CPU generator
+        exactly as pt.py:409 does (one randperm(E) per iteration; none when S >= E)."""
+        E, S = self.n_edges, self.sample_size
+        if S >= E or self.sampler == "device":
+            return None
+        out = np.empty((iterations, S), dtype=np.int32)
+        for t in range(iterations):
+            out[t] = torch.randperm(E)[:S].numpy()
+        return out
+
+    def update_positions(self):
+        """One layout iteration (pt.py:776-806)."""
+        ids = self._draw_samples(1)
+        self._engine.step(None if ids is None else ids[0])
+
+    def run_layout(self, num_iterations=100):
+        """num_iterations iterations without host synchronisation; returns (n, D) numpy (pt.py:808-833)."""
+        if self.verbose:
+            self.logger.info("Running layout for %d iterations", num_iterations)
+        if num_iterations > 0:
+            self._engine.run(num_iterations, self._draw_samples(num_iterations))
+        return self.positions
+
+    # ---- per-phase access (used by the parity tests; same names as pt.py) ------------------
+    def _compute_spring_forces(self):
+        return self._engine.spring_forces()
+
+    def _locate_knn_midpoints(self, sampled_indices=None):
+        """(knn_indices (S, k), sampled_indices (S,)) like pt.py:381-424."""
+        if sampled_indices is None:
+            ids = self._draw_samples(1)
+            sampled_indices = np.arange(self.n_edges, dtype=np.int32) if ids is None else ids[0]
+        sampled_indices = np.asarray(sampled_indices, dtype=np.int32)
+        return self._engine.knn_midpoints(sampled_indices), sampled_indices
+
+    def _compute_intersection_forces(self, knn_indices, sampled_indices):
+        return self._engine.intersection_forces(sampled_indices, knn_indices)
+
+    def kernel_timings(self):
+        return self._engine.timings()
+
+    def display_layout(self, edge_width=1, node_size=3, node_colors=None):
+        """Plotly rendering is outside the accelerated path."""
+        if self.n_components not in (2, 3):
+            raise ValueError("Display only supports 2D or 3D embeddings")  # pt.py:846-871
+        raise NotImplementedError("display_layout is not part of the HIP backend; plot get_positions() instead")
+
+    def __repr__(self):
+        return (f"GraphEmbedderHIP(n_vertices={self.n}, n_components={self.n_components}, "
+                f"n_edges={self.n_edges}, device={self.device})")

@@ -1,0 +1,138 @@
+/*
+ * graphem_hip.h -- C ABI of the MI355X (gfx950) force-directed layout engine.
+ *
+ * This is the drop-in boundary for ONE path of sashakolpakov/graphem-rapids: the
+ * per-iteration loop behind GraphEmbedderPyTorch.run_layout().  The reference
+ * has no FFI of its own (it is 100 % Python); each entry point
+ * below cites the reference method (graphem_rapids/backends/embedder_pytorch.py,
+ * "pt.py") whose work it replaces.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host pointers unless a name says "device";
+ *   - every function returns a gh_status; gh_last_error() gives the message;
+ *   - all work is enqueued on the handle's HIP streams; only the functions
+ *     documented as blocking (copies to host, gh_sync) wait for the GPU;
+ *   - a handle is not thread-safe; distinct handles are independent;
+ *   - positions cross the boundary as (n, D) row-major float32, edges as
+ *     (E, 2) row-major int32 with u < v in the reference's edge order
+ *     (pt.py:220-245), edge ids are positions in that list.
+ */
+#ifndef GRAPHEM_HIP_H
+#define GRAPHEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gh_engine *gh_handle;
+
+typedef enum {
+    GH_OK = 0,
+    GH_ERR_INVALID = 1,     /* bad argument            -> ValueError in the Python mirror   */
+    GH_ERR_RUNTIME = 2,     /* runtime failure         -> RuntimeError                      */
+    GH_ERR_K_TOO_LARGE = 3, /* n_neighbors + 1 > E     -> RuntimeError (torch.topk, pt.py:583) */
+    GH_ERR_HIP = 4,         /* HIP API / kernel error  -> RuntimeError                      */
+    GH_ERR_NOMEM = 5        /* allocation failure      -> MemoryError                       */
+} gh_status;
+
+/* Constructor arguments of the reference that the loop reads (pt.py:51-67, 130-156). */
+typedef struct {
+    float L_min;          /* pt.py:57  */
+    float k_attr;         /* pt.py:58  */
+    float k_inter;        /* pt.py:59  */
+    int32_t n_neighbors;  /* pt.py:60, k */
+    int32_t sample_size;  /* pt.py:61, already min(sample_size, E) as pt.py:156 */
+    uint64_t seed;        /* seed of the on-device sampler (used when no sample ids are passed) */
+} gh_params;
+
+/* Row partition for multi-GPU runs (no reference counterpart).
+ * A rank integrates vertices [row_lo, row_hi) and scans edges [edge_lo, edge_hi)
+ * in the KNN phase; it still holds all n positions and all E edges.
+ * Single GPU: row_lo = 0, row_hi = n, edge_lo = 0, edge_hi = E. */
+typedef struct {
+    int64_t row_lo, row_hi;
+    int64_t edge_lo, edge_hi;
+} gh_partition;
+
+/* ---- lifetime -------------------------------------------------------------- */
+
+/* Replaces the device-side part of GraphEmbedderPyTorch.__init__ (pt.py:150-159):
+ * uploads the edge list, builds the pull lists for the spring phase, allocates all
+ * state.  part may be NULL (whole graph).  Positions start at zero. */
+gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t n_components, int64_t n_edges,
+                    const int32_t *edges, const gh_params *params, const gh_partition *part);
+void gh_destroy(gh_handle h);
+/* Message of the last failure on h (h may be NULL for a failed gh_create). */
+const char *gh_last_error(gh_handle h);
+
+/* ---- positions accessors: `positions` property / setter, get_positions
+ *      (pt.py:324-335, 835-844) ------------------------------------------------ */
+gh_status gh_set_positions(gh_handle h, const float *pos /* (n, D) host */);
+gh_status gh_get_positions(gh_handle h, float *pos /* (n, D) host, blocking */);
+/* Device view for callers that keep data on the GPU (RCCL all-gather, torch tensors):
+ * (n, ld) float32 rows, ld = gh_row_stride(h) >= D floats, columns >= D are zero. */
+float *gh_positions_device(gh_handle h);
+int32_t gh_row_stride(gh_handle h);
+
+/* ---- the loop: update_positions / run_layout (pt.py:776-806, 808-833) ------- */
+
+/* One iteration.  sampled: the S edge ids of this iteration (what
+ * torch.randperm(E)[:S] returned, pt.py:409), host pointer; NULL = draw them on the
+ * device (ignored when S >= E, where the reference uses arange(E), pt.py:412). */
+gh_status gh_step(gh_handle h, const int32_t *sampled);
+/* iters iterations without host synchronisation.  sample_stream: (iters, S) host ids
+ * or NULL for the device sampler. */
+gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_stream);
+/* Blocks until everything enqueued on h has finished. */
+gh_status gh_sync(gh_handle h);
+
+/* ---- per-phase entry points (tests, profiling).  Each runs on the CURRENT
+ *      positions, leaves them unchanged, blocks, and writes host buffers. -------- */
+
+/* _compute_spring_forces (pt.py:595-636): F (n, D). */
+gh_status gh_spring_forces(gh_handle h, float *F);
+/* _locate_knn_midpoints + _compute_knn_chunked/_compute_knn_torch (pt.py:381-424,
+ * 426-483, 543-593): knn (S, k) edge ids, column 0 already dropped (pt.py:421). */
+gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32_t *knn);
+/* _compute_intersection_forces + _check_line_intersections (pt.py:638-774): F (n, D). */
+gh_status gh_intersection_forces(gh_handle h, const int32_t *sampled, const int32_t *knn, float *F);
+/* combine + normalise (pt.py:796-804): out = normalise(pos + (Fs + Fi)); (n, D) each. */
+gh_status gh_integrate_normalise(gh_handle h, const float *Fs, const float *Fi, float *out);
+
+/* ---- multi-GPU hooks.  With a gh_partition a step is split so the
+ *      caller can run its collectives (RCCL through torch.distributed) between the
+ *      parts; all buffers are device pointers owned by the handle. ---------------- */
+
+/* Part 1: spring pull for own rows, KNN scan of own edges.  Afterwards
+ * gh_knn_partial_device() holds this rank's S x (k+1) best (dist2, id) keys. */
+gh_status gh_step_begin(gh_handle h, const int32_t *sampled);
+uint64_t *gh_knn_partial_device(gh_handle h);      /* (S, k+1) uint64 keys, ascending */
+/* Part 2: gathered = (world, S, k+1) keys from all ranks (device pointer; may alias a
+ * caller buffer).  Merges them, computes intersection forces, integrates own rows and
+ * leaves this rank's column sums in gh_stats_partial_device(). */
+gh_status gh_step_merge(gh_handle h, const uint64_t *gathered, int32_t world);
+double *gh_stats_partial_device(gh_handle h);      /* (2, ld) doubles: sum, sum of squares */
+/* Part 3: after the caller all-reduced the stats: normalise own rows in place in the
+ * full position array; the caller then all-gathers the row blocks. */
+gh_status gh_step_finish(gh_handle h);
+
+/* ---- instrumentation --------------------------------------------------------- */
+
+/* Names and accumulated GPU milliseconds of the kernels launched since the last
+ * reset, measured with HIP events on the launching stream when timing is enabled. */
+gh_status gh_timing_enable(gh_handle h, int32_t on);
+gh_status gh_timing_reset(gh_handle h);
+int32_t gh_timing_count(gh_handle h);
+gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, double *total_ms, int64_t *launches);
+
+/* Device / build facts for the host mirror's get_backend_info(). */
+int32_t gh_device_count(void);
+const char *gh_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHEM_HIP_H */

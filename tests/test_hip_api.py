@@ -1,0 +1,125 @@
+"""Drop-in behaviour of GraphEmbedderHIP / create_graphem on the GPU: the reference's own
+property tests (tests/test_pytorch_backend.py, tests/test_embedder.py, tests/test_integration.py
+in the reference tree) restated against the HIP backend."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _rr(n=50, d=4, seed=42):
+    import graphem_rapids_amd as gra
+    return gra.generate_random_regular(n=n, d=d, seed=seed)
+
+
+def test_initialization_attributes():
+    import torch
+    import graphem_rapids_amd as gra
+    emb = gra.GraphEmbedderHIP(_rr(), n_components=2, L_min=10.0, k_attr=0.5, k_inter=0.1, n_neighbors=15,
+                               sample_size=256, verbose=False)
+    assert emb.n == 50 and emb.n_components == 2 and emb.n_edges == 100
+    assert emb.sample_size == 100  # min(sample_size, E)
+    assert emb.positions.shape == (50, 2) and isinstance(emb.positions, np.ndarray)
+    assert isinstance(emb._positions, torch.Tensor) and emb._positions.device.type == "cuda"
+    assert emb._positions.dtype == torch.float32 and emb.device.type == "cuda"
+    assert tuple(emb.edges.shape) == (100, 2)
+    assert "GraphEmbedderHIP" in repr(emb)
+
+
+def test_layout_changes_positions_and_stays_finite():
+    import graphem_rapids_amd as gra
+    emb = gra.create_graphem(_rr(30, 4), n_components=3, backend="hip", verbose=False, seed=1)
+    p0 = emb.get_positions().copy()
+    out = emb.run_layout(num_iterations=5)
+    assert out.shape == (30, 3) and np.isfinite(out).all()
+    assert not np.allclose(out, p0)
+    for _ in range(3):  # repeated calls continue from the current state
+        emb.run_layout(num_iterations=2)
+        assert np.isfinite(emb.positions).all() and np.abs(emb.positions).max() < 1000
+
+
+def test_positions_setter_and_device_view():
+    import torch
+    import graphem_rapids_amd as gra
+    emb = gra.create_graphem(_rr(), n_components=2, verbose=False)
+    new = np.random.default_rng(0).standard_normal((50, 2)).astype(np.float32)
+    emb.positions = new
+    assert np.array_equal(emb.positions, new)
+    assert np.array_equal(emb._positions.cpu().numpy(), new)
+    emb.positions = torch.from_numpy(new * 2)
+    assert np.array_equal(emb.get_positions(), new * 2)
+
+
+def test_dtype_plumbing():
+    import torch
+    import graphem_rapids_amd as gra
+    emb = gra.GraphEmbedderHIP(_rr(), n_components=2, dtype=torch.float64, verbose=False)
+    assert emb._positions.dtype == torch.float64 and emb.positions.dtype == np.float64
+    emb.run_layout(2)
+    assert np.isfinite(emb.positions).all()
+
+
+def test_parameter_validation_and_errors():
+    import graphem_rapids_amd as gra
+    adj = _rr()
+    with pytest.raises(ValueError):
+        gra.GraphEmbedderHIP(adj, n_components=0, verbose=False)
+    with pytest.raises(ValueError):
+        gra.GraphEmbedderHIP(adj, n_components=2, k_attr=-1.0, verbose=False)
+    with pytest.raises(RuntimeError):
+        gra.GraphEmbedderHIP(adj, n_components=2, device="invalid_device", verbose=False)
+    with pytest.raises(RuntimeError):
+        gra.GraphEmbedderHIP(adj, n_components=2, device="cpu", verbose=False)
+    with pytest.raises(ValueError):
+        gra.GraphEmbedderHIP(np.zeros((3, 4)), verbose=False)
+    with pytest.raises((ValueError, RuntimeError)):  # all-zero adjacency (reference: ValueError|RuntimeError)
+        gra.create_graphem(sp.csr_matrix((10, 10)), n_components=2, verbose=False).run_layout(2)
+    with pytest.raises(ValueError):
+        gra.create_graphem(adj, backend="nonsense")
+
+
+def test_reproducibility_same_seed():
+    import graphem_rapids_amd as gra
+    adj = _rr(60, 4, 3)
+    a = gra.create_graphem(adj, n_components=2, verbose=False, seed=123, init="random").run_layout(6)
+    b = gra.create_graphem(adj, n_components=2, verbose=False, seed=123, init="random").run_layout(6)
+    assert np.array_equal(a, b)
+
+
+def test_matches_reference_trajectory_through_the_public_api():
+    """create_graphem(...).run_layout(5) with the reference's own sample stream and start."""
+    import torch
+    import graphem_rapids_amd as gra
+    from conftest import load_golden
+    g = load_golden("c1_er1000")
+    n = int(g["n"])
+    e = g["edges"]
+    adj = sp.csr_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(n, n))
+    adj = adj + adj.T
+    emb = gra.create_graphem(adj, n_components=3, backend="hip", verbose=False, sampler="torch", init="random")
+    assert np.array_equal(emb._edges_np, e)
+    emb.positions = g["p0"]
+    torch.manual_seed(0)  # the reference seeded with 0 and drew nothing before its first randperm
+    emb.run_layout(5)
+    assert np.abs(emb.positions - g["pos_5"]).max() <= 1e-3
+    seeds = gra.graphem_seed_selection(emb, 10, num_iterations=0)
+    assert len(seeds) == 10
+
+
+def test_disconnected_graphs():
+    import graphem_rapids_amd as gra
+    tri = np.array([[0, 1, 1, 0, 0, 0], [1, 0, 1, 0, 0, 0], [1, 1, 0, 0, 0, 0],
+                    [0, 0, 0, 0, 1, 1], [0, 0, 0, 1, 0, 1], [0, 0, 0, 1, 1, 0]])
+    emb = gra.GraphEmbedderHIP(tri, n_components=2, L_min=10.0, k_attr=0.5, k_inter=0.1, n_neighbors=5,
+                               sample_size=6, verbose=False)
+    emb.run_layout(num_iterations=2)
+    assert emb.positions.shape == (6, 2) and np.isfinite(emb.positions).all()
+
+
+def test_high_dimension_random_init_path():
+    """D >= n-1 makes eigsh fail -> the random-start fallback, as in the reference's D=250/300 tests."""
+    import graphem_rapids_amd as gra
+    emb = gra.GraphEmbedderHIP(_rr(100, 4, 1), n_components=250, n_neighbors=5, sample_size=32, verbose=False)
+    out = emb.run_layout(2)
+    assert out.shape == (100, 250) and np.isfinite(out).all()
