@@ -19,7 +19,7 @@ SYMBOLS = [
     "gh_row_stride", "gh_step", "gh_run", "gh_sync", "gh_spring_forces", "gh_knn_midpoints",
     "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_step_merge",
     "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
-    "gh_timing_get", "gh_device_count", "gh_version",
+    "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts",
 ]
 
 
@@ -85,6 +85,8 @@ def load():
     L.gh_timing_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(i64)]
     L.gh_timing_get.restype = ctypes.c_int
+    L.gh_knn_last_counts.argtypes = [vp, vp, vp, vp]
+    L.gh_knn_last_counts.restype = ctypes.c_int
     L.gh_device_count.argtypes = []
     L.gh_device_count.restype = i32
     L.gh_version.argtypes = []
@@ -230,6 +232,12 @@ class Engine:
 
     def stats_partial_device_ptr(self):
         return self.lib.gh_stats_partial_device(self.handle)
+
+    def knn_last_counts(self):
+        """(subset_counts, final_counts, overflow) of the last KNN search, each (S,) int32."""
+        a, b, c = (np.zeros(self.S, dtype=np.int32) for _ in range(3))
+        self._chk(self.lib.gh_knn_last_counts(self.handle, ptr(a), ptr(b), ptr(c)))
+        return a, b, c
 
     # instrumentation
     def timing_enable(self, on=True):

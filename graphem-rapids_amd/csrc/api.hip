@@ -19,13 +19,13 @@ gh_scope::gh_scope(gh_engine *h_, const char *name) : h(h_) {
         h->timers.back().name = name;
         slot = (int)h->timers.size() - 1;
     }
-    hipEventCreate(&a);
-    hipEventCreate(&b);
-    hipEventRecord(a, h->stream);
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, h->stream);
 }
 gh_scope::~gh_scope() {
     if (slot < 0) return;
-    hipEventRecord(b, h->stream);
+    (void)hipEventRecord(b, h->stream);
     h->timers[slot].pending.emplace_back(a, b);
 }
 
@@ -33,10 +33,10 @@ static void resolve_timers(gh_engine *h) {
     for (auto &t : h->timers) {
         for (auto &p : t.pending) {
             float ms = 0.f;
-            hipEventSynchronize(p.second);
+            (void)hipEventSynchronize(p.second);
             if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) { t.total_ms += ms; t.launches += 1; }
-            hipEventDestroy(p.first);
-            hipEventDestroy(p.second);
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
         }
         t.pending.clear();
     }
@@ -75,10 +75,10 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_new, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_tau, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_partial, h->d_knn, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_knn, h->d_first_edge, h->d_mid, h->d_Fs, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
-        if (p) hipFree(p);
-    if (h->stream) hipStreamDestroy(h->stream);
+        if (p) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
 }
 
 // ---- lifetime ----------------------------------------------------------------------
@@ -149,12 +149,30 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         }
     }
 
+    // Edges sorted by first endpoint (always true for the reference's CSR-order edge list):
+    // the edges a row owns are then contiguous and the spring kernel can emit their midpoints.
+    bool sorted = true;
+    for (int64_t e = 1; e < E && sorted; ++e) sorted = edges[2 * e] >= edges[2 * (e - 1)];
+    std::vector<int32_t> first_edge((size_t)h->rows + 1, 0);
+    if (sorted) {
+        int64_t e = 0;
+        for (int64_t i = 0; i <= h->rows; ++i) {
+            const int64_t x = lo + i;
+            while (e < E && edges[2 * e] < x) ++e;
+            first_edge[(size_t)i] = (int32_t)e;
+        }
+        h->fused_mid = first_edge[0] == h->part.edge_lo && first_edge[(size_t)h->rows] == h->part.edge_hi;
+    }
+
     const size_t nLD = (size_t)n * h->LD, S = (size_t)h->S;
     gh_status st;
 #define GH_A(p, count, zero) if ((st = dev_alloc(h, &h->p, (count), (zero))) != GH_OK) return bail(st)
     GH_A(d_edges, (size_t)E * 2, false);
     GH_A(d_rowptr, (size_t)h->rows + 1, false);
     GH_A(d_adj, (size_t)h->adj_len, false);
+    GH_A(d_first_edge, (size_t)h->rows + 1, true);
+    GH_A(d_mid, (size_t)(h->part.edge_hi - h->part.edge_lo) * h->LD, true);
+    GH_A(d_Fs, (size_t)h->rows * h->LD, true);
     GH_A(d_pos, nLD, true);
     GH_A(d_new, (size_t)h->rows * h->LD, true);
     GH_A(d_tmpF, nLD, true);
@@ -165,11 +183,12 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_touched, 4 * S * (size_t)h->k, false);
     GH_A(d_tcount, 1, true);
     GH_A(d_sampled, S, true);
-    GH_A(d_q, S * h->LD, true);
+    GH_A(d_q, S * (size_t)(h->LD + 4), true);
     GH_A(d_tau, S, true);
     GH_A(d_cand, S * GH_CAND_CAP, false);
-    GH_A(d_cnt, S, true);
+    GH_A(d_cnt, S * GH_CNT_STRIDE, true);
     GH_A(d_ovf, S, true);
+    GH_A(d_dbg_cnt, 2 * S, true);
     GH_A(d_partial, S * (size_t)h->K, true);
     GH_A(d_knn, S * (size_t)h->k, true);
     GH_A(d_iscratch, S * (size_t)h->k * h->LD, false);
@@ -184,6 +203,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     if (!up(h->d_edges, edges, sizeof(int32_t) * 2 * (size_t)E) ||
         !up(h->d_rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size()) ||
         !up(h->d_adj, adj.data(), sizeof(int32_t) * (size_t)h->adj_len) ||
+        !up(h->d_first_edge, first_edge.data(), sizeof(int32_t) * first_edge.size()) ||
         hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "upload of the graph failed";
         return bail(GH_ERR_HIP);
@@ -194,8 +214,8 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
 
 extern "C" void gh_destroy(gh_handle h) {
     if (!h) return;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
     resolve_timers(h);
     free_all(h);
     delete h;
@@ -256,12 +276,15 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
     return gh_launch_sample(h);
 }
 
-static gh_status step_begin(gh_engine *h) { return gh_knn_local(h); }
+static gh_status step_begin(gh_engine *h) {
+    GH_TRY(gh_launch_spring_mid(h));
+    return gh_knn_local(h);
+}
 
 static gh_status step_merge(gh_engine *h, const uint64_t *gathered, int world) {
     GH_TRY(gh_knn_merge(h, gathered, world));
     GH_TRY(gh_launch_intersect(h));
-    GH_TRY(gh_launch_spring_update(h));
+    GH_TRY(gh_launch_integrate(h));
     GH_TRY(gh_launch_inter_cleanup(h));
     return GH_OK;
 }
@@ -354,6 +377,7 @@ extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32
     GH_TRY(check_k(h));
     if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
     GH_TRY(set_sample(h, sampled, nullptr));
+    GH_TRY(gh_launch_mid_only(h));
     GH_TRY(gh_knn_local(h));
     GH_TRY(gh_knn_merge(h, h->d_partial, 1));
     GH_HIP(hipMemcpyAsync(knn, h->d_knn, sizeof(int32_t) * (size_t)h->S * h->k, hipMemcpyDeviceToHost, h->stream));
@@ -412,8 +436,8 @@ extern "C" gh_status gh_timing_reset(gh_handle h) {
 }
 extern "C" int32_t gh_timing_count(gh_handle h) {
     if (!h) return 0;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
     resolve_timers(h);
     return (int32_t)h->timers.size();
 }
@@ -423,6 +447,16 @@ extern "C" gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, do
     if (name) *name = h->timers[(size_t)i].name.c_str();
     if (total_ms) *total_ms = h->timers[(size_t)i].total_ms;
     if (launches) *launches = h->timers[(size_t)i].launches;
+    return GH_OK;
+}
+
+extern "C" gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final_counts, int32_t *overflow) {
+    GH_TRY(check_handle(h));
+    const size_t bytes = sizeof(int32_t) * (size_t)h->S;
+    if (subset_counts) GH_HIP(hipMemcpyAsync(subset_counts, h->d_dbg_cnt, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (final_counts) GH_HIP(hipMemcpyAsync(final_counts, h->d_dbg_cnt + h->S, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (overflow) GH_HIP(hipMemcpyAsync(overflow, h->d_ovf, bytes, hipMemcpyDeviceToHost, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));
     return GH_OK;
 }
 

@@ -11,6 +11,9 @@
 #define GH_CAND_CAP 4096
 #define GH_SEL_BUF 4096
 #define GH_SEL_CHUNK 2048
+// Candidate counters are padded to one per 128-byte line: adjacent counters serialise their
+// returning atomics on one L2 line (~11 ns each, measured: 16 K appends per line cost 180 us).
+#define GH_CNT_STRIDE 32
 // Below this many reference edges the per-query block kernel scans everything itself.
 #define GH_SCAN_MIN_EDGES 16384
 
@@ -39,6 +42,10 @@ struct gh_engine {
     int32_t *d_rowptr = nullptr;  // (rows + 1) pull lists of own rows, reference summation order
     int32_t *d_adj = nullptr;     // neighbours
     int64_t adj_len = 0;
+    int32_t *d_first_edge = nullptr; // (rows + 1) first edge id of each own row (edge list sorted by first endpoint)
+    bool fused_mid = false;       // own edge range == edges owned by own rows: spring kernel writes midpoints
+    float *d_mid = nullptr;       // (edge_hi - edge_lo, LD) midpoints of the own edges, current iteration
+    float *d_Fs = nullptr;        // (rows, LD) spring forces of the own rows
 
     // state
     float *d_pos = nullptr;       // (n, LD)
@@ -59,11 +66,12 @@ struct gh_engine {
     int32_t *d_stream_ids = nullptr;  // (iters, S) uploaded sample stream of gh_run
     size_t stream_ids_cap = 0;
     float *d_iscratch = nullptr;  // (S * k, LD) per-pair scratch of the intersection kernel
-    float *d_q = nullptr;         // (S, LD) query midpoints
+    float *d_q = nullptr;         // (S, QS) query records: midpoint coordinates + tau (knn.hip gh_qs)
     float *d_tau = nullptr;       // (S) squared-distance thresholds
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
-    int32_t *d_cnt = nullptr;     // (S)
+    int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line
     int32_t *d_ovf = nullptr;     // (S)
+    int32_t *d_dbg_cnt = nullptr; // (2, S) candidate-list lengths seen by the last subset / final select
     uint64_t *d_partial = nullptr;// (S, K) this rank's best keys, ascending
     int32_t *d_knn = nullptr;     // (S, k)
 
@@ -92,7 +100,9 @@ gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -
 // forces.hip
 gh_status gh_launch_intersect(gh_engine *h);               // d_sampled, d_knn -> d_acc/d_touched
 gh_status gh_launch_inter_cleanup(gh_engine *h);
-gh_status gh_launch_spring_update(gh_engine *h);           // -> d_new, d_stats
+gh_status gh_launch_spring_mid(gh_engine *h);              // -> d_Fs, d_mid
+gh_status gh_launch_mid_only(gh_engine *h);                // -> d_mid
+gh_status gh_launch_integrate(gh_engine *h);               // d_Fs, d_acc -> d_new, d_stats
 gh_status gh_launch_spring_only(gh_engine *h, float *d_F); // F (n, LD), own rows
 gh_status gh_launch_inter_to_dense(gh_engine *h, float *d_F);
 gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi);

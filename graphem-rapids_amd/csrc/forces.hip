@@ -16,85 +16,147 @@ namespace {
 //   diff = p_y - p_x,  dist = |diff| + 1e-6,  f = (-k_attr * (dist - L_min)) * (diff / dist)
 // which equals +f of pt.py:629 when x is the first endpoint and -f when it is the
 // second, bit for bit (negation commutes with every rounding involved).
-template <int D, int LD>
+template <int D, int LD, bool WRITE_MID>
 __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const int32_t *__restrict__ adj,
-                                            int beg, int end, const float *px, float L_min, float neg_k, float *F) {
+                                            int beg, int end, int64_t self, const float *px, float L_min,
+                                            float neg_k, float *F, float *__restrict__ mid, int64_t mid_row0,
+                                            int nfirst) {
+    // Neighbours are fetched C at a time so C independent row gathers are in flight per lane;
+    // the forces are still accumulated strictly in list order.  The first nfirst neighbours
+    // are the edges (self, y) with self < y: their midpoints (pt.py:785) cost nothing here,
+    // both endpoints being in registers, and spare the KNN scan its own random gathers.
+    constexpr int C = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;
 #pragma unroll
     for (int d = 0; d < LD; ++d) F[d] = 0.0f;
-    for (int j = beg; j < end; ++j) {
-        const int64_t y = adj[j];
-        float py[LD], diff[D];
-        gh_load_row<LD>(pos, y, py);
+    for (int base = beg; base < end; base += C) {
+        int64_t ys[C];
 #pragma unroll
-        for (int d = 0; d < D; ++d) diff[d] = py[d] - px[d];
-        const float dist = sqrtf(gh_sumsq<D>(diff)) + 1e-6f;
-        const float fm = neg_k * (dist - L_min);
+        for (int j = 0; j < C; ++j) ys[j] = base + j < end ? (int64_t)adj[base + j] : self;
+        float py[C][LD];
 #pragma unroll
-        for (int d = 0; d < D; ++d) F[d] = F[d] + fm * (diff[d] / dist);
+        for (int j = 0; j < C; ++j) gh_load_row<LD>(pos, ys[j], py[j]);
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            if (base + j < end) {
+                float diff[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) diff[d] = py[j][d] - px[d];
+                const float dist = sqrtf(gh_sumsq<D>(diff)) + 1e-6f;
+                const float fm = neg_k * (dist - L_min);
+#pragma unroll
+                for (int d = 0; d < D; ++d) F[d] = F[d] + fm * (diff[d] / dist);
+                if (WRITE_MID && base + j - beg < nfirst) {
+                    float mrow[LD];
+#pragma unroll
+                    for (int d = 0; d < LD; ++d) mrow[d] = d < D ? (px[d] + py[j][d]) / 2.0f : 0.0f;
+                    gh_store_row<LD>(mid, mid_row0 + (base + j - beg), mrow);
+                }
+            }
+        }
     }
 }
 
-// Fused spring + combine (pt.py:782, 796-799): new = pos + (F_spring + F_inter) for the
-// rows [row_lo, row_lo + rows), and per-workgroup column sums / sums of squares in fp64.
-// MODE 0: fused update.  MODE 1: only write the spring forces (per-phase entry point).
-template <int D, int LD, int MODE>
-__global__ __launch_bounds__(256) void spring_update_kernel(
+// Spring forces of the rows [row_lo, row_lo + rows) (pt.py:595-636) and, when WRITE_MID, the
+// midpoints of the edges those rows own (edges are sorted by first endpoint, so the edges of
+// row i are first_edge[i] .. first_edge[i+1]).  F goes to outF[(i + f_row0) * LD].
+template <int D, int LD, bool WRITE_MID>
+__global__ __launch_bounds__(256) void spring_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
-    int64_t row_lo, int64_t rows, float L_min, float neg_k, const double *__restrict__ acc,
-    const int32_t *__restrict__ tflag, float *__restrict__ out, double *__restrict__ blockstats) {
+    const int32_t *__restrict__ first_edge, int64_t edge_lo, int64_t row_lo, int64_t rows, float L_min,
+    float neg_k, float *__restrict__ outF, int64_t f_row0, float *__restrict__ mid) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const int64_t x = row_lo + i;
+    float px[LD], F[LD];
+    gh_load_row<LD>(pos, x, px);
+    int nfirst = 0;
+    int64_t mid_row0 = 0;
+    if (WRITE_MID) {
+        const int fe = first_edge[i];
+        nfirst = first_edge[i + 1] - fe;
+        mid_row0 = fe - edge_lo;
+    }
+    spring_pull<D, LD, WRITE_MID>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mid, mid_row0, nfirst);
+    gh_store_row<LD>(outF, i + f_row0, F);
+}
+
+// Combine (pt.py:796-799): new = pos + (F_spring + F_inter) for the own rows, plus the
+// per-workgroup column sums / sums of squares in fp64.  Streaming, one thread per row.
+template <int LD>
+__global__ __launch_bounds__(256) void integrate_kernel(
+    const float *__restrict__ pos, const float *__restrict__ Fs, int64_t row_lo, int64_t rows,
+    const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out,
+    double *__restrict__ blockstats) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     double sx[LD], sxx[LD];
 #pragma unroll
     for (int d = 0; d < LD; ++d) { sx[d] = 0.0; sxx[d] = 0.0; }
     if (i < rows) {
         const int64_t x = row_lo + i;
-        float px[LD], F[LD];
+        float px[LD], F[LD], nw[LD];
         gh_load_row<LD>(pos, x, px);
-        spring_pull<D, LD>(pos, adj, rowptr[i], rowptr[i + 1], px, L_min, neg_k, F);
-        if (MODE == 1) {
-            gh_store_row<LD>(out, x, F);
-        } else {
-            float nw[LD];
-            const bool touched = tflag[x] != 0;
-#pragma unroll
-            for (int d = 0; d < LD; ++d) {
-                const float fi = touched ? (float)acc[x * LD + d] : 0.0f;
-                const float tot = F[d] + fi;
-                nw[d] = px[d] + tot;
-                sx[d] = (double)nw[d];
-                sxx[d] = (double)nw[d] * (double)nw[d];
-            }
-            gh_store_row<LD>(out, i, nw);
-        }
-    }
-    if (MODE == 0) {
-        __shared__ double red[4][2 * LD];
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        gh_load_row<LD>(Fs, i, F);
+        const bool touched = tflag[x] != 0;
 #pragma unroll
         for (int d = 0; d < LD; ++d) {
-            const double a = gh_wave_sum(sx[d]), b = gh_wave_sum(sxx[d]);
-            if (lane == 0) { red[w][d] = a; red[w][LD + d] = b; }
+            const float fi = touched ? (float)acc[x * LD + d] : 0.0f;
+            const float tot = F[d] + fi;
+            nw[d] = px[d] + tot;
+            sx[d] = (double)nw[d];
+            sxx[d] = (double)nw[d] * (double)nw[d];
         }
-        __syncthreads();
-        if (threadIdx.x < 2 * LD) {
-            const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-            blockstats[(int64_t)blockIdx.x * 2 * LD + threadIdx.x] = v;
-        }
+        gh_store_row<LD>(out, i, nw);
+    }
+    __shared__ double red[4][2 * LD];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < LD; ++d) {
+        const double a = gh_wave_sum(sx[d]), b = gh_wave_sum(sxx[d]);
+        if (lane == 0) { red[w][d] = a; red[w][LD + d] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * LD) {
+        const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        blockstats[(int64_t)blockIdx.x * 2 * LD + threadIdx.x] = v;
     }
 }
 
+// Any LD: new = pos + (Fs + Fi), one thread per element (statistics by column_stats_kernel).
+__global__ __launch_bounds__(256) void integrate_generic_kernel(
+    const float *__restrict__ pos, const float *__restrict__ Fs, int LD, int64_t row_lo, int64_t rows,
+    const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= rows * LD) return;
+    const int64_t x = row_lo + t / LD;
+    const int64_t g = row_lo * LD + t;
+    const float fi = tflag[x] != 0 ? (float)acc[g] : 0.0f;
+    const float tot = Fs[t] + fi;
+    out[t] = pos[g] + tot;
+}
+
+// Midpoints of the edges [e_lo, e_lo + M) by gathering both endpoints (used when the edge
+// list is not sorted by first endpoint, or a partition does not follow row ownership).
+__global__ __launch_bounds__(256) void mid_gather_kernel(const float *__restrict__ pos,
+                                                        const int32_t *__restrict__ edges, int64_t e_lo, int64_t M,
+                                                        int D, int LD, float *__restrict__ mid) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= M * LD) return;
+    const int64_t j = t / LD;
+    const int d = (int)(t % LD);
+    const int64_t u = edges[2 * (e_lo + j)], v = edges[2 * (e_lo + j) + 1];
+    mid[t] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
+}
+
 // Any D: one thread per vertex, rows in global memory, same arithmetic and order.
-template <int MODE>
-__global__ __launch_bounds__(256) void spring_update_generic_kernel(
+__global__ __launch_bounds__(256) void spring_generic_kernel(
     const float *__restrict__ pos, int D, int LD, const int32_t *__restrict__ rowptr,
     const int32_t *__restrict__ adj, int64_t row_lo, int64_t rows, float L_min, float neg_k,
-    const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out,
-    float *__restrict__ scratch /* (rows, LD) diff scratch */) {
+    float *__restrict__ outF, int64_t f_row0, float *__restrict__ scratch /* (rows, LD) diff scratch */) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= rows) return;
     const int64_t x = row_lo + i;
     float *diff = scratch + i * LD;
-    float *dst = MODE == 1 ? out + x * LD : out + i * LD;
+    float *dst = outF + (i + f_row0) * LD;
     for (int d = 0; d < LD; ++d) dst[d] = 0.0f;
     for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
         const int64_t y = adj[j];
@@ -102,14 +164,6 @@ __global__ __launch_bounds__(256) void spring_update_generic_kernel(
         const float dist = sqrtf(gh_sumsq_rt(diff, D)) + 1e-6f;
         const float fm = neg_k * (dist - L_min);
         for (int d = 0; d < D; ++d) dst[d] = dst[d] + fm * (diff[d] / dist);
-    }
-    if (MODE == 0) {
-        const bool touched = tflag[x] != 0;
-        for (int d = 0; d < D; ++d) {
-            const float fi = touched ? (float)acc[x * LD + d] : 0.0f;
-            const float tot = dst[d] + fi;
-            dst[d] = pos[x * LD + d] + tot;
-        }
     }
 }
 
@@ -310,14 +364,17 @@ __global__ void arange_kernel(int64_t S, int32_t *__restrict__ sampled) {
 
 inline unsigned grid_for(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
 
-template <int MODE>
-gh_status launch_spring(gh_engine *h, float *out) {
+bool spring_is_templated(int D) { return D == 2 || D == 3 || D == 4 || D == 8 || D == 16; }
+
+// WRITE_MID only when the engine's edge range follows row ownership (h->fused_mid).
+template <bool WRITE_MID>
+gh_status launch_spring(gh_engine *h, float *outF, int64_t f_row0) {
     const unsigned grid = grid_for(h->rows, 256);
     const float neg_k = -h->prm.k_attr;
-#define GH_SPRING_CASE(DD, LL)                                                                               \
-    spring_update_kernel<DD, LL, MODE><<<dim3(grid), dim3(256), 0, h->stream>>>(                             \
-        h->d_pos, h->d_rowptr, h->d_adj, h->part.row_lo, h->rows, h->prm.L_min, neg_k, h->d_acc, h->d_tflag, \
-        out, h->d_blockstats)
+#define GH_SPRING_CASE(DD, LL)                                                                              \
+    spring_kernel<DD, LL, WRITE_MID><<<dim3(grid), dim3(256), 0, h->stream>>>(                              \
+        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->part.edge_lo, h->part.row_lo, h->rows,         \
+        h->prm.L_min, neg_k, outF, f_row0, h->d_mid)
     switch (h->D) {
         case 2: GH_SPRING_CASE(2, 4); break;
         case 3: GH_SPRING_CASE(3, 4); break;
@@ -325,31 +382,72 @@ gh_status launch_spring(gh_engine *h, float *out) {
         case 8: GH_SPRING_CASE(8, 8); break;
         case 16: GH_SPRING_CASE(16, 16); break;
         default:
-            spring_update_generic_kernel<MODE><<<dim3(grid), dim3(256), 0, h->stream>>>(
-                h->d_pos, h->D, h->LD, h->d_rowptr, h->d_adj, h->part.row_lo, h->rows, h->prm.L_min, neg_k,
-                h->d_acc, h->d_tflag, out, h->d_tmpF2);
+            spring_generic_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(
+                h->d_pos, h->D, h->LD, h->d_rowptr, h->d_adj, h->part.row_lo, h->rows, h->prm.L_min, neg_k, outF,
+                f_row0, h->d_tmpF2);
     }
 #undef GH_SPRING_CASE
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
 
-bool spring_is_templated(int D) { return D == 2 || D == 3 || D == 4 || D == 8 || D == 16; }
+gh_status launch_mid_gather(gh_engine *h) {
+    const int64_t M = h->part.edge_hi - h->part.edge_lo;
+    if (M == 0) return GH_OK;
+    gh_scope t(h, "mid_gather");
+    mid_gather_kernel<<<dim3(grid_for(M * h->LD, 256)), dim3(256), 0, h->stream>>>(h->d_pos, h->d_edges, h->part.edge_lo,
+                                                                                  M, h->D, h->LD, h->d_mid);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
 
 }  // namespace
 
-gh_status gh_launch_spring_update(gh_engine *h) {
+// Spring forces of the own rows -> d_Fs, and the midpoints of the own edges -> d_mid.
+gh_status gh_launch_spring_mid(gh_engine *h) {
+    const bool fused = h->fused_mid && spring_is_templated(h->D);
+    if (h->rows > 0) {
+        gh_scope t(h, fused ? "spring_mid" : "spring");
+        gh_status st = fused ? launch_spring<true>(h, h->d_Fs, 0) : launch_spring<false>(h, h->d_Fs, 0);
+        if (st) return st;
+    }
+    if (!fused) return launch_mid_gather(h);
+    return GH_OK;
+}
+
+// Midpoints only (per-phase KNN entry point).
+gh_status gh_launch_mid_only(gh_engine *h) { return launch_mid_gather(h); }
+
+// new = pos + (Fs + Fi) for the own rows -> d_new, column statistics -> d_stats.
+gh_status gh_launch_integrate(gh_engine *h) {
     if (h->rows == 0) {
         GH_HIP(hipMemsetAsync(h->d_stats, 0, sizeof(double) * 2 * h->LD, h->stream));
         return GH_OK;
     }
+    const unsigned grid = grid_for(h->rows, 256);
     {
-        gh_scope t(h, "spring_update");
-        gh_status st = launch_spring<0>(h, h->d_new);
-        if (st) return st;
+        gh_scope t(h, "integrate");
+        switch (h->LD) {
+            case 4:
+                integrate_kernel<4><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
+                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats);
+                break;
+            case 8:
+                integrate_kernel<8><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
+                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats);
+                break;
+            case 16:
+                integrate_kernel<16><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
+                                                                             h->d_acc, h->d_tflag, h->d_new, h->d_blockstats);
+                break;
+            default:
+                integrate_generic_kernel<<<dim3(grid_for(h->rows * h->LD, 256)), dim3(256), 0, h->stream>>>(
+                    h->d_pos, h->d_Fs, h->LD, h->part.row_lo, h->rows, h->d_acc, h->d_tflag, h->d_new);
+        }
+        GH_LAUNCH_CHECK();
     }
     gh_scope t(h, "stats_reduce");
-    if (spring_is_templated(h->D)) {
+    if (h->LD <= 16) {
         stats_reduce_kernel<<<dim3(2 * h->LD), dim3(256), 0, h->stream>>>(h->d_blockstats, h->nblocks_update, h->LD,
                                                                           h->d_stats);
     } else {
@@ -363,7 +461,7 @@ gh_status gh_launch_spring_only(gh_engine *h, float *d_F) {
     GH_HIP(hipMemsetAsync(d_F, 0, sizeof(float) * h->n * h->LD, h->stream));
     if (h->rows == 0) return GH_OK;
     gh_scope t(h, "spring_only");
-    return launch_spring<1>(h, d_F);
+    return launch_spring<false>(h, d_F, h->part.row_lo);
 }
 
 gh_status gh_launch_intersect(gh_engine *h) {

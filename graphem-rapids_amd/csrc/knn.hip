@@ -21,24 +21,33 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
 // ---------------------------------------------------------------------------------
+// Query records: QS floats per query = coordinates, then tau.  D <= 3 packs into one
+// 16-byte record (x, y, z|0, tau) so a query arrives as ONE s_load_dwordx4.
+__host__ __device__ inline int gh_qs(int D, int LD) { return D <= 3 ? 4 : LD + 4; }
+__host__ __device__ inline int gh_qtau(int D, int LD) { return D <= 3 ? 3 : LD; }
+
 // Query midpoints (pt.py:785 for the sampled rows, pt.py:410) and list reset.
 __global__ void knn_prepare_kernel(const float *__restrict__ pos, const int32_t *__restrict__ edges,
-                                   const int32_t *__restrict__ sampled, int64_t S, int LD,
-                                   float *__restrict__ q, int32_t *__restrict__ cnt, int32_t *__restrict__ ovf) {
+                                   const int32_t *__restrict__ sampled, int64_t S, int D, int LD,
+                                   float *__restrict__ qt, int32_t *__restrict__ cnt, int32_t *__restrict__ ovf) {
     const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (s >= S) return;
+    const int QS = gh_qs(D, LD);
     const int64_t e = sampled[s];
     const int64_t u = edges[2 * e], v = edges[2 * e + 1];
-    for (int d = 0; d < LD; ++d) q[s * LD + d] = (pos[u * LD + d] + pos[v * LD + d]) / 2.0f;
-    cnt[s] = 0;
+    for (int d = 0; d < QS; ++d) qt[s * QS + d] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
+    qt[s * QS + gh_qtau(D, LD)] = INFINITY;
+    cnt[s * GH_CNT_STRIDE] = 0;
     ovf[s] = 0;
 }
 
 // Bitonic sort of n2 (power of two) keys in LDS by one 256-thread workgroup, ascending.
+// Only used when K > GH_EXTRACT_MAX_K (latency-bound: ~20 us per 1024 keys).
 __device__ void block_sort(uint64_t *buf, int n2) {
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -61,24 +70,112 @@ __device__ __forceinline__ int next_pow2(int x) {
     return p;
 }
 
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = __shfl_xor(v, off, GH_WAVE);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// K smallest of the keys a 256-thread workgroup holds in registers (NPT per thread, unused
+// slots = GH_KEY_INF), written ascending to out[0..K) in LDS.  K rounds of a block-wide
+// minimum: keys are unique (the id is part of the key), so the owner of a round's minimum
+// retires it by equality.  ~200 cycles per round, against ~50 barrier phases for a sort.
+template <int NPT>
+__device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *out, uint64_t (*red)[4]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = 0; r < K; ++r) {
+        uint64_t m = keys[0];
+#pragma unroll
+        for (int j = 1; j < NPT; ++j) m = keys[j] < m ? keys[j] : m;
+        m = wave_min_u64(m);
+        if (lane == 0) red[r & 1][w] = m;
+        __syncthreads();
+        uint64_t bm = red[r & 1][0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) bm = red[r & 1][i] < bm ? red[r & 1][i] : bm;
+        if (threadIdx.x == 0) out[r] = bm;
+        if (bm != GH_KEY_INF) {
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) keys[j] = keys[j] == bm ? GH_KEY_INF : keys[j];
+        }
+    }
+    __syncthreads();
+}
+
+#define GH_EXTRACT_MAX_K 64
+
 // ---------------------------------------------------------------------------------
 // One workgroup per query: exact K smallest (dist2, id) keys over the reference edges
-// e_lo + j*stride, j < M.  Any D (runtime), any K <= GH_SEL_BUF - GH_SEL_CHUNK.
-// Running threshold + LDS compaction: keys below the current K-th key are appended to an
-// LDS buffer; when the next chunk might not fit, the buffer is sorted and cut to K.
+// e_lo + j*stride, j < M.  Any D (runtime).  Chunks of 2048 references: every thread
+// computes 8 keys into registers; keys that do not beat the current K-th key are dropped
+// at once; a chunk with a survivor re-extracts the best K from (survivors + previous best).
+// K <= GH_EXTRACT_MAX_K.
 __global__ __launch_bounds__(256) void knn_block_select_kernel(
-    const float *__restrict__ pos, int LD, int D, const int32_t *__restrict__ edges, int64_t e_lo, int64_t M,
-    int64_t stride, const float *__restrict__ q, int K, const int32_t *__restrict__ only_flagged,
-    uint64_t *__restrict__ out_keys /* (S, K) or null */, float *__restrict__ tau_out /* (S) or null */) {
+    const float *__restrict__ mid, int LD, int D, int64_t e_lo, int64_t M,
+    int64_t stride, const float *__restrict__ qt, int QS, int K, const int32_t *__restrict__ only_flagged,
+    uint64_t *__restrict__ out_keys /* (S, K) or null */, float *__restrict__ tau_out /* qt + tau offset, or null */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint64_t *buf = reinterpret_cast<uint64_t *>(smem_raw);                       // GH_SEL_BUF keys
+    float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[2][4];
+    constexpr int NPT = 8;
+
+    const int64_t qi = blockIdx.x;
+    if (only_flagged && only_flagged[qi] == 0) return;
+    for (int d = threadIdx.x; d < LD; d += blockDim.x) qs[d] = d < D ? qt[qi * QS + d] : 0.0f;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) best[i] = GH_KEY_INF;
+    __syncthreads();
+
+    for (int64_t base = 0; base < M; base += 256 * NPT) {
+        const uint64_t tk = best[K - 1];
+        uint64_t keys[NPT + 1];
+        int any = 0;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int64_t r = base + j * 256 + threadIdx.x;
+            uint64_t key = GH_KEY_INF;
+            if (r < M) {
+                const int64_t e = e_lo + r * stride;
+                const float *mr = mid + (r * stride) * LD;
+                float s = 0.0f;
+                for (int d = 0; d < D; ++d) {
+                    const float t = qs[d] - mr[d];
+                    s = fmaf(t, t, s);
+                }
+                key = gh_key(s, (uint32_t)e);
+                if (key < tk) any = 1; else key = GH_KEY_INF;
+            }
+            keys[j] = key;
+        }
+        if (__syncthreads_or(any)) {
+            keys[NPT] = threadIdx.x < K ? best[threadIdx.x] : GH_KEY_INF;  // previous best joins the pool
+            __syncthreads();
+            block_extract_smallest<NPT + 1>(keys, K, best, red);
+        }
+    }
+    if (out_keys)
+        for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
+    if (tau_out && threadIdx.x == 0) tau_out[qi * QS] = best[K - 1] != GH_KEY_INF ? gh_key_d2(best[K - 1]) : INFINITY;
+}
+
+// The same selection for large K (> GH_EXTRACT_MAX_K): running threshold + LDS compaction +
+// bitonic sort.  K <= GH_SEL_BUF - GH_SEL_CHUNK.
+__global__ __launch_bounds__(256) void knn_block_select_sort_kernel(
+    const float *__restrict__ mid, int LD, int D, int64_t e_lo, int64_t M,
+    int64_t stride, const float *__restrict__ qt, int QS, int K, const int32_t *__restrict__ only_flagged,
+    uint64_t *__restrict__ out_keys, float *__restrict__ tau_out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint64_t *buf = reinterpret_cast<uint64_t *>(smem_raw);                           // GH_SEL_BUF keys
     float *qs = reinterpret_cast<float *>(smem_raw + sizeof(uint64_t) * GH_SEL_BUF);  // LD floats
     __shared__ int cnt;
     __shared__ uint64_t tau_key;
 
     const int64_t qi = blockIdx.x;
     if (only_flagged && only_flagged[qi] == 0) return;
-    for (int d = threadIdx.x; d < LD; d += blockDim.x) qs[d] = q[qi * LD + d];
+    for (int d = threadIdx.x; d < LD; d += blockDim.x) qs[d] = d < D ? qt[qi * QS + d] : 0.0f;
     if (threadIdx.x == 0) { cnt = 0; tau_key = GH_KEY_INF; }
     __syncthreads();
 
@@ -88,12 +185,10 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(
             const int64_t r = base + j;
             if (r < M) {
                 const int64_t e = e_lo + r * stride;
-                const int64_t u = edges[2 * e], v = edges[2 * e + 1];
-                const float *pu = pos + u * LD, *pv = pos + v * LD;
+                const float *mr = mid + (r * stride) * LD;
                 float s = 0.0f;
                 for (int d = 0; d < D; ++d) {
-                    const float m = (pu[d] + pv[d]) / 2.0f;
-                    const float t = qs[d] - m;
+                    const float t = qs[d] - mr[d];
                     s = fmaf(t, t, s);
                 }
                 const uint64_t key = gh_key(s, (uint32_t)e);
@@ -121,84 +216,146 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(
     const int c = cnt;
     if (out_keys)
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = i < c ? buf[i] : GH_KEY_INF;
-    if (tau_out && threadIdx.x == 0) tau_out[qi] = c >= K ? gh_key_d2(buf[K - 1]) : INFINITY;
+    if (tau_out && threadIdx.x == 0) tau_out[qi * QS] = c >= K ? gh_key_d2(buf[K - 1]) : INFINITY;
 }
 
 // ---------------------------------------------------------------------------------
-// The filtered scan.  256 threads x R reference midpoints in registers; all S queries
-// stream past as scalar operands.  Per pair: D sub, 1 mul, D-1 fma, 1 compare.
+// The filtered scan.  256 threads x R reference midpoints in registers, held as R/2
+// packed pairs so the distance arithmetic runs on v_pk_add/mul/fma_f32 (two references
+// per VALU instruction: measured, a plain fp32 VALU op occupies a SIMD for 4 cycles, so
+// packed math is the only way past half of the fp32 vector peak).  The workgroup's query
+// group (<= 256 records of coordinates + tau) is staged in LDS once and streams past as
+// broadcast ds_read_b128, prefetched one query ahead.  Per pair: D/2 sub, 1/2 mul,
+// (D-1)/2 fma; per query one min-tree over the R distances, ONE compare and ONE branch
+// (a per-pair branch version was bound by the CU's scalar unit, and scalar loads of the
+// query table hot-spotted).  blockIdx.y selects the query group.
+typedef float gh_f2 __attribute__((ext_vector_type(2)));
+#define GH_SCAN_QGROUP 256
+#define GH_SCAN_HITBUF 1024
+
+__device__ __forceinline__ void gh_append_candidate(uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, int sg,
+                                                    uint64_t key) {
+    const int p = atomicAdd(&cnt[sg * GH_CNT_STRIDE], 1);
+    if (p < GH_CAND_CAP) cand[(int64_t)sg * GH_CAND_CAP + p] = key;
+}
+
 template <int D, int R>
 __global__ __launch_bounds__(256) void knn_scan_kernel(
-    const float *__restrict__ pos, const int32_t *__restrict__ edges, int64_t e_lo, int64_t M, int64_t stride,
-    const float *__restrict__ q, const float *__restrict__ tau, int S, uint64_t *__restrict__ cand,
-    int32_t *__restrict__ cnt) {
+    const float *__restrict__ mid, int64_t e_lo, int64_t M, int64_t stride,
+    const float *__restrict__ qt, int S, int qgroup, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
+    static_assert(R % 2 == 0, "references are processed in packed pairs");
     constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
-    float m[R][D];
+    constexpr int QS = D <= 3 ? 4 : LD + 4;
+    constexpr int QT = D <= 3 ? 3 : LD;
+    __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)];
+    __shared__ uint64_t hkey[GH_SCAN_HITBUF];
+    __shared__ int hq[GH_SCAN_HITBUF];
+    __shared__ int hcount;
+
+    if (threadIdx.x == 0) hcount = 0;
+    const int s_lo = blockIdx.y * qgroup;
+    const int nq = min(S - s_lo, qgroup);
+    {   // stage the query group (coalesced 16-byte loads); one spare record for the prefetch
+        const float4 *src = reinterpret_cast<const float4 *>(qt) + (int64_t)s_lo * (QS / 4);
+        for (int i = threadIdx.x; i < (nq + 1) * (QS / 4); i += 256)
+            qsh[i] = i < nq * (QS / 4) ? src[i] : make_float4(0.f, 0.f, 0.f, -1.f);
+    }
+    gh_f2 m[R / 2][D];
     uint32_t id[R];
     const int64_t tile = (int64_t)blockIdx.x * (256 * R);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int64_t j = tile + r * 256 + threadIdx.x;
+        float mv[LD];
         if (j < M) {
-            const int64_t e = e_lo + j * stride;
-            const int2 uv = reinterpret_cast<const int2 *>(edges)[e];
-            float pu[LD], pv[LD];
-            gh_load_row<LD>(pos, uv.x, pu);
-            gh_load_row<LD>(pos, uv.y, pv);
-#pragma unroll
-            for (int d = 0; d < D; ++d) m[r][d] = (pu[d] + pv[d]) / 2.0f;
-            id[r] = (uint32_t)e;
+            gh_load_row<LD>(mid, j * stride, mv);  // coalesced when stride == 1
+            id[r] = (uint32_t)(e_lo + j * stride);
         } else {
 #pragma unroll
-            for (int d = 0; d < D; ++d) m[r][d] = INFINITY;  // dist2 = inf never passes dist2 <= tau
+            for (int d = 0; d < LD; ++d) mv[d] = INFINITY;  // dist2 = inf never passes dist2 <= tau
             id[r] = 0xFFFFFFFFu;
         }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (r & 1) m[r / 2][d].y = mv[d];
+            else m[r / 2][d].x = mv[d];
+        }
     }
-    for (int s = 0; s < S; ++s) {
-        float qv[D];
+    __syncthreads();
+
+    float4 rec[QS / 4], nxt[QS / 4];
 #pragma unroll
-        for (int d = 0; d < D; ++d) qv[d] = q[s * LD + d];  // wave-uniform -> scalar loads
-        const float t = tau[s];
+    for (int i = 0; i < QS / 4; ++i) nxt[i] = qsh[i];
+    for (int s = 0; s < nq; ++s) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const float t0 = qv[0] - m[r][0];
-            float d2 = t0 * t0;  // == fmaf(t0, t0, +0)
+        for (int i = 0; i < QS / 4; ++i) rec[i] = nxt[i];
+#pragma unroll
+        for (int i = 0; i < QS / 4; ++i) nxt[i] = qsh[(s + 1) * (QS / 4) + i];  // broadcast read, next query
+        const float *qv = reinterpret_cast<const float *>(rec);
+        const float tau = qv[QT];
+        gh_f2 d2[R / 2];
+#pragma unroll
+        for (int r = 0; r < R / 2; ++r) {
+            const gh_f2 t0 = (gh_f2){qv[0], qv[0]} - m[r][0];
+            gh_f2 acc = t0 * t0;  // == fma(t0, t0, +0)
 #pragma unroll
             for (int d = 1; d < D; ++d) {
-                const float td = qv[d] - m[r][d];
-                d2 = fmaf(td, td, d2);
+                const gh_f2 td = (gh_f2){qv[d], qv[d]} - m[r][d];
+                acc = __builtin_elementwise_fma(td, td, acc);
             }
-            if (d2 <= t) {
-                const int p = atomicAdd(&cnt[s], 1);
-                if (p < GH_CAND_CAP) cand[(int64_t)s * GH_CAND_CAP + p] = gh_key(d2, id[r]);
+            d2[r] = acc;
+        }
+        float dmin = fminf(d2[0].x, d2[0].y);
+#pragma unroll
+        for (int r = 1; r < R / 2; ++r) dmin = fminf(dmin, fminf(d2[r].x, d2[r].y));
+        if (dmin <= tau) {  // rare: some reference of this thread is a candidate
+            const int sg = s_lo + s;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float dr = (r & 1) ? d2[r / 2].y : d2[r / 2].x;
+                if (dr <= tau) {
+                    // Park the hit in LDS; the global (returning) atomic that reserves its list slot
+                    // costs a ~1.5 us round trip, which must not sit inside this loop.
+                    const int p = atomicAdd(&hcount, 1);
+                    if (p < GH_SCAN_HITBUF) { hkey[p] = gh_key(dr, id[r]); hq[p] = sg; }
+                    else gh_append_candidate(cand, cnt, sg, gh_key(dr, id[r]));
+                }
             }
         }
     }
+    __syncthreads();
+    const int nh = min(hcount, GH_SCAN_HITBUF);
+    for (int i = threadIdx.x; i < nh; i += 256) gh_append_candidate(cand, cnt, hq[i], hkey[i]);
 }
 
-// One workgroup per query: sort the candidate list; final -> K best keys, else tighten tau.
+// One workgroup per query: K smallest of the candidate list; final -> K best keys, else tighten tau.
 __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ cand, int32_t *__restrict__ cnt,
-                                                         int K, int final_level, float *__restrict__ tau,
+                                                         int K, int final_level, float *__restrict__ tau, int QS,
                                                          uint64_t *__restrict__ out_keys,
-                                                         int32_t *__restrict__ ovf) {
-    __shared__ uint64_t buf[GH_CAND_CAP];
+                                                         int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt) {
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[2][4];
+    constexpr int NPT = GH_CAND_CAP / 256;
     const int64_t qi = blockIdx.x;
-    const int c = cnt[qi];
+    const int c = cnt[qi * GH_CNT_STRIDE];
     __syncthreads();
-    if (threadIdx.x == 0) cnt[qi] = 0;
+    if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; }
     if (c > GH_CAND_CAP || c < K) {
         // overflow (or an impossible short list): the list is not trustworthy
         if (final_level && threadIdx.x == 0) ovf[qi] = 1;
         return;  // tau keeps its previous (still valid, looser) value
     }
-    const int n2 = next_pow2(c < 2 ? 2 : c);
-    for (int i = threadIdx.x; i < n2; i += blockDim.x) buf[i] = i < c ? cand[qi * GH_CAND_CAP + i] : GH_KEY_INF;
-    __syncthreads();
-    block_sort(buf, n2);
+    uint64_t keys[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = j * 256 + threadIdx.x;
+        keys[j] = i < c ? cand[qi * GH_CAND_CAP + i] : GH_KEY_INF;
+    }
+    block_extract_smallest<NPT>(keys, K, best, red);
     if (final_level) {
-        for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = buf[i];
+        for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
     } else if (threadIdx.x == 0) {
-        tau[qi] = gh_key_d2(buf[K - 1]);
+        tau[qi * QS] = gh_key_d2(best[K - 1]);
     }
 }
 
@@ -227,9 +384,43 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restri
 template <int D, int R>
 void launch_scan(gh_engine *h, int64_t M, int64_t stride) {
     const int64_t per = 256 * R;
-    const int64_t grid = (M + per - 1) / per;
-    knn_scan_kernel<D, R><<<dim3((unsigned)grid), dim3(256), 0, h->stream>>>(
-        h->d_pos, h->d_edges, h->part.edge_lo, M, stride, h->d_q, h->d_tau, (int)h->S, h->d_cand, h->d_cnt);
+    const int64_t tiles = (M + per - 1) / per;
+    // enough workgroups to fill 256 CUs: split the queries when there are few tiles
+    int groups = (int)((1024 + tiles - 1) / tiles);
+    const int min_groups = (int)((h->S + GH_SCAN_QGROUP - 1) / GH_SCAN_QGROUP);
+    if (groups < min_groups) groups = min_groups;
+    if (groups > (int)h->S) groups = (int)h->S;
+    int qgroup = (int)((h->S + groups - 1) / groups);
+    if (qgroup > GH_SCAN_QGROUP) qgroup = GH_SCAN_QGROUP;
+    groups = (int)((h->S + qgroup - 1) / qgroup);
+    knn_scan_kernel<D, R><<<dim3((unsigned)tiles, (unsigned)groups), dim3(256), 0, h->stream>>>(
+        h->d_mid, h->part.edge_lo, M, stride, h->d_q, (int)h->S, qgroup, h->d_cand, h->d_cnt);
+}
+
+template <int R>
+void launch_scan_d(gh_engine *h, int64_t M, int64_t stride) {
+    switch (h->D) {
+        case 2: launch_scan<2, R>(h, M, stride); break;
+        case 3: launch_scan<3, R>(h, M, stride); break;
+        case 4: launch_scan<4, R>(h, M, stride); break;
+        default:
+            if (h->LD == 8) launch_scan<8, (R > 4 ? 4 : R)>(h, M, stride);
+            else launch_scan<16, (R > 2 ? 2 : R)>(h, M, stride);
+    }
+}
+
+void launch_block_select(gh_engine *h, int64_t M, int64_t stride, const int32_t *only_flagged, uint64_t *out_keys,
+                         bool write_tau) {
+    const int QS = gh_qs(h->D, h->LD);
+    float *tau_out = write_tau ? h->d_q + gh_qtau(h->D, h->LD) : nullptr;
+    if (h->K <= GH_EXTRACT_MAX_K) {
+        knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
+            h->d_mid, h->LD, h->D, h->part.edge_lo, M, stride, h->d_q, QS, h->K, only_flagged, out_keys, tau_out);
+    } else {
+        const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)h->LD;
+        knn_block_select_sort_kernel<<<dim3((unsigned)h->S), dim3(256), smem, h->stream>>>(
+            h->d_mid, h->LD, h->D, h->part.edge_lo, M, stride, h->d_q, QS, h->K, only_flagged, out_keys, tau_out);
+    }
 }
 
 }  // namespace
@@ -237,19 +428,19 @@ void launch_scan(gh_engine *h, int64_t M, int64_t stride) {
 gh_status gh_knn_local(gh_engine *h) {
     const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
     const int K = h->K;
-    const size_t sel_smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)h->LD;
+    const int QS = gh_qs(h->D, h->LD);
     {
         gh_scope t(h, "knn_prepare");
         const int bs = 256;
         knn_prepare_kernel<<<dim3((unsigned)((h->S + bs - 1) / bs)), dim3(bs), 0, h->stream>>>(
-            h->d_pos, h->d_edges, h->d_sampled_cur, h->S, h->LD, h->d_q, h->d_cnt, h->d_ovf);
+            h->d_pos, h->d_edges, h->d_sampled_cur, h->S, h->D, h->LD, h->d_q, h->d_cnt, h->d_ovf);
         GH_LAUNCH_CHECK();
     }
-    const bool scan_path = Mtot >= GH_SCAN_MIN_EDGES && h->LD <= 16 && h->D >= 2 && K <= 128 && h->S <= 0x7FFFFFFF;
+    const bool scan_path = Mtot >= GH_SCAN_MIN_EDGES && h->LD <= 16 && h->D >= 2 && K <= GH_EXTRACT_MAX_K &&
+                           h->S <= 0x7FFFFFFF;
     if (!scan_path) {
         gh_scope t(h, "knn_block_select");
-        knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sel_smem, h->stream>>>(
-            h->d_pos, h->LD, h->D, h->d_edges, h->part.edge_lo, Mtot, 1, h->d_q, K, nullptr, h->d_partial, nullptr);
+        launch_block_select(h, Mtot, 1, nullptr, h->d_partial, false);
         GH_LAUNCH_CHECK();
         return GH_OK;
     }
@@ -268,35 +459,28 @@ gh_status gh_knn_local(gh_engine *h) {
     {
         gh_scope t(h, "knn_level0_select");
         const int64_t M0 = (Mtot + strides[0] - 1) / strides[0];
-        knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sel_smem, h->stream>>>(
-            h->d_pos, h->LD, h->D, h->d_edges, h->part.edge_lo, M0, strides[0], h->d_q, K, nullptr, nullptr, h->d_tau);
+        launch_block_select(h, M0, strides[0], nullptr, nullptr, true);
         GH_LAUNCH_CHECK();
     }
     for (int l = 1; l <= L; ++l) {
         const int64_t M = (Mtot + strides[l] - 1) / strides[l];
         {
             gh_scope t(h, l == L ? "knn_scan" : "knn_scan_subset");
-            switch (h->D) {
-                case 2: launch_scan<2, 4>(h, M, strides[l]); break;
-                case 3: launch_scan<3, 4>(h, M, strides[l]); break;
-                case 4: launch_scan<4, 4>(h, M, strides[l]); break;
-                default:
-                    if (h->LD == 8) launch_scan<8, 2>(h, M, strides[l]);
-                    else launch_scan<16, 2>(h, M, strides[l]);
-            }
+            if (l == L) launch_scan_d<8>(h, M, strides[l]);
+            else launch_scan_d<2>(h, M, strides[l]);
             GH_LAUNCH_CHECK();
         }
         {
             gh_scope t(h, "knn_select");
             knn_select_kernel<<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(
-                h->d_cand, h->d_cnt, K, l == L ? 1 : 0, h->d_tau, h->d_partial, h->d_ovf);
+                h->d_cand, h->d_cnt, K, l == L ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), QS, h->d_partial, h->d_ovf,
+                h->d_dbg_cnt + (size_t)(l == L ? 1 : 0) * h->S);
             GH_LAUNCH_CHECK();
         }
     }
     {
         gh_scope t(h, "knn_overflow_fallback");
-        knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sel_smem, h->stream>>>(
-            h->d_pos, h->LD, h->D, h->d_edges, h->part.edge_lo, Mtot, 1, h->d_q, K, h->d_ovf, h->d_partial, nullptr);
+        launch_block_select(h, Mtot, 1, h->d_ovf, h->d_partial, false);
         GH_LAUNCH_CHECK();
     }
     return GH_OK;

@@ -128,6 +128,11 @@ gh_status gh_timing_reset(gh_handle h);
 int32_t gh_timing_count(gh_handle h);
 gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, double *total_ms, int64_t *launches);
 
+/* Diagnostics of the last KNN search: per query, the candidate-list length the last subset
+ * level and the final level saw, and whether the exact fallback had to redo the query
+ * (any of the three (S,) host pointers may be NULL).  Blocking. */
+gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final_counts, int32_t *overflow);
+
 /* Device / build facts for the host mirror's get_backend_info(). */
 int32_t gh_device_count(void);
 const char *gh_version(void);
