@@ -99,7 +99,7 @@ def main():
         run = lay.run
         sync = lay.sync
         barrier = dist.barrier
-        eng = lay.engine
+        eng = lay.engine.eng
     else:
         eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, device_id=local_rank)
         eng.set_positions(pos)

@@ -19,7 +19,8 @@ SYMBOLS = [
     "gh_row_stride", "gh_step", "gh_run", "gh_sync", "gh_spring_forces", "gh_knn_midpoints",
     "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_step_merge",
     "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
-    "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts",
+    "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts", "gh_set_stream",
+    "gh_positions_rows_allocated",
 ]
 
 
@@ -85,6 +86,10 @@ def load():
     L.gh_timing_get.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double),
                                 ctypes.POINTER(i64)]
     L.gh_timing_get.restype = ctypes.c_int
+    L.gh_set_stream.argtypes = [vp, vp, i32]
+    L.gh_set_stream.restype = ctypes.c_int
+    L.gh_positions_rows_allocated.argtypes = [vp]
+    L.gh_positions_rows_allocated.restype = i64
     L.gh_knn_last_counts.argtypes = [vp, vp, vp, vp]
     L.gh_knn_last_counts.restype = ctypes.c_int
     L.gh_device_count.argtypes = []
@@ -223,6 +228,13 @@ class Engine:
 
     def step_finish(self):
         self._chk(self.lib.gh_step_finish(self.handle))
+
+    def set_stream(self, stream_ptr, use_own=False):
+        """Enqueue on the given raw HIP stream (0 = the default stream) or back on the engine's own."""
+        self._chk(self.lib.gh_set_stream(self.handle, ctypes.c_void_p(stream_ptr), 1 if use_own else 0))
+
+    def positions_rows_allocated(self):
+        return int(self.lib.gh_positions_rows_allocated(self.handle))
 
     def positions_device_ptr(self):
         return self.lib.gh_positions_device(self.handle)

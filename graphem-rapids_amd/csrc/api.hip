@@ -78,7 +78,7 @@ static void free_all(gh_engine *h) {
                     h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_knn, h->d_first_edge, h->d_mid, h->d_Fs, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
 // ---- lifetime ----------------------------------------------------------------------
@@ -122,7 +122,9 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
 
     auto bail = [&](gh_status st) { g_create_error = h->err; free_all(h); delete h; return st; };
     if (hipSetDevice(device_id) != hipSuccess) return bail(GH_ERR_HIP);
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(GH_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(GH_ERR_HIP); }
+    h->stream = h->own_stream;
+    h->pos_rows = n + GH_POS_PAD_ROWS;
 
     // Pull lists of the own rows in the reference's summation order (pt.py:633-634):
     // first the edges where the vertex is endpoint 0, then those where it is endpoint 1,
@@ -173,7 +175,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_first_edge, (size_t)h->rows + 1, true);
     GH_A(d_mid, (size_t)(h->part.edge_hi - h->part.edge_lo) * h->LD, true);
     GH_A(d_Fs, (size_t)h->rows * h->LD, true);
-    GH_A(d_pos, nLD, true);
+    GH_A(d_pos, (size_t)h->pos_rows * h->LD, true);
     GH_A(d_new, (size_t)h->rows * h->LD, true);
     GH_A(d_tmpF, nLD, true);
     GH_A(d_tmpF2, nLD, true);
@@ -346,6 +348,14 @@ extern "C" gh_status gh_step_begin(gh_handle h, const int32_t *sampled) {
     GH_TRY(set_sample(h, sampled, nullptr));
     return step_begin(h);
 }
+extern "C" gh_status gh_set_stream(gh_handle h, void *hip_stream, int32_t use_own) {
+    GH_TRY(check_handle(h));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    resolve_timers(h);
+    h->stream = use_own ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
+    return GH_OK;
+}
+extern "C" int64_t gh_positions_rows_allocated(gh_handle h) { return h ? h->pos_rows : 0; }
 extern "C" uint64_t *gh_knn_partial_device(gh_handle h) { return h ? h->d_partial : nullptr; }
 extern "C" gh_status gh_step_merge(gh_handle h, const uint64_t *gathered, int32_t world) {
     GH_TRY(check_handle(h));

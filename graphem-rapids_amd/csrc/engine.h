@@ -14,6 +14,8 @@
 // Candidate counters are padded to one per 128-byte line: adjacent counters serialise their
 // returning atomics on one L2 line (~11 ns each, measured: 16 K appends per line cost 180 us).
 #define GH_CNT_STRIDE 32
+// Spare rows behind the n positions so equal all-gather chunks fit for any world size <= this.
+#define GH_POS_PAD_ROWS 1024
 // Below this many reference edges the per-query block kernel scans everything itself.
 #define GH_SCAN_MIN_EDGES 16384
 
@@ -35,7 +37,9 @@ struct gh_engine {
     uint64_t iter = 0;      // iterations done (device sampler counter)
     std::string err;
 
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // stream all work is enqueued on
+    hipStream_t own_stream = nullptr;   // created by gh_create
+    int64_t pos_rows = 0;               // rows allocated in d_pos (n + GH_POS_PAD_ROWS)
 
     // graph
     int32_t *d_edges = nullptr;   // (E, 2)

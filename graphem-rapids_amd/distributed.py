@@ -1,0 +1,124 @@
+"""Row-partitioned layout across the GPUs of one node (the reference has no
+multi-GPU code, so this is new functionality whose oracle is "N ranks == 1 rank").
+
+One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).  Rank r owns the
+vertex rows [r*chunk, (r+1)*chunk) and the edges whose first endpoint it owns (the edge list is
+sorted by first endpoint, so that is a contiguous edge range).  Every rank holds all n
+positions and the whole edge list.  Per iteration:
+
+    part 1  (local)   spring pull of own rows + midpoints of own edges; exact KNN of the S
+                      sampled midpoints among the OWN edges -> S x (k+1) keys
+    gather  (RCCL)    all-gather of the keys                       S*(k+1)*8 B per rank
+    part 2  (local)   merge keys -> global KNN; intersection forces (redundant on every rank,
+                      O(S*k)); integrate own rows; own column sums
+    reduce  (RCCL)    all-reduce of 2*ld doubles (sum, sum of squares)
+    part 3  (local)   normalise own rows in the full position array
+    gather  (RCCL)    in-place all-gather of the position row blocks   chunk*ld*4 B per rank
+
+The sample ids are the same on every rank: either passed in, or drawn by the engine's counter
+based sampler from (seed, iteration).  The compute engine is injectable so that the collective
+choreography can be tested with the gloo backend on CPUs (tests/test_distributed_cpu.py).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def partition_rows(n, world, rank):
+    """Equal chunks of ceil(n / world) rows; the last ranks may own fewer (or no) real rows."""
+    chunk = (n + world - 1) // world
+    lo = min(n, rank * chunk)
+    hi = min(n, lo + chunk)
+    return chunk, lo, hi
+
+
+def partition_edges(edges, row_lo, row_hi):
+    """Edge range owned by the rows [row_lo, row_hi): edges are sorted by first endpoint."""
+    e0 = np.asarray(edges)[:, 0]
+    if len(e0) > 1 and np.any(e0[1:] < e0[:-1]):
+        raise ValueError("the edge list must be sorted by first endpoint (CSR row order)")
+    return int(np.searchsorted(e0, row_lo, side="left")), int(np.searchsorted(e0, row_hi, side="left"))
+
+
+class HipShardEngine:
+    """The product engine of one rank: libgraphem_hip.so on this rank's GPU, torch tensor views
+    of its device buffers, all work on torch's current stream."""
+
+    def __init__(self, n, D, edges, L_min, k_attr, k_inter, k, S, seed, partition, device_id):
+        from . import _native
+        from .embedder_hip import device_view
+        self.eng = _native.Engine(n, D, edges, L_min, k_attr, k_inter, k, S, seed=seed, device_id=device_id,
+                                  partition=partition)
+        self.device = torch.device("cuda", device_id)
+        self.eng.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        e = self.eng
+        self.ld = e.ld
+        rows = e.positions_rows_allocated()
+        self.pos = device_view(e.positions_device_ptr(), (rows, e.ld), torch.float32, self.device, e)
+        self.partial = device_view(e.knn_partial_device_ptr(), (e.S, k + 1), torch.int64, self.device, e)
+        self.stats = device_view(e.stats_partial_device_ptr(), (2, e.ld), torch.float64, self.device, e)
+
+    def set_positions(self, pos):
+        self.eng.set_positions(pos)
+
+    def get_positions(self):
+        return self.eng.get_positions()
+
+    def step_begin(self, sampled):
+        self.eng.step_begin(sampled)
+
+    def step_merge(self, gathered, world):
+        self.eng.step_merge(gathered.data_ptr(), world)
+
+    def step_finish(self):
+        self.eng.step_finish()
+
+    def sync(self):
+        self.eng.sync()
+
+
+class PartitionedLayout:
+    def __init__(self, n, D, edges, L_min=1.0, k_attr=0.2, k_inter=0.5, n_neighbors=10, sample_size=256, seed=0,
+                 rank=None, world=None, device_id=0, engine_factory=None, group=None):
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
+        self.group = group
+        self.n, self.D = int(n), int(D)
+        edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        self.chunk, self.row_lo, self.row_hi = partition_rows(self.n, self.world, self.rank)
+        self.edge_lo, self.edge_hi = partition_edges(edges, self.row_lo, self.row_hi)
+        part = (self.row_lo, self.row_hi, self.edge_lo, self.edge_hi)
+        factory = engine_factory or HipShardEngine
+        self.engine = factory(self.n, self.D, edges, L_min, k_attr, k_inter, n_neighbors, min(sample_size, len(edges)),
+                              seed, part, device_id)
+        if self.chunk * self.world > self.engine.pos.shape[0]:
+            raise ValueError("world size too large for the engine's position padding")
+        self.K = n_neighbors + 1
+        self.S = min(sample_size, len(edges))
+        self.gathered = torch.empty((self.world, self.S, self.K), dtype=torch.int64, device=self.engine.pos.device)
+
+    def set_positions(self, pos):
+        self.engine.set_positions(np.ascontiguousarray(pos, dtype=np.float32))
+
+    def get_positions(self):
+        return self.engine.get_positions()
+
+    def step(self, sampled=None):
+        e = self.engine
+        e.step_begin(sampled)
+        # output in concatenated form (world*S, K): accepted by both the RCCL and the gloo backend
+        dist.all_gather_into_tensor(self.gathered.view(self.world * self.S, self.K), e.partial, group=self.group)
+        e.step_merge(self.gathered, self.world)
+        dist.all_reduce(e.stats, op=dist.ReduceOp.SUM, group=self.group)
+        e.step_finish()
+        # in-place all-gather: rank r's block sits at rows [r*chunk, (r+1)*chunk) of the output
+        full = e.pos[: self.chunk * self.world]
+        mine = e.pos[self.rank * self.chunk:(self.rank + 1) * self.chunk]
+        dist.all_gather_into_tensor(full, mine, group=self.group)
+
+    def run(self, iters, sample_stream=None):
+        for t in range(iters):
+            self.step(None if sample_stream is None else sample_stream[t])
+
+    def sync(self):
+        self.engine.sync()

@@ -106,6 +106,15 @@ gh_status gh_integrate_normalise(gh_handle h, const float *Fs, const float *Fi, 
  *      caller can run its collectives (RCCL through torch.distributed) between the
  *      parts; all buffers are device pointers owned by the handle. ---------------- */
 
+/* Run all later work of h on the caller's HIP stream (e.g. torch's current stream, so the
+ * engine's kernels are stream-ordered with RCCL collectives).  hip_stream may be NULL, which
+ * is HIP's default (null) stream -- torch's default stream.  use_own != 0 switches back to the
+ * stream gh_create made and ignores hip_stream. */
+gh_status gh_set_stream(gh_handle h, void *hip_stream, int32_t use_own);
+/* Rows allocated in the device position array: >= n, padded so that world equal chunks of
+ * ceil(n / world) rows fit for an in-place all-gather (rows >= n are zero and never read). */
+int64_t gh_positions_rows_allocated(gh_handle h);
+
 /* Part 1: spring pull for own rows, KNN scan of own edges.  Afterwards
  * gh_knn_partial_device() holds this rank's S x (k+1) best (dist2, id) keys. */
 gh_status gh_step_begin(gh_handle h, const int32_t *sampled);

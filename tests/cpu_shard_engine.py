@@ -1,0 +1,80 @@
+"""TEST INFRASTRUCTURE: a CPU stand-in for one rank's engine, built on the oracle's functions and
+numpy, with the same interface as graphem_rapids_amd.distributed.HipShardEngine.  It lets the
+multi-rank choreography of PartitionedLayout (partitioning, collective sequence, in-place
+position all-gather) run under the gloo backend without a GPU.  Never used by the product."""
+import numpy as np
+import torch
+
+import oracle
+
+
+class CpuShardEngine:
+    PAD_ROWS = 1024
+
+    def __init__(self, n, D, edges, L_min, k_attr, k_inter, k, S, seed, partition, device_id):
+        self.n, self.D, self.k, self.S = n, D, k, S
+        self.edges = np.ascontiguousarray(edges, dtype=np.int32)
+        self.prm = (L_min, k_attr, k_inter)
+        self.row_lo, self.row_hi, self.edge_lo, self.edge_hi = partition
+        self.ld = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else (D + 3) // 4 * 4
+        self.pos = torch.zeros((n + self.PAD_ROWS, self.ld), dtype=torch.float32)
+        self.partial = torch.zeros((S, k + 1), dtype=torch.int64)
+        self.stats = torch.zeros((2, self.ld), dtype=torch.float64)
+        self.seed, self.iter = seed, 0
+
+    def _p(self):
+        return self.pos[: self.n, : self.D].numpy()
+
+    def set_positions(self, pos):
+        self.pos[: self.n, : self.D] = torch.from_numpy(np.asarray(pos, dtype=np.float32))
+
+    def get_positions(self):
+        return self._p().copy()
+
+    def step_begin(self, sampled):
+        E = len(self.edges)
+        if self.S >= E:
+            sampled = np.arange(E, dtype=np.int32)
+        elif sampled is None:  # same ids on every rank from (seed, iteration)
+            sampled = np.random.default_rng([self.seed, self.iter]).permutation(E)[: self.S].astype(np.int32)
+        self.sampled = np.asarray(sampled, dtype=np.int32)
+        p = self._p()
+        self.Fs = oracle.spring_forces(p, self.edges, self.prm[0], self.prm[1])[self.row_lo:self.row_hi]
+        mid = oracle.midpoints(p, self.edges)
+        q = mid[self.sampled]
+        loc = mid[self.edge_lo:self.edge_hi]
+        keys = np.full((self.S, self.k + 1), np.iinfo(np.int64).max, dtype=np.int64)  # INF key pattern 0x7FFF..: sorts last
+        if len(loc):
+            d2 = ((q[:, None, :] - loc[None, :, :]) ** 2).sum(-1, dtype=np.float32)
+            ids = np.arange(self.edge_lo, self.edge_hi, dtype=np.int64)
+            key = (d2.view(np.uint32).astype(np.int64) << 32) | ids[None, :]
+            key.sort(axis=1)
+            m = min(self.k + 1, key.shape[1])
+            keys[:, :m] = key[:, :m]
+        self.partial[:] = torch.from_numpy(keys)
+
+    def step_merge(self, gathered, world):
+        g = gathered.numpy().transpose(1, 0, 2).reshape(self.S, -1)  # (S, world*K)
+        g = np.sort(g, axis=1)[:, : self.k + 1]
+        knn = (g[:, 1:] & 0xFFFFFFFF).astype(np.int32)               # drop column 0 (pt.py:421)
+        p = self._p()
+        Fi = oracle.intersection_forces(p, self.edges, self.sampled, knn, self.prm[2])[self.row_lo:self.row_hi]
+        tot = self.Fs + Fi
+        self.new = p[self.row_lo:self.row_hi] + tot
+        st = np.zeros((2, self.ld))
+        st[0, : self.D] = self.new.astype(np.float64).sum(0)
+        st[1, : self.D] = (self.new.astype(np.float64) ** 2).sum(0)
+        self.stats[:] = torch.from_numpy(st)
+
+    def step_finish(self):
+        st = self.stats.numpy()
+        n = self.n
+        mean = st[0, : self.D] / n
+        var = np.maximum((st[1, : self.D] - st[0, : self.D] * mean) / (n - 1), 0.0)
+        sd = np.sqrt(var).astype(np.float32) + np.float32(1e-6)
+        out = (self.new - mean.astype(np.float32)) / sd
+        self.pos[self.row_lo:self.row_hi, : self.D] = torch.from_numpy(out.astype(np.float32))
+        self.iter += 1
+
+    def sync(self):
+        pass

@@ -1,0 +1,84 @@
+"""The multi-rank path (graphem_rapids_amd.distributed.PartitionedLayout) under gloo on CPUs,
+world sizes 2 and 3, with the CPU stand-in engine: partition arithmetic, the collective sequence
+and the in-place position all-gather must reproduce the single-rank result and the oracle."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphem_rapids_amd.distributed import PartitionedLayout
+    from cpu_shard_engine import CpuShardEngine
+    n, D, edges, pos, stream, k, S = case
+    lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=3, rank=rank, world=world,
+                            engine_factory=CpuShardEngine)
+    lay.set_positions(pos)
+    lay.run(len(stream), stream)
+    np.save(os.path.join(out_dir, f"pos_w{world}_r{rank}.npy"), lay.get_positions())
+    lay.set_positions(pos)
+    lay.run(2)  # engine-drawn samples must agree across ranks too
+    np.save(os.path.join(out_dir, f"auto_w{world}_r{rank}.npy"), lay.get_positions())
+    dist.destroy_process_group()
+
+
+def _case(n=403, D=3, deg=6, k=6, S=40, iters=3):
+    import graphem_rapids_amd as gra
+    edges = gra.random_regular_edges(n - 1, deg, seed=1).astype(np.int32)  # vertex n-1 stays isolated
+    rng = np.random.default_rng(0)
+    pos = rng.standard_normal((n, D)).astype(np.float32)
+    stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(iters)]).astype(np.int32)
+    return n, D, edges, pos, stream, k, S
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_layout_matches_single_rank_and_oracle(world, tmp_path):
+    import oracle
+    case = _case()
+    n, D, edges, pos, stream, k, S = case
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(1, _free_port(), case, str(tmp_path)), nprocs=1, join=True)
+    single = np.load(tmp_path / "pos_w1_r0.npy")
+    ref = oracle.run_layout(pos, edges, stream, k)
+    assert np.abs(single - ref).max() < 1e-4
+    for r in range(world):
+        got = np.load(tmp_path / f"pos_w{world}_r{r}.npy")
+        assert np.abs(got - single).max() < 1e-5, f"rank {r}"       # N ranks == 1 rank
+        assert np.abs(got - ref).max() < 1e-4                        # and == the oracle
+        auto = np.load(tmp_path / f"auto_w{world}_r{r}.npy")
+        assert np.array_equal(auto, np.load(tmp_path / f"auto_w{world}_r0.npy"))  # every rank holds the same positions
+
+
+def test_partition_helpers():
+    from graphem_rapids_amd.distributed import partition_edges, partition_rows
+    assert partition_rows(10, 4, 0) == (3, 0, 3)
+    assert partition_rows(10, 4, 3) == (3, 9, 10)
+    assert partition_rows(5, 8, 7) == (1, 5, 5)          # more ranks than rows: empty shard
+    e = np.array([[0, 1], [0, 5], [2, 3], [2, 9], [7, 8]])
+    assert partition_edges(e, 0, 2) == (0, 2)
+    assert partition_edges(e, 2, 7) == (2, 4)
+    assert partition_edges(e, 7, 10) == (4, 5)
+    covered = sum(b - a for a, b in (partition_edges(e, lo, hi) for lo, hi in [(0, 3), (3, 6), (6, 10)]))
+    assert covered == len(e)
+    with pytest.raises(ValueError):
+        partition_edges(np.array([[3, 4], [1, 2]]), 0, 5)

@@ -250,3 +250,66 @@ def test_device_sampler():
     assert np.array_equal(a, b)          # same seed -> same trajectory
     assert not np.array_equal(a, c)      # different seed -> different samples
     assert np.isfinite(a).all()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_engines_equal_single_engine(world):
+    """The split step (gh_step_begin / gh_step_merge / gh_step_finish) with row partitions: `world`
+    engines on ONE GPU, collectives emulated with device copies, must reproduce the unpartitioned
+    engine (the oracle of the multi-GPU mode is the 1-GPU result)."""
+    import torch
+    from graphem_rapids_amd import _native
+    from graphem_rapids_amd.distributed import HipShardEngine, partition_edges, partition_rows
+    n, D, k, S = 30011, 3, 10, 256
+    edges, pos, _ = _random_case(n - 1, D, 8, k, S, seed=21)  # last vertex isolated
+    pos = np.vstack([pos, np.zeros((1, D), np.float32)])
+    rng = np.random.default_rng(4)
+    stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(3)]).astype(np.int32)
+    single = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S)
+    single.set_positions(pos)
+    single.run(3, stream)
+    ref = single.get_positions()
+    single.close()
+
+    shards, parts = [], []
+    for r in range(world):
+        chunk, lo, hi = partition_rows(n, world, r)
+        elo, ehi = partition_edges(edges, lo, hi)
+        parts.append((lo, hi))
+        shards.append(HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, (lo, hi, elo, ehi), 0))
+        shards[-1].set_positions(pos)
+    for t in range(3):
+        for sh in shards:
+            sh.step_begin(stream[t])
+        gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()
+        for sh in shards:
+            sh.step_merge(gathered, world)
+        tot = sum(sh.stats.clone() for sh in shards)
+        for sh in shards:
+            sh.stats.copy_(tot)
+            sh.step_finish()
+        for r, (lo, hi) in enumerate(parts):
+            for o, other in enumerate(shards):
+                if o != r:
+                    other.pos[lo:hi].copy_(shards[r].pos[lo:hi])
+    torch.cuda.synchronize()
+    for sh in shards:
+        got = sh.get_positions()
+        assert np.abs(got - ref).max() <= 2e-6
+        assert np.array_equal(got, shards[0].get_positions())
+
+
+def test_unsorted_edge_list_takes_the_gather_path():
+    """An edge list that is not sorted by first endpoint cannot use the fused spring+midpoint
+    kernel; results must not change (only the edge ids are permuted)."""
+    from graphem_rapids_amd import _native
+    edges, pos, sampled = _random_case(20000, 3, 8, 10, 256, seed=33)
+    perm = np.random.default_rng(0).permutation(len(edges))
+    shuffled = np.ascontiguousarray(edges[perm])
+    eng = _native.Engine(20000, 3, shuffled, 1.0, 0.2, 0.5, 10, 256)
+    eng.set_positions(pos)
+    assert np.array_equal(eng.knn_midpoints(sampled), oracle.knn_midpoints(pos, shuffled, sampled, 10))
+    assert np.array_equal(eng.spring_forces(), oracle.spring_forces(pos, shuffled, 1.0, 0.2))
+    eng.step(sampled)
+    assert np.abs(eng.get_positions() - oracle.step(pos, shuffled, sampled, 10)).max() <= 1e-4
+    eng.close()
