@@ -144,23 +144,28 @@ def main():
         kern = {name: {"avg_us": 1e3 * tot / cnt, "launches_per_step": cnt / args.steps}
                 for name, (tot, cnt) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
         E_rank = E // world
-        scan_us = kern.get("knn_scan", {}).get("avg_us")
+        # dominant kernel: the fused spring+scan kernel (or the stand-alone scan when unfused)
+        dom = "spring_scan" if "spring_scan" in kern else "knn_scan"
+        scan_us = kern.get(dom, {}).get("avg_us")
         flops_scan = 3.0 * D * S * E_rank                      # F_knn = 3*D*S*E per launch (per rank)
         roofline = None
         if scan_us:
             ach = flops_scan / (scan_us * 1e-6)
-            roofline = {"kernel": "knn_scan", "bound": "mfma", "pipe": "fp32 VALU (peak equals the dense fp32 MFMA peak)",
+            roofline = {"kernel": dom, "bound": "mfma",
+                        "pipe": "fp32 VALU, packed v_pk_*_f32 (vector fp32 peak = dense fp32 MFMA peak)",
                         "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_PEAK,
                         "traffic": None, "avg_launch_us": scan_us, "algorithmic_flops_per_launch": flops_scan}
         b_iter = 16.0 * E + 36.0 * n * D                       # B_iter = 16E + 36nD
         hbm = {"bound": "hbm", "achieved": b_iter / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                "frac": b_iter / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_iter": b_iter, "traffic": None}
-        su_us = kern.get("spring_update", {}).get("avg_us")
-        if su_us:
-            b_su = 8.0 * E + (4.0 + 16.0 * 2 + 4.0) * n       # pull lists + rowptr + read pos + write new + flag
-            hbm["spring_update"] = {"avg_launch_us": su_us, "algorithmic_bytes": b_su,
-                                    "achieved_GBps": b_su / (su_us * 1e-6) / 1e9,
-                                    "frac": b_su / (su_us * 1e-6) / HBM_PEAK}
+        if scan_us and dom == "spring_scan":
+            # the same kernel's memory side: pull lists + row pointers + positions read + forces written
+            b_sp = (8.0 * E + (8.0 + 4.0 * D * 2) * n) / world
+            hbm["spring_scan"] = {"avg_launch_us": scan_us, "algorithmic_bytes": b_sp,
+                                  "achieved_GBps": b_sp / (scan_us * 1e-6) / 1e9,
+                                  "frac": b_sp / (scan_us * 1e-6) / HBM_PEAK,
+                                  "random_row_fetches": 2.0 * E / world,
+                                  "row_fetch_rate_G_per_s": 2.0 * E / world / (scan_us * 1e-6) / 1e9}
         out = {
             "metric": "layout iterations/s", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local std::string g_create_error;
@@ -75,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_new, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_tau, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_knn, h->d_first_edge, h->d_mid, h->d_Fs, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_knn, h->d_first_edge, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -125,6 +126,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(GH_ERR_HIP); }
     h->stream = h->own_stream;
     h->pos_rows = n + GH_POS_PAD_ROWS;
+    h->force_unfused = getenv("GRAPHEM_HIP_UNFUSED") != nullptr;  // A/B switch for profiling and tests
 
     // Pull lists of the own rows in the reference's summation order (pt.py:633-634):
     // first the edges where the vertex is endpoint 0, then those where it is endpoint 1,
@@ -165,6 +167,34 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         }
         h->fused_mid = first_edge[0] == h->part.edge_lo && first_edge[(size_t)h->rows] == h->part.edge_hi;
     }
+    // Vertex ranges of the fused spring+scan workgroups: as many consecutive own rows as hold at
+    // most TILE owned edges (and at most 1024 rows, 4 per thread).
+    std::vector<int32_t> vblock;
+    {
+        const int tile = gh_fused_tile(h->LD);
+        const bool dim_ok = D == 2 || D == 3 || D == 4 || D == 8 || D == 16;
+        bool ok = h->fused_mid && dim_ok;
+        if (ok) {
+            vblock.push_back(0);
+            int64_t i = 0;
+            while (i < h->rows && ok) {
+                int64_t j = i, cnt = 0;
+                while (j < h->rows && j - i < 1024) {
+                    const int64_t own = first_edge[(size_t)j + 1] - first_edge[(size_t)j];
+                    if (own > tile) { ok = false; break; }  // a single row owns more than a tile: unfused path
+                    if (cnt + own > tile) break;
+                    cnt += own;
+                    ++j;
+                }
+                if (!ok) break;
+                vblock.push_back((int32_t)j);
+                i = j;
+            }
+        }
+        h->fused_scan = ok;
+        if (!ok) vblock.assign(1, 0);
+        h->n_vblocks = (int)vblock.size() - 1;
+    }
 
     const size_t nLD = (size_t)n * h->LD, S = (size_t)h->S;
     gh_status st;
@@ -175,6 +205,8 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_first_edge, (size_t)h->rows + 1, true);
     GH_A(d_mid, (size_t)(h->part.edge_hi - h->part.edge_lo) * h->LD, true);
     GH_A(d_Fs, (size_t)h->rows * h->LD, true);
+    GH_A(d_midsub, (size_t)((h->part.edge_hi - h->part.edge_lo) / 2 + 2) * h->LD, true);
+    GH_A(d_vblock, vblock.size(), false);
     GH_A(d_pos, (size_t)h->pos_rows * h->LD, true);
     GH_A(d_new, (size_t)h->rows * h->LD, true);
     GH_A(d_tmpF, nLD, true);
@@ -206,6 +238,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         !up(h->d_rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size()) ||
         !up(h->d_adj, adj.data(), sizeof(int32_t) * (size_t)h->adj_len) ||
         !up(h->d_first_edge, first_edge.data(), sizeof(int32_t) * first_edge.size()) ||
+        !up(h->d_vblock, vblock.data(), sizeof(int32_t) * vblock.size()) ||
         hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "upload of the graph failed";
         return bail(GH_ERR_HIP);
@@ -278,7 +311,14 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
     return gh_launch_sample(h);
 }
 
+// Spring forces of the own rows -> d_Fs and this rank's K best keys per query -> d_partial.
 static gh_status step_begin(gh_engine *h) {
+    if (h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused) {
+        GH_TRY(gh_knn_prepare(h));
+        GH_TRY(gh_knn_thresholds(h));
+        GH_TRY(gh_launch_spring_scan(h));
+        return gh_knn_finish(h, false);
+    }
     GH_TRY(gh_launch_spring_mid(h));
     return gh_knn_local(h);
 }
@@ -387,8 +427,7 @@ extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32
     GH_TRY(check_k(h));
     if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
     GH_TRY(set_sample(h, sampled, nullptr));
-    GH_TRY(gh_launch_mid_only(h));
-    GH_TRY(gh_knn_local(h));
+    GH_TRY(step_begin(h));  // the same kernels a step runs (spring forces are a by-product)
     GH_TRY(gh_knn_merge(h, h->d_partial, 1));
     GH_HIP(hipMemcpyAsync(knn, h->d_knn, sizeof(int32_t) * (size_t)h->S * h->k, hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipStreamSynchronize(h->stream));

@@ -93,3 +93,53 @@ __device__ __forceinline__ double gh_wave_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, GH_WAVE);
     return v;
 }
+
+// ---------------------------------------------------------------------------------
+// Spring force on one vertex, pull style (reference pt.py:595-636): the vertex walks its own
+// neighbour list, nobody else writes its row, so there are no atomics and the sum is
+// reproducible.  The list is stored in the reference's summation order (all edges where the
+// vertex is the first endpoint, then all where it is the second, each in edge order: the
+// two sequential index_add_ calls of pt.py:633-634).  For a neighbour y of x
+//   diff = p_y - p_x,  dist = |diff| + 1e-6,  f = (-k_attr * (dist - L_min)) * (diff / dist)
+// which equals +f of pt.py:629 when x is the first endpoint and -f when it is the second,
+// bit for bit (negation commutes with every rounding involved).
+template <int D, int LD, bool WRITE_MID>
+__device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const int32_t *__restrict__ adj,
+                                            int beg, int end, int64_t self, const float *px, float L_min,
+                                            float neg_k, float *F, float *__restrict__ mid, int64_t mid_row0,
+                                            int nfirst) {
+    // Neighbours are fetched C at a time so C independent row gathers are in flight per lane;
+    // the forces are still accumulated strictly in list order.  The first nfirst neighbours
+    // are the edges (self, y) with self < y: their midpoints (pt.py:785) cost nothing here,
+    // both endpoints being in registers, and spare the KNN scan its own random gathers.
+    constexpr int C = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;
+#pragma unroll
+    for (int d = 0; d < LD; ++d) F[d] = 0.0f;
+    for (int base = beg; base < end; base += C) {
+        int64_t ys[C];
+#pragma unroll
+        for (int j = 0; j < C; ++j) ys[j] = base + j < end ? (int64_t)adj[base + j] : self;
+        float py[C][LD];
+#pragma unroll
+        for (int j = 0; j < C; ++j) gh_load_row<LD>(pos, ys[j], py[j]);
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            if (base + j < end) {
+                float diff[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) diff[d] = py[j][d] - px[d];
+                const float dist = sqrtf(gh_sumsq<D>(diff)) + 1e-6f;
+                const float fm = neg_k * (dist - L_min);
+#pragma unroll
+                for (int d = 0; d < D; ++d) F[d] = F[d] + fm * (diff[d] / dist);
+                if (WRITE_MID && base + j - beg < nfirst) {
+                    float mrow[LD];
+#pragma unroll
+                    for (int d = 0; d < LD; ++d) mrow[d] = d < D ? (px[d] + py[j][d]) / 2.0f : 0.0f;
+                    gh_store_row<LD>(mid, mid_row0 + (base + j - beg), mrow);
+                }
+            }
+        }
+    }
+}
+

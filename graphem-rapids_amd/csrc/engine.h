@@ -50,6 +50,11 @@ struct gh_engine {
     bool fused_mid = false;       // own edge range == edges owned by own rows: spring kernel writes midpoints
     float *d_mid = nullptr;       // (edge_hi - edge_lo, LD) midpoints of the own edges, current iteration
     float *d_Fs = nullptr;        // (rows, LD) spring forces of the own rows
+    float *d_midsub = nullptr;    // (ceil(own edges / 2), LD) compact midpoints of the threshold subsets
+    int32_t *d_vblock = nullptr;  // (n_vblocks + 1) vertex ranges of the fused spring+scan workgroups
+    int n_vblocks = 0;
+    bool force_unfused = false;   // GRAPHEM_HIP_UNFUSED set: keep the separate spring / scan kernels
+    bool fused_scan = false;      // fused spring+scan kernel usable for this graph / partition
 
     // state
     float *d_pos = nullptr;       // (n, LD)
@@ -99,7 +104,14 @@ struct gh_scope {
 };
 
 // knn.hip
-gh_status gh_knn_local(gh_engine *h);                      // d_sampled -> d_partial
+gh_status gh_knn_local(gh_engine *h);                      // d_sampled, d_mid -> d_partial (unfused)
+bool gh_knn_scan_path(const gh_engine *h);
+gh_status gh_knn_prepare(gh_engine *h);
+gh_status gh_knn_thresholds(gh_engine *h);
+gh_status gh_knn_finish(gh_engine *h, bool have_mid);
+// fused.hip
+int gh_fused_tile(int LD);                                 // edges per fused workgroup
+gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -> d_knn
 // forces.hip
 gh_status gh_launch_intersect(gh_engine *h);               // d_sampled, d_knn -> d_acc/d_touched
@@ -123,6 +135,12 @@ gh_status gh_launch_arange(gh_engine *h);
             h->err = std::string(#call) + ": " + hipGetErrorString(e_);                     \
             return GH_ERR_HIP;                                                              \
         }                                                                                   \
+    } while (0)
+
+#define GH_TRY_ST(x)                                                                        \
+    do {                                                                                    \
+        gh_status st_ = (x);                                                                \
+        if (st_ != GH_OK) return st_;                                                       \
     } while (0)
 
 #define GH_LAUNCH_CHECK()                                                                   \

@@ -1,0 +1,112 @@
+// Fused spring + KNN scan: the dominant kernel of an iteration.
+//
+// Why fused: the spring pull is bound by the chip's random-line fetch rate (8 neighbour rows
+// of 16 bytes per vertex, each a 128-byte line from the Infinity Cache: ~64 G lines/s), the
+// KNN scan by the fp32 VALU.  As separate kernels they run back to back (measured 166 + 153 us
+// on the 1M-vertex graph) and the midpoints make a round trip through HBM.  Here one workgroup
+// owns a range of vertices holding at most TILE owned edges (edge (u, v), u < v, is owned by
+// u; the edge list is sorted by first endpoint so the range is contiguous):
+//   phase A  spring pull of its vertices (reference pt.py:595-636, summation order of the
+//            two index_add_ calls) -> Fs; the midpoints (pt.py:785) of the owned edges fall
+//            out of the gathered rows and are kept in LDS, never written to memory;
+//   phase B  those midpoints become the workgroup's reference tile: R per thread in packed
+//            registers, all S queries stream past (scan_core.h).
+// Workgroups in phase A (waiting on gathers) and workgroups in phase B (issuing VALU) share
+// the CUs, so the two bounds overlap instead of adding.
+#include "common.h"
+#include "engine.h"
+#include "scan_core.h"
+
+int gh_fused_tile(int LD) { return LD <= 4 ? 2048 : LD <= 8 ? 1024 : 512; }
+
+namespace {
+
+template <int D, int LD, int R>
+__global__ __launch_bounds__(256) void spring_scan_kernel(
+    const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
+    const int32_t *__restrict__ first_edge, const int32_t *__restrict__ vblock, int64_t row_lo, float L_min,
+    float neg_k, float *__restrict__ Fs, const float *__restrict__ qt, int S, uint64_t *__restrict__ cand,
+    int32_t *__restrict__ cnt) {
+    constexpr int TILE = 256 * R;
+    constexpr int QS = D <= 3 ? 4 : LD + 4;
+    constexpr int HITBUF = TILE * LD * 4 / 16;  // hit records reuse the midpoint tile's LDS
+    __shared__ float4 tile[TILE * LD / 4];
+    __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)];
+    __shared__ int hcount;
+    float *mids = reinterpret_cast<float *>(tile);
+
+    const int v0 = vblock[blockIdx.x], v1 = vblock[blockIdx.x + 1];
+    const int fe0 = first_edge[v0];
+    const int nedges = first_edge[v1] - fe0;
+    if (threadIdx.x == 0) hcount = 0;
+
+    // ---- phase A: spring forces of the vertices v0..v1, midpoints of their owned edges to LDS
+    for (int i = v0 + threadIdx.x; i < v1; i += 256) {
+        const int64_t x = row_lo + i;
+        float px[LD], F[LD];
+        gh_load_row<LD>(pos, x, px);
+        const int fe = first_edge[i];
+        spring_pull<D, LD, true>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mids, fe - fe0,
+                                 first_edge[i + 1] - fe);
+        gh_store_row<LD>(Fs, i, F);
+    }
+    __syncthreads();
+
+    // ---- phase B: the tile becomes this workgroup's references
+    gh_f2 m[R / 2][D];
+    uint32_t id[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int j = r * 256 + threadIdx.x;
+        float mv[LD];
+        if (j < nedges) {
+            gh_load_row<LD>(mids, j, mv);
+            id[r] = (uint32_t)(fe0 + j);
+        } else {
+#pragma unroll
+            for (int d = 0; d < LD; ++d) mv[d] = INFINITY;  // dist2 = inf never passes dist2 <= tau
+            id[r] = 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (r & 1) m[r / 2][d].y = mv[d];
+            else m[r / 2][d].x = mv[d];
+        }
+    }
+    __syncthreads();  // every thread has its references: the tile's LDS becomes the hit buffer
+    uint64_t *hkey = reinterpret_cast<uint64_t *>(tile);
+    int *hq = reinterpret_cast<int *>(hkey + HITBUF);
+    for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
+        const int nq = min(S - s_lo, GH_SCAN_QGROUP);
+        if (s_lo > 0) __syncthreads();  // the previous group's records are still being read
+        gh_stage_queries<QS>(qt, s_lo, nq, qsh);
+        __syncthreads();
+        gh_scan_queries<D, R, HITBUF>(m, id, qsh, nq, s_lo, hkey, hq, &hcount, cand, cnt);
+    }
+    __syncthreads();
+    gh_flush_hits<HITBUF>(hkey, hq, &hcount, cand, cnt);
+}
+
+template <int D, int LD, int R>
+void launch(gh_engine *h) {
+    spring_scan_kernel<D, LD, R><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
+        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
+        h->d_Fs, h->d_q, (int)h->S, h->d_cand, h->d_cnt);
+}
+
+}  // namespace
+
+gh_status gh_launch_spring_scan(gh_engine *h) {
+    if (h->n_vblocks == 0) return GH_OK;
+    gh_scope t(h, "spring_scan");
+    switch (h->D) {
+        case 2: launch<2, 4, 8>(h); break;
+        case 3: launch<3, 4, 8>(h); break;
+        case 4: launch<4, 4, 8>(h); break;
+        case 8: launch<8, 8, 4>(h); break;
+        case 16: launch<16, 16, 2>(h); break;
+        default: h->err = "fused spring+scan launched for an unsupported dimension"; return GH_ERR_RUNTIME;
+    }
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}

@@ -19,6 +19,7 @@
 //             edges, which is exact for any input.
 #include "common.h"
 #include "engine.h"
+#include "scan_core.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -26,11 +27,6 @@
 namespace {
 
 // ---------------------------------------------------------------------------------
-// Query records: QS floats per query = coordinates, then tau.  D <= 3 packs into one
-// 16-byte record (x, y, z|0, tau) so a query arrives as ONE s_load_dwordx4.
-__host__ __device__ inline int gh_qs(int D, int LD) { return D <= 3 ? 4 : LD + 4; }
-__host__ __device__ inline int gh_qtau(int D, int LD) { return D <= 3 ? 3 : LD; }
-
 // Query midpoints (pt.py:785 for the sampled rows, pt.py:410) and list reset.
 __global__ void knn_prepare_kernel(const float *__restrict__ pos, const int32_t *__restrict__ edges,
                                    const int32_t *__restrict__ sampled, int64_t S, int D, int LD,
@@ -114,8 +110,8 @@ __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *o
 // at once; a chunk with a survivor re-extracts the best K from (survivors + previous best).
 // K <= GH_EXTRACT_MAX_K.
 __global__ __launch_bounds__(256) void knn_block_select_kernel(
-    const float *__restrict__ mid, int LD, int D, int64_t e_lo, int64_t M,
-    int64_t stride, const float *__restrict__ qt, int QS, int K, const int32_t *__restrict__ only_flagged,
+    const float *__restrict__ mid, const float *__restrict__ pos, const int32_t *__restrict__ edges, int LD, int D,
+    int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride, const float *__restrict__ qt, int QS, int K, const int32_t *__restrict__ only_flagged,
     uint64_t *__restrict__ out_keys /* (S, K) or null */, float *__restrict__ tau_out /* qt + tau offset, or null */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats
@@ -139,11 +135,19 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(
             uint64_t key = GH_KEY_INF;
             if (r < M) {
                 const int64_t e = e_lo + r * stride;
-                const float *mr = mid + (r * stride) * LD;
                 float s = 0.0f;
-                for (int d = 0; d < D; ++d) {
-                    const float t = qs[d] - mr[d];
-                    s = fmaf(t, t, s);
+                if (mid) {
+                    const float *mr = mid + (r * mem_stride) * LD;
+                    for (int d = 0; d < D; ++d) {
+                        const float t = qs[d] - mr[d];
+                        s = fmaf(t, t, s);
+                    }
+                } else {  // no midpoint array (fused spring+scan path): gather the endpoints
+                    const float *pu = pos + (int64_t)edges[2 * e] * LD, *pv = pos + (int64_t)edges[2 * e + 1] * LD;
+                    for (int d = 0; d < D; ++d) {
+                        const float t = qs[d] - (pu[d] + pv[d]) / 2.0f;
+                        s = fmaf(t, t, s);
+                    }
                 }
                 key = gh_key(s, (uint32_t)e);
                 if (key < tk) any = 1; else key = GH_KEY_INF;
@@ -164,8 +168,8 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(
 // The same selection for large K (> GH_EXTRACT_MAX_K): running threshold + LDS compaction +
 // bitonic sort.  K <= GH_SEL_BUF - GH_SEL_CHUNK.
 __global__ __launch_bounds__(256) void knn_block_select_sort_kernel(
-    const float *__restrict__ mid, int LD, int D, int64_t e_lo, int64_t M,
-    int64_t stride, const float *__restrict__ qt, int QS, int K, const int32_t *__restrict__ only_flagged,
+    const float *__restrict__ mid, const float *__restrict__ pos, const int32_t *__restrict__ edges, int LD, int D,
+    int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride, const float *__restrict__ qt, int QS, int K, const int32_t *__restrict__ only_flagged,
     uint64_t *__restrict__ out_keys, float *__restrict__ tau_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t *buf = reinterpret_cast<uint64_t *>(smem_raw);                           // GH_SEL_BUF keys
@@ -185,11 +189,19 @@ __global__ __launch_bounds__(256) void knn_block_select_sort_kernel(
             const int64_t r = base + j;
             if (r < M) {
                 const int64_t e = e_lo + r * stride;
-                const float *mr = mid + (r * stride) * LD;
                 float s = 0.0f;
-                for (int d = 0; d < D; ++d) {
-                    const float t = qs[d] - mr[d];
-                    s = fmaf(t, t, s);
+                if (mid) {
+                    const float *mr = mid + (r * mem_stride) * LD;
+                    for (int d = 0; d < D; ++d) {
+                        const float t = qs[d] - mr[d];
+                        s = fmaf(t, t, s);
+                    }
+                } else {  // no midpoint array (fused spring+scan path): gather the endpoints
+                    const float *pu = pos + (int64_t)edges[2 * e] * LD, *pv = pos + (int64_t)edges[2 * e + 1] * LD;
+                    for (int d = 0; d < D; ++d) {
+                        const float t = qs[d] - (pu[d] + pv[d]) / 2.0f;
+                        s = fmaf(t, t, s);
+                    }
                 }
                 const uint64_t key = gh_key(s, (uint32_t)e);
                 if (key < tk) {
@@ -220,33 +232,18 @@ __global__ __launch_bounds__(256) void knn_block_select_sort_kernel(
 }
 
 // ---------------------------------------------------------------------------------
-// The filtered scan.  256 threads x R reference midpoints in registers, held as R/2
-// packed pairs so the distance arithmetic runs on v_pk_add/mul/fma_f32 (two references
-// per VALU instruction: measured, a plain fp32 VALU op occupies a SIMD for 4 cycles, so
-// packed math is the only way past half of the fp32 vector peak).  The workgroup's query
-// group (<= 256 records of coordinates + tau) is staged in LDS once and streams past as
-// broadcast ds_read_b128, prefetched one query ahead.  Per pair: D/2 sub, 1/2 mul,
-// (D-1)/2 fma; per query one min-tree over the R distances, ONE compare and ONE branch
-// (a per-pair branch version was bound by the CU's scalar unit, and scalar loads of the
-// query table hot-spotted).  blockIdx.y selects the query group.
-typedef float gh_f2 __attribute__((ext_vector_type(2)));
-#define GH_SCAN_QGROUP 256
+// The filtered scan as a stand-alone kernel: references are read from the midpoint array
+// (coalesced when stride == 1).  blockIdx.y selects the query group.  The inner loop lives in
+// scan_core.h.
 #define GH_SCAN_HITBUF 1024
-
-__device__ __forceinline__ void gh_append_candidate(uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, int sg,
-                                                    uint64_t key) {
-    const int p = atomicAdd(&cnt[sg * GH_CNT_STRIDE], 1);
-    if (p < GH_CAND_CAP) cand[(int64_t)sg * GH_CAND_CAP + p] = key;
-}
 
 template <int D, int R>
 __global__ __launch_bounds__(256) void knn_scan_kernel(
-    const float *__restrict__ mid, int64_t e_lo, int64_t M, int64_t stride,
+    const float *__restrict__ mid, int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride,
     const float *__restrict__ qt, int S, int qgroup, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
     static_assert(R % 2 == 0, "references are processed in packed pairs");
     constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
-    constexpr int QT = D <= 3 ? 3 : LD;
     __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)];
     __shared__ uint64_t hkey[GH_SCAN_HITBUF];
     __shared__ int hq[GH_SCAN_HITBUF];
@@ -255,11 +252,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
     if (threadIdx.x == 0) hcount = 0;
     const int s_lo = blockIdx.y * qgroup;
     const int nq = min(S - s_lo, qgroup);
-    {   // stage the query group (coalesced 16-byte loads); one spare record for the prefetch
-        const float4 *src = reinterpret_cast<const float4 *>(qt) + (int64_t)s_lo * (QS / 4);
-        for (int i = threadIdx.x; i < (nq + 1) * (QS / 4); i += 256)
-            qsh[i] = i < nq * (QS / 4) ? src[i] : make_float4(0.f, 0.f, 0.f, -1.f);
-    }
+    gh_stage_queries<QS>(qt, s_lo, nq, qsh);
     gh_f2 m[R / 2][D];
     uint32_t id[R];
     const int64_t tile = (int64_t)blockIdx.x * (256 * R);
@@ -268,7 +261,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
         const int64_t j = tile + r * 256 + threadIdx.x;
         float mv[LD];
         if (j < M) {
-            gh_load_row<LD>(mid, j * stride, mv);  // coalesced when stride == 1
+            gh_load_row<LD>(mid, j * mem_stride, mv);
             id[r] = (uint32_t)(e_lo + j * stride);
         } else {
 #pragma unroll
@@ -282,50 +275,25 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
         }
     }
     __syncthreads();
-
-    float4 rec[QS / 4], nxt[QS / 4];
-#pragma unroll
-    for (int i = 0; i < QS / 4; ++i) nxt[i] = qsh[i];
-    for (int s = 0; s < nq; ++s) {
-#pragma unroll
-        for (int i = 0; i < QS / 4; ++i) rec[i] = nxt[i];
-#pragma unroll
-        for (int i = 0; i < QS / 4; ++i) nxt[i] = qsh[(s + 1) * (QS / 4) + i];  // broadcast read, next query
-        const float *qv = reinterpret_cast<const float *>(rec);
-        const float tau = qv[QT];
-        gh_f2 d2[R / 2];
-#pragma unroll
-        for (int r = 0; r < R / 2; ++r) {
-            const gh_f2 t0 = (gh_f2){qv[0], qv[0]} - m[r][0];
-            gh_f2 acc = t0 * t0;  // == fma(t0, t0, +0)
-#pragma unroll
-            for (int d = 1; d < D; ++d) {
-                const gh_f2 td = (gh_f2){qv[d], qv[d]} - m[r][d];
-                acc = __builtin_elementwise_fma(td, td, acc);
-            }
-            d2[r] = acc;
-        }
-        float dmin = fminf(d2[0].x, d2[0].y);
-#pragma unroll
-        for (int r = 1; r < R / 2; ++r) dmin = fminf(dmin, fminf(d2[r].x, d2[r].y));
-        if (dmin <= tau) {  // rare: some reference of this thread is a candidate
-            const int sg = s_lo + s;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const float dr = (r & 1) ? d2[r / 2].y : d2[r / 2].x;
-                if (dr <= tau) {
-                    // Park the hit in LDS; the global (returning) atomic that reserves its list slot
-                    // costs a ~1.5 us round trip, which must not sit inside this loop.
-                    const int p = atomicAdd(&hcount, 1);
-                    if (p < GH_SCAN_HITBUF) { hkey[p] = gh_key(dr, id[r]); hq[p] = sg; }
-                    else gh_append_candidate(cand, cnt, sg, gh_key(dr, id[r]));
-                }
-            }
-        }
-    }
+    gh_scan_queries<D, R, GH_SCAN_HITBUF>(m, id, qsh, nq, s_lo, hkey, hq, &hcount, cand, cnt);
     __syncthreads();
-    const int nh = min(hcount, GH_SCAN_HITBUF);
-    for (int i = threadIdx.x; i < nh; i += 256) gh_append_candidate(cand, cnt, hq[i], hkey[i]);
+    gh_flush_hits<GH_SCAN_HITBUF>(hkey, hq, &hcount, cand, cnt);
+}
+
+// Compact copy of the midpoints of the edges e_lo + j*stride, j < M (the nested subsets the
+// threshold levels work on), gathered from positions: M is ~E/45, so this is cheap, and the
+// threshold stage no longer needs the full midpoint array.
+__global__ __launch_bounds__(256) void knn_subset_gather_kernel(const float *__restrict__ pos,
+                                                               const int32_t *__restrict__ edges, int64_t e_lo,
+                                                               int64_t M, int64_t stride, int D, int LD,
+                                                               float *__restrict__ out) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= M * LD) return;
+    const int64_t j = t / LD;
+    const int d = (int)(t % LD);
+    const int64_t e = e_lo + j * stride;
+    const int64_t u = edges[2 * e], v = edges[2 * e + 1];
+    out[t] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
 }
 
 // One workgroup per query: K smallest of the candidate list; final -> K best keys, else tighten tau.
@@ -382,7 +350,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restri
 }
 
 template <int D, int R>
-void launch_scan(gh_engine *h, int64_t M, int64_t stride) {
+void launch_scan(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, int64_t id_stride) {
     const int64_t per = 256 * R;
     const int64_t tiles = (M + per - 1) / per;
     // enough workgroups to fill 256 CUs: split the queries when there are few tiles
@@ -394,96 +362,145 @@ void launch_scan(gh_engine *h, int64_t M, int64_t stride) {
     if (qgroup > GH_SCAN_QGROUP) qgroup = GH_SCAN_QGROUP;
     groups = (int)((h->S + qgroup - 1) / qgroup);
     knn_scan_kernel<D, R><<<dim3((unsigned)tiles, (unsigned)groups), dim3(256), 0, h->stream>>>(
-        h->d_mid, h->part.edge_lo, M, stride, h->d_q, (int)h->S, qgroup, h->d_cand, h->d_cnt);
+        mid, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, (int)h->S, qgroup, h->d_cand, h->d_cnt);
 }
 
 template <int R>
-void launch_scan_d(gh_engine *h, int64_t M, int64_t stride) {
+void launch_scan_d(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, int64_t id_stride) {
     switch (h->D) {
-        case 2: launch_scan<2, R>(h, M, stride); break;
-        case 3: launch_scan<3, R>(h, M, stride); break;
-        case 4: launch_scan<4, R>(h, M, stride); break;
+        case 2: launch_scan<2, R>(h, mid, M, mem_stride, id_stride); break;
+        case 3: launch_scan<3, R>(h, mid, M, mem_stride, id_stride); break;
+        case 4: launch_scan<4, R>(h, mid, M, mem_stride, id_stride); break;
         default:
-            if (h->LD == 8) launch_scan<8, (R > 4 ? 4 : R)>(h, M, stride);
-            else launch_scan<16, (R > 2 ? 2 : R)>(h, M, stride);
+            if (h->LD == 8) launch_scan<8, (R > 4 ? 4 : R)>(h, mid, M, mem_stride, id_stride);
+            else launch_scan<16, (R > 2 ? 2 : R)>(h, mid, M, mem_stride, id_stride);
     }
 }
 
-void launch_block_select(gh_engine *h, int64_t M, int64_t stride, const int32_t *only_flagged, uint64_t *out_keys,
-                         bool write_tau) {
+// mid == nullptr: gather the endpoints from positions instead (slow; the exact fallback only).
+void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, int64_t id_stride,
+                         const int32_t *only_flagged, uint64_t *out_keys, bool write_tau) {
     const int QS = gh_qs(h->D, h->LD);
     float *tau_out = write_tau ? h->d_q + gh_qtau(h->D, h->LD) : nullptr;
     if (h->K <= GH_EXTRACT_MAX_K) {
         knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
-            h->d_mid, h->LD, h->D, h->part.edge_lo, M, stride, h->d_q, QS, h->K, only_flagged, out_keys, tau_out);
+            mid, h->d_pos, h->d_edges, h->LD, h->D, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, QS, h->K,
+            only_flagged, out_keys, tau_out);
     } else {
         const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)h->LD;
         knn_block_select_sort_kernel<<<dim3((unsigned)h->S), dim3(256), smem, h->stream>>>(
-            h->d_mid, h->LD, h->D, h->part.edge_lo, M, stride, h->d_q, QS, h->K, only_flagged, out_keys, tau_out);
+            mid, h->d_pos, h->d_edges, h->LD, h->D, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, QS, h->K,
+            only_flagged, out_keys, tau_out);
     }
 }
 
-}  // namespace
+struct level_plan {
+    int L;
+    std::vector<int64_t> strides;  // strides[L] == 1 (all edges); strides[l-1] = r * strides[l]
+};
 
-gh_status gh_knn_local(gh_engine *h) {
-    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
-    const int K = h->K;
-    const int QS = gh_qs(h->D, h->LD);
-    {
-        gh_scope t(h, "knn_prepare");
-        const int bs = 256;
-        knn_prepare_kernel<<<dim3((unsigned)((h->S + bs - 1) / bs)), dim3(bs), 0, h->stream>>>(
-            h->d_pos, h->d_edges, h->d_sampled_cur, h->S, h->D, h->LD, h->d_q, h->d_cnt, h->d_ovf);
-        GH_LAUNCH_CHECK();
-    }
-    const bool scan_path = Mtot >= GH_SCAN_MIN_EDGES && h->LD <= 16 && h->D >= 2 && K <= GH_EXTRACT_MAX_K &&
-                           h->S <= 0x7FFFFFFF;
-    if (!scan_path) {
-        gh_scope t(h, "knn_block_select");
-        launch_block_select(h, Mtot, 1, nullptr, h->d_partial, false);
-        GH_LAUNCH_CHECK();
-        return GH_OK;
-    }
-    // Level plan: nested strided subsets, ratio r between levels, ~2048 edges at level 0.
+// Nested strided subsets, ratio r between levels, ~2048 edges at level 0.
+level_plan plan_levels(int64_t Mtot, int K) {
     int rmax = 1536 / K;
     if (rmax > 64) rmax = 64;
     if (rmax < 2) rmax = 2;
     const double want = (double)Mtot / 2048.0;
-    int L = 1;
-    while (pow((double)rmax, L) < want) ++L;
-    int64_t r = (int64_t)ceil(pow(want, 1.0 / L));
+    level_plan p;
+    p.L = 1;
+    while (pow((double)rmax, p.L) < want) ++p.L;
+    int64_t r = (int64_t)ceil(pow(want, 1.0 / p.L));
     if (r < 2) r = 2;
-    std::vector<int64_t> strides(L + 1);
-    strides[L] = 1;
-    for (int l = L - 1; l >= 0; --l) strides[l] = strides[l + 1] * r;
+    p.strides.assign((size_t)p.L + 1, 1);
+    for (int l = p.L - 1; l >= 0; --l) p.strides[(size_t)l] = p.strides[(size_t)l + 1] * r;
+    return p;
+}
+
+gh_status launch_select(gh_engine *h, bool final_level) {
+    gh_scope t(h, "knn_select");
+    knn_select_kernel<<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(
+        h->d_cand, h->d_cnt, h->K, final_level ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), gh_qs(h->D, h->LD),
+        h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+}  // namespace
+
+bool gh_knn_scan_path(const gh_engine *h) {
+    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    return Mtot >= GH_SCAN_MIN_EDGES && h->LD <= 16 && h->D >= 2 && h->K <= GH_EXTRACT_MAX_K && h->S <= 0x7FFFFFFF;
+}
+
+// Query records + list reset.
+gh_status gh_knn_prepare(gh_engine *h) {
+    gh_scope t(h, "knn_prepare");
+    const int bs = 256;
+    knn_prepare_kernel<<<dim3((unsigned)((h->S + bs - 1) / bs)), dim3(bs), 0, h->stream>>>(
+        h->d_pos, h->d_edges, h->d_sampled_cur, h->S, h->D, h->LD, h->d_q, h->d_cnt, h->d_ovf);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+// Thresholds for the final level: every level but the last, on a compact gathered copy of the
+// largest proper subset.  Needs gh_knn_scan_path(h).
+gh_status gh_knn_thresholds(gh_engine *h) {
+    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    const level_plan p = plan_levels(Mtot, h->K);
+    const int64_t s1 = p.strides[(size_t)p.L - 1];  // stride of the largest proper subset
+    const int64_t M1 = (Mtot + s1 - 1) / s1;
+    {
+        gh_scope t(h, "knn_subset_gather");
+        knn_subset_gather_kernel<<<dim3((unsigned)((M1 * h->LD + 255) / 256)), dim3(256), 0, h->stream>>>(
+            h->d_pos, h->d_edges, h->part.edge_lo, M1, s1, h->D, h->LD, h->d_midsub);
+        GH_LAUNCH_CHECK();
+    }
     {
         gh_scope t(h, "knn_level0_select");
-        const int64_t M0 = (Mtot + strides[0] - 1) / strides[0];
-        launch_block_select(h, M0, strides[0], nullptr, nullptr, true);
+        const int64_t M0 = (Mtot + p.strides[0] - 1) / p.strides[0];
+        launch_block_select(h, h->d_midsub, M0, p.strides[0] / s1, p.strides[0], nullptr, nullptr, true);
         GH_LAUNCH_CHECK();
     }
-    for (int l = 1; l <= L; ++l) {
-        const int64_t M = (Mtot + strides[l] - 1) / strides[l];
+    for (int l = 1; l < p.L; ++l) {
+        const int64_t st = p.strides[(size_t)l];
+        const int64_t M = (Mtot + st - 1) / st;
         {
-            gh_scope t(h, l == L ? "knn_scan" : "knn_scan_subset");
-            if (l == L) launch_scan_d<8>(h, M, strides[l]);
-            else launch_scan_d<2>(h, M, strides[l]);
+            gh_scope t(h, "knn_scan_subset");
+            launch_scan_d<2>(h, h->d_midsub, M, st / s1, st);
             GH_LAUNCH_CHECK();
         }
-        {
-            gh_scope t(h, "knn_select");
-            knn_select_kernel<<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(
-                h->d_cand, h->d_cnt, K, l == L ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), QS, h->d_partial, h->d_ovf,
-                h->d_dbg_cnt + (size_t)(l == L ? 1 : 0) * h->S);
-            GH_LAUNCH_CHECK();
-        }
-    }
-    {
-        gh_scope t(h, "knn_overflow_fallback");
-        launch_block_select(h, Mtot, 1, h->d_ovf, h->d_partial, false);
-        GH_LAUNCH_CHECK();
+        GH_TRY_ST(launch_select(h, false));
     }
     return GH_OK;
+}
+
+// K best keys of every query from its final candidate list; queries whose list overflowed are
+// redone exactly over all own edges (from d_mid when have_mid, else by gathering endpoints).
+gh_status gh_knn_finish(gh_engine *h, bool have_mid) {
+    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    GH_TRY_ST(launch_select(h, true));
+    gh_scope t(h, "knn_overflow_fallback");
+    launch_block_select(h, have_mid ? h->d_mid : nullptr, Mtot, 1, 1, h->d_ovf, h->d_partial, false);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+// Unfused search over the materialised midpoints d_mid -> d_partial.
+gh_status gh_knn_local(gh_engine *h) {
+    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    GH_TRY_ST(gh_knn_prepare(h));
+    if (!gh_knn_scan_path(h)) {
+        gh_scope t(h, "knn_block_select");
+        launch_block_select(h, h->d_mid, Mtot, 1, 1, nullptr, h->d_partial, false);
+        GH_LAUNCH_CHECK();
+        return GH_OK;
+    }
+    GH_TRY_ST(gh_knn_thresholds(h));
+    {
+        gh_scope t(h, "knn_scan");
+        launch_scan_d<8>(h, h->d_mid, Mtot, 1, 1);
+        GH_LAUNCH_CHECK();
+    }
+    return gh_knn_finish(h, true);
 }
 
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {
