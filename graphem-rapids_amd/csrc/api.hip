@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_new, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_tau, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_knn, h->d_first_edge, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_knn, h->d_merged, h->d_first_edge, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -225,6 +225,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_dbg_cnt, 2 * S, true);
     GH_A(d_partial, S * (size_t)h->K, true);
     GH_A(d_knn, S * (size_t)h->k, true);
+    GH_A(d_merged, S * (size_t)h->K, true);
     GH_A(d_iscratch, S * (size_t)h->k * h->LD, false);
     h->nblocks_update = (int)((h->rows + 255) / 256);
     GH_A(d_blockstats, (size_t)std::max(h->nblocks_update, 1) * 2 * h->LD, true);
@@ -295,9 +296,12 @@ static gh_status check_k(gh_engine *h) {
 
 // Chooses this iteration's sample ids: caller's ids, arange (S >= E, pt.py:412) or the sampler.
 static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t *dev_ids) {
+    h->sample_pending = false;
     if (h->S >= h->E) {  // no randomness consumed
         h->d_sampled_cur = h->d_sampled;
-        return gh_launch_arange(h);
+        h->sample_pending = true;  // produced inside the KNN setup kernel (or by gh_ensure_sample)
+        h->sample_mode = 2;
+        return GH_OK;
     }
     if (dev_ids) { h->d_sampled_cur = const_cast<int32_t *>(dev_ids); return GH_OK; }
     h->d_sampled_cur = h->d_sampled;
@@ -308,7 +312,9 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
         GH_HIP(hipStreamSynchronize(h->stream));
         return GH_OK;
     }
-    return gh_launch_sample(h);
+    h->sample_pending = true;
+    h->sample_mode = 1;
+    return GH_OK;
 }
 
 // Spring forces of the own rows -> d_Fs and this rank's K best keys per query -> d_partial.
@@ -327,12 +333,11 @@ static gh_status step_merge(gh_engine *h, const uint64_t *gathered, int world) {
     GH_TRY(gh_knn_merge(h, gathered, world));
     GH_TRY(gh_launch_intersect(h));
     GH_TRY(gh_launch_integrate(h));
-    GH_TRY(gh_launch_inter_cleanup(h));
     return GH_OK;
 }
 
 static gh_status step_finish(gh_engine *h) {
-    GH_TRY(gh_launch_normalise(h));
+    GH_TRY(gh_launch_normalise(h, true));  // also zeroes what the intersection phase touched
     h->iter += 1;
     return GH_OK;
 }
@@ -428,9 +433,11 @@ extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32
     if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
     GH_TRY(set_sample(h, sampled, nullptr));
     GH_TRY(step_begin(h));  // the same kernels a step runs (spring forces are a by-product)
-    GH_TRY(gh_knn_merge(h, h->d_partial, 1));
-    GH_HIP(hipMemcpyAsync(knn, h->d_knn, sizeof(int32_t) * (size_t)h->S * h->k, hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint64_t> keys((size_t)h->S * h->K);
+    GH_HIP(hipMemcpyAsync(keys.data(), h->d_partial, sizeof(uint64_t) * keys.size(), hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipStreamSynchronize(h->stream));
+    for (int64_t s = 0; s < h->S; ++s)  // column 0 dropped blindly (pt.py:421)
+        for (int c = 1; c < h->K; ++c) knn[s * h->k + (c - 1)] = (int32_t)(keys[(size_t)s * h->K + c] & 0xFFFFFFFFu);
     return GH_OK;
 }
 
@@ -441,7 +448,13 @@ extern "C" gh_status gh_intersection_forces(gh_handle h, const int32_t *sampled,
     for (int64_t i = 0; i < h->S * h->k; ++i)
         if (knn[i] < 0 || knn[i] >= h->E) { h->err = "neighbour edge id out of range"; return GH_ERR_INVALID; }
     GH_TRY(set_sample(h, sampled, nullptr));
-    GH_HIP(hipMemcpyAsync(h->d_knn, knn, sizeof(int32_t) * (size_t)h->S * h->k, hipMemcpyHostToDevice, h->stream));
+    GH_TRY(gh_ensure_sample(h));
+    std::vector<uint64_t> keys((size_t)h->S * h->K, 0);  // the kernel reads ids from key columns 1..k
+    for (int64_t s = 0; s < h->S; ++s)
+        for (int c = 1; c < h->K; ++c) keys[(size_t)s * h->K + c] = (uint32_t)knn[s * h->k + (c - 1)];
+    GH_HIP(hipMemcpyAsync(h->d_merged, keys.data(), sizeof(uint64_t) * keys.size(), hipMemcpyHostToDevice, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    h->d_keys_cur = h->d_merged;
     GH_TRY(gh_launch_intersect(h));
     GH_TRY(gh_launch_inter_to_dense(h, h->d_tmpF));
     GH_TRY(gh_launch_inter_cleanup(h));
@@ -462,7 +475,7 @@ extern "C" gh_status gh_integrate_normalise(gh_handle h, const float *Fs, const 
     GH_TRY(gh_launch_integrate_given(h, h->d_tmpF, h->d_tmpF2));
     // normalise into scratch so the current positions stay unchanged
     GH_HIP(hipMemcpyAsync(h->d_tmpF, h->d_pos, sizeof(float) * (size_t)h->n * h->LD, hipMemcpyDeviceToDevice, h->stream));
-    GH_TRY(gh_launch_normalise(h));
+    GH_TRY(gh_launch_normalise(h, false));
     GH_TRY(gh_launch_unpad(h, h->d_pos, h->d_io));
     GH_HIP(hipMemcpyAsync(out, h->d_io, bytes, hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipMemcpyAsync(h->d_pos, h->d_tmpF, sizeof(float) * (size_t)h->n * h->LD, hipMemcpyDeviceToDevice, h->stream));

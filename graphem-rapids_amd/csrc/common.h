@@ -143,3 +143,31 @@ __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Device sampler: the t-th value of a keyed pseudo-random permutation of [0, E) (stands in for
+// torch.randperm(E)[t], pt.py:409).  A 4-round Feistel network on ceil(log2 E) bits with cycle
+// walking: every thread computes its own id, ids are distinct by construction, and every rank
+// gets the same ids for the same (seed, iteration).
+__device__ __forceinline__ uint32_t gh_mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__device__ inline int32_t gh_sample_id(int64_t E, uint64_t seed, uint64_t iter, int64_t t) {
+    int bits = 1;
+    while (((int64_t)1 << bits) < E) ++bits;
+    const int lb = bits / 2, hb = bits - lb;  // low / high half widths
+    const uint64_t lmask = ((uint64_t)1 << lb) - 1, hmask = ((uint64_t)1 << hb) - 1;
+    const uint64_t key = seed * 0x9E3779B97F4A7C15ull + iter * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull;
+    uint64_t x = (uint64_t)t;
+    do {
+        uint64_t lo = x & lmask, hi = (x >> lb) & hmask;
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            // alternate which half is modified so unequal widths stay a bijection
+            if ((rnd & 1) == 0) hi = (hi ^ gh_mix32(key + ((uint64_t)rnd << 56) + lo)) & hmask;
+            else lo = (lo ^ gh_mix32(key + ((uint64_t)rnd << 56) + hi)) & lmask;
+        }
+        x = (hi << lb) | lo;
+    } while ((int64_t)x >= E);
+    return (int32_t)x;
+}

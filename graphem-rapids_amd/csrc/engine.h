@@ -8,7 +8,7 @@
 #include "../../include/graphem_hip.h"
 
 // Candidate-list capacity per query in the filtered KNN scan, and the LDS sort size.
-#define GH_CAND_CAP 4096
+#define GH_CAND_CAP 8192
 #define GH_SEL_BUF 4096
 #define GH_SEL_CHUNK 2048
 // Candidate counters are padded to one per 128-byte line: adjacent counters serialise their
@@ -74,6 +74,8 @@ struct gh_engine {
     int32_t *d_sampled_cur = nullptr; // ids of the current iteration (d_sampled or a row of d_stream_ids)
     int32_t *d_stream_ids = nullptr;  // (iters, S) uploaded sample stream of gh_run
     size_t stream_ids_cap = 0;
+    bool sample_pending = false;  // ids of this iteration still to be produced (inside knn_setup_kernel)
+    int sample_mode = 0;          // 1 device sampler, 2 arange
     float *d_iscratch = nullptr;  // (S * k, LD) per-pair scratch of the intersection kernel
     float *d_q = nullptr;         // (S, QS) query records: midpoint coordinates + tau (knn.hip gh_qs)
     float *d_tau = nullptr;       // (S) squared-distance thresholds
@@ -82,7 +84,9 @@ struct gh_engine {
     int32_t *d_ovf = nullptr;     // (S)
     int32_t *d_dbg_cnt = nullptr; // (2, S) candidate-list lengths seen by the last subset / final select
     uint64_t *d_partial = nullptr;// (S, K) this rank's best keys, ascending
-    int32_t *d_knn = nullptr;     // (S, k)
+    int32_t *d_knn = nullptr;     // (S, k) neighbour ids (per-phase entry point output only)
+    uint64_t *d_merged = nullptr; // (S, K) keys merged over the ranks (world > 1)
+    const uint64_t *d_keys_cur = nullptr;  // keys the intersection phase reads: d_partial or d_merged
 
     // normalisation
     double *d_blockstats = nullptr; // (nblocks, 2, LD)
@@ -122,11 +126,12 @@ gh_status gh_launch_integrate(gh_engine *h);               // d_Fs, d_acc -> d_n
 gh_status gh_launch_spring_only(gh_engine *h, float *d_F); // F (n, LD), own rows
 gh_status gh_launch_inter_to_dense(gh_engine *h, float *d_F);
 gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi);
-gh_status gh_launch_normalise(gh_engine *h);               // d_new, d_stats -> d_pos rows
+gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup);  // d_new, d_stats -> d_pos rows (+ zero d_acc)
 gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD);
 gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD);
 gh_status gh_launch_sample(gh_engine *h);                  // device sampler -> d_sampled
 gh_status gh_launch_arange(gh_engine *h);
+gh_status gh_ensure_sample(gh_engine *h);                  // run a pending stand-alone sampler launch
 
 #define GH_HIP(call)                                                                        \
     do {                                                                                    \

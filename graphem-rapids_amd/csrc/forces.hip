@@ -167,7 +167,21 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double *__restr
 // mean / std from them.  Writes rows [row_lo, row_lo+rows) of pos.
 __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict__ nw, int64_t rows, int64_t row_lo,
                                                        int D, int LD, int64_t n, const double *__restrict__ stats,
-                                                       float *__restrict__ pos) {
+                                                       float *__restrict__ pos, double *__restrict__ acc,
+                                                       int32_t *__restrict__ tflag,
+                                                       const int32_t *__restrict__ touched,
+                                                       const int32_t *__restrict__ tcount) {
+    // also zero what the intersection phase touched (acc != nullptr): the integrate kernel that
+    // read those accumulators has finished; tcount itself is reset by the next KNN setup
+    if (acc) {
+        const int64_t nt = (int64_t)(*tcount) * LD;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t x = touched[t / LD];
+            const int d = (int)(t % LD);
+            acc[x * LD + d] = 0.0;
+            if (d == 0) tflag[x] = 0;
+        }
+    }
     extern __shared__ float ms[];  // mean[LD], std[LD]
     for (int d = threadIdx.x; d < LD; d += blockDim.x) {
         float mean = 0.0f, sd = 1.0f;
@@ -217,14 +231,15 @@ __device__ __forceinline__ float orient2d(const float *a, const float *b, const 
 __global__ __launch_bounds__(256) void intersect_kernel(const float *__restrict__ pos, int D, int LD,
                                                        const int32_t *__restrict__ edges,
                                                        const int32_t *__restrict__ sampled,
-                                                       const int32_t *__restrict__ knn, int64_t S, int k,
+                                                       const uint64_t *__restrict__ keys, int64_t S, int k,
                                                        float k_inter, double *__restrict__ acc,
                                                        int32_t *__restrict__ tflag, int32_t *__restrict__ touched,
                                                        int32_t *__restrict__ tcount, float *__restrict__ scratch) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= S * k) return;
     const int64_t r = t / k;
-    const int32_t i = sampled[r], j = knn[t];
+    // neighbour c of query r is key column c+1: column 0 is dropped blindly (pt.py:421)
+    const int32_t i = sampled[r], j = (int32_t)gh_key_id(keys[r * (k + 1) + (t - r * k) + 1]);
     if (!(i < j)) return;
     const int32_t v[4] = {edges[2 * (int64_t)i], edges[2 * (int64_t)i + 1], edges[2 * (int64_t)j], edges[2 * (int64_t)j + 1]};
     if (v[0] == v[2] || v[0] == v[3] || v[1] == v[2] || v[1] == v[3]) return;
@@ -289,33 +304,10 @@ __global__ void unpad_kernel(const float *__restrict__ src, int64_t n, int D, in
 }
 
 // ---------------------------------------------------------------------------------
-// Device sampler: S distinct edge ids, the first S values of a keyed pseudo-random
-// permutation of [0, E) (stands in for torch.randperm(E)[:S], pt.py:409).  A 4-round
-// Feistel network on ceil(log2 E) bits with cycle walking: every thread computes its
-// own id, no dedupe pass, same ids on every rank for the same (seed, iteration).
-__device__ __forceinline__ uint32_t mix32(uint64_t x) {
-    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
-    return (uint32_t)x;
-}
+// Stand-alone sampler launch (the hot path samples inside knn_setup_kernel instead).
 __global__ void sample_kernel(int64_t E, int64_t S, uint64_t seed, uint64_t iter, int32_t *__restrict__ sampled) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= S) return;
-    int bits = 1;
-    while (((int64_t)1 << bits) < E) ++bits;
-    const int lb = bits / 2, hb = bits - lb;  // low / high half widths
-    const uint64_t lmask = ((uint64_t)1 << lb) - 1, hmask = ((uint64_t)1 << hb) - 1;
-    const uint64_t key = seed * 0x9E3779B97F4A7C15ull + iter * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull;
-    uint64_t x = (uint64_t)t;
-    do {
-        uint64_t lo = x & lmask, hi = (x >> lb) & hmask;
-        for (int rnd = 0; rnd < 4; ++rnd) {
-            // alternate which half is modified so unequal widths stay a bijection
-            if ((rnd & 1) == 0) hi = (hi ^ mix32(key + ((uint64_t)rnd << 56) + lo)) & hmask;
-            else lo = (lo ^ mix32(key + ((uint64_t)rnd << 56) + hi)) & lmask;
-        }
-        x = (hi << lb) | lo;
-    } while ((int64_t)x >= E);
-    sampled[t] = (int32_t)x;
+    if (t < S) sampled[t] = gh_sample_id(E, seed, iter, t);
 }
 __global__ void arange_kernel(int64_t S, int32_t *__restrict__ sampled) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -429,7 +421,7 @@ gh_status gh_launch_intersect(gh_engine *h) {
     if (P == 0) return GH_OK;
     gh_scope t(h, "intersect");
     intersect_kernel<<<dim3(grid_for(P, 256)), dim3(256), 0, h->stream>>>(
-        h->d_pos, h->D, h->LD, h->d_edges, h->d_sampled_cur, h->d_knn, h->S, h->k, h->prm.k_inter, h->d_acc,
+        h->d_pos, h->D, h->LD, h->d_edges, h->d_sampled_cur, h->d_keys_cur, h->S, h->k, h->prm.k_inter, h->d_acc,
         h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch);
     GH_LAUNCH_CHECK();
     return GH_OK;
@@ -466,14 +458,15 @@ gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float
     return GH_OK;
 }
 
-gh_status gh_launch_normalise(gh_engine *h) {
-    if (h->rows == 0) return GH_OK;
+gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup) {
+    if (h->rows == 0) return with_cleanup ? gh_launch_inter_cleanup(h) : GH_OK;
     gh_scope t(h, "normalise");
     const int64_t total = h->rows * h->LD;
     unsigned grid = grid_for(total, 256);
     if (grid > 2048) grid = 2048;
     normalise_kernel<<<dim3(grid), dim3(256), sizeof(float) * 2 * h->LD, h->stream>>>(
-        h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos);
+        h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos,
+        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
@@ -501,4 +494,10 @@ gh_status gh_launch_arange(gh_engine *h) {
     arange_kernel<<<dim3(grid_for(h->S, 256)), dim3(256), 0, h->stream>>>(h->S, h->d_sampled);
     GH_LAUNCH_CHECK();
     return GH_OK;
+}
+
+gh_status gh_ensure_sample(gh_engine *h) {
+    if (!h->sample_pending) return GH_OK;
+    h->sample_pending = false;
+    return h->sample_mode == 2 ? gh_launch_arange(h) : gh_launch_sample(h);
 }

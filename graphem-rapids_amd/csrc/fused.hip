@@ -17,17 +17,38 @@
 #include "engine.h"
 #include "scan_core.h"
 
-int gh_fused_tile(int LD) { return LD <= 4 ? 2048 : LD <= 8 ? 1024 : 512; }
+#include <stdio.h>
+#include <stdlib.h>
+
+// Fused-kernel geometry: NT threads x R references per thread = owned edges per workgroup.
+// Measured on the 1M-vertex graph (D = 3): 256x8 225 us, 256x4 197 us -- the smaller tile costs
+// ~18 % more VALU work per pair but halves the LDS per workgroup, so twice as many workgroups
+// are resident and their gather / VALU phases interleave better.
+// GRAPHEM_HIP_FUSED_CFG="NT,R" overrides the LD = 4 default for experiments.
+static void fused_cfg(int LD, int *nt, int *r) {
+    *nt = 256;
+    *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
+    const char *e = getenv("GRAPHEM_HIP_FUSED_CFG");
+    if (e && LD <= 4) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 128 || a == 256) && (b == 2 || b == 4 || b == 8)) { *nt = a; *r = b; }
+    }
+}
+int gh_fused_tile(int LD) {
+    int nt, r;
+    fused_cfg(LD, &nt, &r);
+    return nt * r;
+}
 
 namespace {
 
-template <int D, int LD, int R>
-__global__ __launch_bounds__(256) void spring_scan_kernel(
+template <int D, int LD, int R, int NT>
+__global__ __launch_bounds__(NT) void spring_scan_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
     const int32_t *__restrict__ first_edge, const int32_t *__restrict__ vblock, int64_t row_lo, float L_min,
     float neg_k, float *__restrict__ Fs, const float *__restrict__ qt, int S, uint64_t *__restrict__ cand,
     int32_t *__restrict__ cnt) {
-    constexpr int TILE = 256 * R;
+    constexpr int TILE = NT * R;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     constexpr int HITBUF = TILE * LD * 4 / 16;  // hit records reuse the midpoint tile's LDS
     __shared__ float4 tile[TILE * LD / 4];
@@ -41,7 +62,7 @@ __global__ __launch_bounds__(256) void spring_scan_kernel(
     if (threadIdx.x == 0) hcount = 0;
 
     // ---- phase A: spring forces of the vertices v0..v1, midpoints of their owned edges to LDS
-    for (int i = v0 + threadIdx.x; i < v1; i += 256) {
+    for (int i = v0 + threadIdx.x; i < v1; i += NT) {
         const int64_t x = row_lo + i;
         float px[LD], F[LD];
         gh_load_row<LD>(pos, x, px);
@@ -57,7 +78,7 @@ __global__ __launch_bounds__(256) void spring_scan_kernel(
     uint32_t id[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int j = r * 256 + threadIdx.x;
+        const int j = r * NT + threadIdx.x;
         float mv[LD];
         if (j < nedges) {
             gh_load_row<LD>(mids, j, mv);
@@ -79,17 +100,17 @@ __global__ __launch_bounds__(256) void spring_scan_kernel(
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
         if (s_lo > 0) __syncthreads();  // the previous group's records are still being read
-        gh_stage_queries<QS>(qt, s_lo, nq, qsh);
+        gh_stage_queries<QS, NT>(qt, s_lo, nq, qsh);
         __syncthreads();
         gh_scan_queries<D, R, HITBUF>(m, id, qsh, nq, s_lo, hkey, hq, &hcount, cand, cnt);
     }
     __syncthreads();
-    gh_flush_hits<HITBUF>(hkey, hq, &hcount, cand, cnt);
+    gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
 }
 
-template <int D, int LD, int R>
+template <int D, int LD, int R, int NT>
 void launch(gh_engine *h) {
-    spring_scan_kernel<D, LD, R><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
+    spring_scan_kernel<D, LD, R, NT><<<dim3((unsigned)h->n_vblocks), dim3(NT), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
         h->d_Fs, h->d_q, (int)h->S, h->d_cand, h->d_cnt);
 }
@@ -99,14 +120,30 @@ void launch(gh_engine *h) {
 gh_status gh_launch_spring_scan(gh_engine *h) {
     if (h->n_vblocks == 0) return GH_OK;
     gh_scope t(h, "spring_scan");
-    switch (h->D) {
-        case 2: launch<2, 4, 8>(h); break;
-        case 3: launch<3, 4, 8>(h); break;
-        case 4: launch<4, 4, 8>(h); break;
-        case 8: launch<8, 8, 4>(h); break;
-        case 16: launch<16, 16, 2>(h); break;
-        default: h->err = "fused spring+scan launched for an unsupported dimension"; return GH_ERR_RUNTIME;
+    int nt, r;
+    fused_cfg(h->LD, &nt, &r);
+#define GH_FUSED_D(NTT, RR)                                   \
+    switch (h->D) {                                           \
+        case 2: launch<2, 4, RR, NTT>(h); break;              \
+        case 3: launch<3, 4, RR, NTT>(h); break;              \
+        default: launch<4, 4, RR, NTT>(h); break;             \
     }
+    if (h->LD == 4) {
+        if (nt == 256 && r == 8) { GH_FUSED_D(256, 8) }
+        else if (nt == 256 && r == 4) { GH_FUSED_D(256, 4) }
+        else if (nt == 256 && r == 2) { GH_FUSED_D(256, 2) }
+        else if (nt == 128 && r == 8) { GH_FUSED_D(128, 8) }
+        else if (nt == 128 && r == 4) { GH_FUSED_D(128, 4) }
+        else { GH_FUSED_D(128, 2) }
+    } else if (h->LD == 8) {
+        launch<8, 8, 4, 256>(h);
+    } else if (h->LD == 16) {
+        launch<16, 16, 2, 256>(h);
+    } else {
+        h->err = "fused spring+scan launched for an unsupported dimension";
+        return GH_ERR_RUNTIME;
+    }
+#undef GH_FUSED_D
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

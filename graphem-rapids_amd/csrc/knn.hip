@@ -22,24 +22,46 @@
 #include "scan_core.h"
 
 #include <math.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
 
 // ---------------------------------------------------------------------------------
-// Query midpoints (pt.py:785 for the sampled rows, pt.py:410) and list reset.
-__global__ void knn_prepare_kernel(const float *__restrict__ pos, const int32_t *__restrict__ edges,
-                                   const int32_t *__restrict__ sampled, int64_t S, int D, int LD,
-                                   float *__restrict__ qt, int32_t *__restrict__ cnt, int32_t *__restrict__ ovf) {
-    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (s >= S) return;
-    const int QS = gh_qs(D, LD);
-    const int64_t e = sampled[s];
+// One launch sets a KNN search up: (a) this iteration's sample ids -- given, drawn by the device
+// sampler, or arange when S >= E (pt.py:403-413); (b) the S query records: midpoint of the
+// sampled edge (pt.py:785, pt.py:410) + tau = inf, and the candidate-list reset; (c) the compact
+// copy of the midpoints of every `stride`-th own edge that the threshold kernel works on
+// (M1 ~ E/64 rows gathered from positions: the full midpoint array is never needed for it).
+// mode: 0 ids already in `sampled`, 1 device sampler, 2 arange.
+__global__ __launch_bounds__(256) void knn_setup_kernel(
+    const float *__restrict__ pos, const int32_t *__restrict__ edges, int32_t *__restrict__ sampled, int mode,
+    int64_t E, uint64_t seed, uint64_t iter, int64_t S, int D, int LD, float *__restrict__ qt,
+    int32_t *__restrict__ cnt, int32_t *__restrict__ ovf, int64_t e_lo, int64_t M1, int64_t stride,
+    float *__restrict__ midsub, int32_t *__restrict__ tcount) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t == 0) *tcount = 0;  // the previous iteration's normalise kernel has consumed it
+    if (t < S) {
+        int32_t e32;
+        if (mode == 1) { e32 = gh_sample_id(E, seed, iter, t); sampled[t] = e32; }
+        else if (mode == 2) { e32 = (int32_t)t; sampled[t] = e32; }
+        else e32 = sampled[t];
+        const int QS = gh_qs(D, LD);
+        const int64_t e = e32;
+        const int64_t u = edges[2 * e], v = edges[2 * e + 1];
+        for (int d = 0; d < QS; ++d) qt[t * QS + d] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
+        qt[t * QS + gh_qtau(D, LD)] = INFINITY;
+        cnt[t * GH_CNT_STRIDE] = 0;
+        ovf[t] = 0;
+        return;
+    }
+    const int64_t g = t - S;
+    if (g >= M1 * LD) return;
+    const int64_t j = g / LD;
+    const int d = (int)(g % LD);
+    const int64_t e = e_lo + j * stride;
     const int64_t u = edges[2 * e], v = edges[2 * e + 1];
-    for (int d = 0; d < QS; ++d) qt[s * QS + d] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
-    qt[s * QS + gh_qtau(D, LD)] = INFINITY;
-    cnt[s * GH_CNT_STRIDE] = 0;
-    ovf[s] = 0;
+    midsub[g] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
 }
 
 // Bitonic sort of n2 (power of two) keys in LDS by one 256-thread workgroup, ascending.
@@ -102,6 +124,28 @@ __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *o
 }
 
 #define GH_EXTRACT_MAX_K 64
+
+// K smallest of the c keys in src (LDS or global), by the smallest per-thread register count
+// that holds them: the cost of a round is proportional to the keys each thread rescans.
+template <int MAXNPT>
+__device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64_t *out, uint64_t (*red)[4]) {
+    auto run = [&](auto npt_tag) {
+        constexpr int NPT = decltype(npt_tag)::value;
+        uint64_t keys[NPT];
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = j * 256 + threadIdx.x;
+            keys[j] = i < c ? src[i] : GH_KEY_INF;
+        }
+        __syncthreads();  // src may alias out's neighbourhood in LDS; everyone has loaded
+        block_extract_smallest<NPT>(keys, K, out, red);
+    };
+    if (c <= 256) run(std::integral_constant<int, 1>{});
+    else if (c <= 1024 || MAXNPT <= 4) run(std::integral_constant<int, (MAXNPT < 4 ? MAXNPT : 4)>{});
+    else if (c <= 2048 || MAXNPT <= 8) run(std::integral_constant<int, (MAXNPT < 8 ? MAXNPT : 8)>{});
+    else if (c <= 4096 || MAXNPT <= 16) run(std::integral_constant<int, (MAXNPT < 16 ? MAXNPT : 16)>{});
+    else run(std::integral_constant<int, MAXNPT>{});
+}
 
 // ---------------------------------------------------------------------------------
 // One workgroup per query: exact K smallest (dist2, id) keys over the reference edges
@@ -280,20 +324,94 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
     gh_flush_hits<GH_SCAN_HITBUF>(hkey, hq, &hcount, cand, cnt);
 }
 
-// Compact copy of the midpoints of the edges e_lo + j*stride, j < M (the nested subsets the
-// threshold levels work on), gathered from positions: M is ~E/45, so this is cheap, and the
-// threshold stage no longer needs the full midpoint array.
-__global__ __launch_bounds__(256) void knn_subset_gather_kernel(const float *__restrict__ pos,
-                                                               const int32_t *__restrict__ edges, int64_t e_lo,
-                                                               int64_t M, int64_t stride, int D, int LD,
-                                                               float *__restrict__ out) {
-    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t >= M * LD) return;
-    const int64_t j = t / LD;
-    const int d = (int)(t % LD);
-    const int64_t e = e_lo + j * stride;
-    const int64_t u = edges[2 * e], v = edges[2 * e + 1];
-    out[t] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
+// Threshold kernel: one workgroup per query streams the compact subset (M1 rows, coalesced
+// 16-byte loads, L2-resident) and returns tau = the K-th smallest squared distance in it: an
+// upper bound of the true K-th distance, since the K-th order statistic of a subset can only be
+// larger.  Survivors of the running threshold are parked in LDS; the K smallest are extracted
+// only when the buffer could overflow (twice in practice) and at the end.
+template <int LD>
+__global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restrict__ midsub, int64_t M1, int D,
+                                                            float *__restrict__ qt, int QS, int QT, int K) {
+    constexpr int BUF = 4096, NPT = BUF / 256;
+    constexpr int RPT = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;  // rows per thread per pass (2048 / 1024 / 512 rows)
+    __shared__ uint64_t buf[BUF];
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[2][4];
+    __shared__ int cnt;
+    __shared__ float qs[LD];
+    const int64_t qi = blockIdx.x;
+    if (threadIdx.x < LD) qs[threadIdx.x] = threadIdx.x < D ? qt[qi * QS + threadIdx.x] : 0.0f;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    float q[LD];
+#pragma unroll
+    for (int d = 0; d < LD; ++d) q[d] = qs[d];
+    float tau = INFINITY;
+
+    auto cut = [&](int c) {  // keep the K smallest of buf[0..c), tighten tau
+        block_extract_adaptive<NPT>(buf, c, K, best, red);
+        if (threadIdx.x < K) buf[threadIdx.x] = best[threadIdx.x];
+        if (threadIdx.x == 0) cnt = c < K ? c : K;
+        tau = c >= K ? gh_key_d2(best[K - 1]) : INFINITY;
+        __syncthreads();
+    };
+
+    // pass 0: the first 2048 rows all survive (tau = inf) and establish the threshold
+    const int64_t head = M1 < 2048 ? M1 : 2048;
+    for (int64_t r = threadIdx.x; r < head; r += 256) {
+        float mv[LD];
+        gh_load_row<LD>(midsub, r, mv);
+        float s = 0.0f;
+#pragma unroll
+        for (int d = 0; d < LD; ++d) {  // pad columns are 0 on both sides: fma(0,0,s) == s
+            const float t = q[d] - mv[d];
+            s = fmaf(t, t, s);
+        }
+        buf[atomicAdd(&cnt, 1)] = gh_key(s, (uint32_t)r);
+    }
+    __syncthreads();
+    cut(cnt);
+    // later passes: RPT rows per thread, the NEXT pass's loads are issued before this pass is
+    // processed so the L2 latency overlaps the compute; survivors are rare
+    float nxt[RPT][LD];
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) {
+        const int64_t r = head + j * 256 + threadIdx.x;
+        gh_load_row<LD>(midsub, r < M1 ? r : 0, nxt[j]);
+    }
+    for (int64_t base = head; base < M1; base += 256 * RPT) {
+        float mv[RPT][LD];
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+#pragma unroll
+            for (int d = 0; d < LD; ++d) mv[j][d] = nxt[j][d];
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int64_t r = base + 256 * RPT + j * 256 + threadIdx.x;
+            gh_load_row<LD>(midsub, r < M1 ? r : 0, nxt[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int64_t r = base + j * 256 + threadIdx.x;
+            float s = 0.0f;
+#pragma unroll
+            for (int d = 0; d < LD; ++d) {
+                const float t = q[d] - mv[j][d];
+                s = fmaf(t, t, s);
+            }
+            if (r < M1 && s <= tau) {
+                const int p = atomicAdd(&cnt, 1);
+                if (p < BUF) buf[p] = gh_key(s, (uint32_t)r);
+            }
+        }
+        // No barrier in this loop: with tau set the buffer fills by ~K/pass.  Should it ever fill up
+        // (thousands of rows within tau: ties), further survivors are dropped, which keeps tau a
+        // valid -- merely looser -- upper bound.
+    }
+    __syncthreads();
+    cut(cnt < BUF ? cnt : BUF);
+    if (threadIdx.x == 0) qt[qi * QS + QT] = tau;
 }
 
 // One workgroup per query: K smallest of the candidate list; final -> K best keys, else tighten tau.
@@ -313,13 +431,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
         if (final_level && threadIdx.x == 0) ovf[qi] = 1;
         return;  // tau keeps its previous (still valid, looser) value
     }
-    uint64_t keys[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; ++j) {
-        const int i = j * 256 + threadIdx.x;
-        keys[j] = i < c ? cand[qi * GH_CAND_CAP + i] : GH_KEY_INF;
-    }
-    block_extract_smallest<NPT>(keys, K, best, red);
+    block_extract_adaptive<NPT>(cand + qi * GH_CAND_CAP, c, K, best, red);
     if (final_level) {
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
     } else if (threadIdx.x == 0) {
@@ -327,10 +439,11 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     }
 }
 
-// Merge the per-rank key lists (world, S, K) -> neighbour ids with column 0 dropped
-// (pt.py:421: knn_indices[:, 1:]).  world == 1 degenerates to a copy.
+// Merge the per-rank key lists (world, S, K) into the K globally best keys per query (S, K).
+// Only launched for world > 1; the intersection phase reads keys and drops column 0 itself
+// (pt.py:421: knn_indices[:, 1:]).
 __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restrict__ gathered, int world, int64_t S,
-                                                        int K, int32_t *__restrict__ knn) {
+                                                        int K, uint64_t *__restrict__ merged) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t *buf = reinterpret_cast<uint64_t *>(smem_raw);
     const int64_t qi = blockIdx.x;
@@ -345,8 +458,8 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restri
         buf[i] = key;
     }
     __syncthreads();
-    if (world > 1) block_sort(buf, n2);
-    for (int c = 1 + threadIdx.x; c < K; c += blockDim.x) knn[qi * (K - 1) + (c - 1)] = (int32_t)gh_key_id(buf[c]);
+    block_sort(buf, n2);
+    for (int c = threadIdx.x; c < K; c += blockDim.x) merged[qi * K + c] = buf[c];
 }
 
 template <int D, int R>
@@ -394,25 +507,14 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
     }
 }
 
-struct level_plan {
-    int L;
-    std::vector<int64_t> strides;  // strides[L] == 1 (all edges); strides[l-1] = r * strides[l]
-};
-
-// Nested strided subsets, ratio r between levels, ~2048 edges at level 0.
-level_plan plan_levels(int64_t Mtot, int K) {
-    int rmax = 1536 / K;
-    if (rmax > 64) rmax = 64;
-    if (rmax < 2) rmax = 2;
-    const double want = (double)Mtot / 2048.0;
-    level_plan p;
-    p.L = 1;
-    while (pow((double)rmax, p.L) < want) ++p.L;
-    int64_t r = (int64_t)ceil(pow(want, 1.0 / p.L));
+// Stride of the threshold subset: the final pass then sees ~K*stride candidates per query
+// (mean; the list holds 4096), the threshold kernel streams E/stride rows per query.
+int64_t subset_stride(int64_t Mtot, int K) {
+    int64_t r = 1408 / K;
+    if (r > 128) r = 128;
     if (r < 2) r = 2;
-    p.strides.assign((size_t)p.L + 1, 1);
-    for (int l = p.L - 1; l >= 0; --l) p.strides[(size_t)l] = p.strides[(size_t)l + 1] * r;
-    return p;
+    while (r > 2 && Mtot / r < 4 * (int64_t)K) r /= 2;  // keep the subset well above K rows
+    return r;
 }
 
 gh_status launch_select(gh_engine *h, bool final_level) {
@@ -431,45 +533,37 @@ bool gh_knn_scan_path(const gh_engine *h) {
     return Mtot >= GH_SCAN_MIN_EDGES && h->LD <= 16 && h->D >= 2 && h->K <= GH_EXTRACT_MAX_K && h->S <= 0x7FFFFFFF;
 }
 
-// Query records + list reset.
+// Sample ids (if still pending), query records, list reset and -- on the scan path -- the compact
+// threshold subset: one launch.
 gh_status gh_knn_prepare(gh_engine *h) {
-    gh_scope t(h, "knn_prepare");
-    const int bs = 256;
-    knn_prepare_kernel<<<dim3((unsigned)((h->S + bs - 1) / bs)), dim3(bs), 0, h->stream>>>(
-        h->d_pos, h->d_edges, h->d_sampled_cur, h->S, h->D, h->LD, h->d_q, h->d_cnt, h->d_ovf);
+    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    const bool scan = gh_knn_scan_path(h);
+    const int64_t st = scan ? subset_stride(Mtot, h->K) : 1;
+    const int64_t M1 = scan ? (Mtot + st - 1) / st : 0;
+    const int mode = h->sample_pending ? h->sample_mode : 0;
+    h->sample_pending = false;
+    gh_scope t(h, "knn_setup");
+    const int64_t threads = h->S + M1 * h->LD;
+    knn_setup_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream>>>(
+        h->d_pos, h->d_edges, h->d_sampled_cur, mode, h->E, h->prm.seed, h->iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
+        h->d_ovf, h->part.edge_lo, M1, st, h->d_midsub, h->d_tcount);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
 
-// Thresholds for the final level: every level but the last, on a compact gathered copy of the
-// largest proper subset.  Needs gh_knn_scan_path(h).
+// tau of every query from the compact subset (gh_knn_prepare made it).  Needs gh_knn_scan_path(h).
 gh_status gh_knn_thresholds(gh_engine *h) {
     const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
-    const level_plan p = plan_levels(Mtot, h->K);
-    const int64_t s1 = p.strides[(size_t)p.L - 1];  // stride of the largest proper subset
-    const int64_t M1 = (Mtot + s1 - 1) / s1;
-    {
-        gh_scope t(h, "knn_subset_gather");
-        knn_subset_gather_kernel<<<dim3((unsigned)((M1 * h->LD + 255) / 256)), dim3(256), 0, h->stream>>>(
-            h->d_pos, h->d_edges, h->part.edge_lo, M1, s1, h->D, h->LD, h->d_midsub);
-        GH_LAUNCH_CHECK();
+    const int64_t st = subset_stride(Mtot, h->K);
+    const int64_t M1 = (Mtot + st - 1) / st;
+    const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
+    gh_scope t(h, "knn_threshold");
+    switch (h->LD) {
+        case 4: knn_threshold_kernel<4><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, QS, QT, h->K); break;
+        case 8: knn_threshold_kernel<8><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, QS, QT, h->K); break;
+        default: knn_threshold_kernel<16><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, QS, QT, h->K); break;
     }
-    {
-        gh_scope t(h, "knn_level0_select");
-        const int64_t M0 = (Mtot + p.strides[0] - 1) / p.strides[0];
-        launch_block_select(h, h->d_midsub, M0, p.strides[0] / s1, p.strides[0], nullptr, nullptr, true);
-        GH_LAUNCH_CHECK();
-    }
-    for (int l = 1; l < p.L; ++l) {
-        const int64_t st = p.strides[(size_t)l];
-        const int64_t M = (Mtot + st - 1) / st;
-        {
-            gh_scope t(h, "knn_scan_subset");
-            launch_scan_d<2>(h, h->d_midsub, M, st / s1, st);
-            GH_LAUNCH_CHECK();
-        }
-        GH_TRY_ST(launch_select(h, false));
-    }
+    GH_LAUNCH_CHECK();
     return GH_OK;
 }
 
@@ -504,6 +598,10 @@ gh_status gh_knn_local(gh_engine *h) {
 }
 
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {
+    if (world == 1) {  // nothing to merge: the intersection phase reads this rank's keys directly
+        h->d_keys_cur = gathered;
+        return GH_OK;
+    }
     const int total = world * h->K;
     int n2 = 2;
     while (n2 < total) n2 <<= 1;
@@ -513,7 +611,8 @@ gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {
     }
     gh_scope t(h, "knn_merge");
     knn_merge_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(uint64_t) * (size_t)n2, h->stream>>>(
-        gathered, world, h->S, h->K, h->d_knn);
+        gathered, world, h->S, h->K, h->d_merged);
     GH_LAUNCH_CHECK();
+    h->d_keys_cur = h->d_merged;
     return GH_OK;
 }

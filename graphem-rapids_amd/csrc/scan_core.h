@@ -19,10 +19,10 @@ __device__ __forceinline__ void gh_append_candidate(uint64_t *__restrict__ cand,
 }
 
 // Stage nq query records (plus one spare for the prefetch) of the group starting at s_lo.
-template <int QS>
+template <int QS, int NT = 256>
 __device__ __forceinline__ void gh_stage_queries(const float *__restrict__ qt, int s_lo, int nq, float4 *qsh) {
     const float4 *src = reinterpret_cast<const float4 *>(qt) + (int64_t)s_lo * (QS / 4);
-    for (int i = threadIdx.x; i < (nq + 1) * (QS / 4); i += 256)
+    for (int i = threadIdx.x; i < (nq + 1) * (QS / 4); i += NT)
         qsh[i] = i < nq * (QS / 4) ? src[i] : make_float4(0.f, 0.f, 0.f, -1.f);
 }
 
@@ -81,9 +81,9 @@ __device__ __forceinline__ void gh_scan_queries(const gh_f2 (&m)[R / 2][D], cons
     }
 }
 
-template <int HITBUF>
+template <int HITBUF, int NT = 256>
 __device__ __forceinline__ void gh_flush_hits(const uint64_t *hkey, const int *hq, const int *hcount,
                                               uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
     const int nh = min(*hcount, HITBUF);
-    for (int i = threadIdx.x; i < nh; i += 256) gh_append_candidate(cand, cnt, hq[i], hkey[i]);
+    for (int i = threadIdx.x; i < nh; i += NT) gh_append_candidate(cand, cnt, hq[i], hkey[i]);
 }
