@@ -78,7 +78,7 @@ struct gh_engine {
     int sample_mode = 0;          // 1 device sampler, 2 arange
     float *d_iscratch = nullptr;  // (S * k, LD) per-pair scratch of the intersection kernel
     float *d_q = nullptr;         // (S, QS) query records: midpoint coordinates + tau (knn.hip gh_qs)
-    float *d_tau = nullptr;       // (S) squared-distance thresholds
+    float *d_qscan = nullptr;     // (S, QS) pre-filter records (-2q, t) written by the threshold kernel
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
     int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line
     int32_t *d_ovf = nullptr;     // (S)
@@ -114,7 +114,7 @@ gh_status gh_knn_prepare(gh_engine *h);
 gh_status gh_knn_thresholds(gh_engine *h);
 gh_status gh_knn_finish(gh_engine *h, bool have_mid);
 // fused.hip
-int gh_fused_tile(int LD);                                 // edges per fused workgroup
+int gh_fused_tile(int LD, int64_t own_edges);              // edges per fused workgroup
 gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -> d_knn
 // forces.hip

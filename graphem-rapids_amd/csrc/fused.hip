@@ -25,18 +25,21 @@
 // ~18 % more VALU work per pair but halves the LDS per workgroup, so twice as many workgroups
 // are resident and their gather / VALU phases interleave better.
 // GRAPHEM_HIP_FUSED_CFG="NT,R" overrides the LD = 4 default for experiments.
-static void fused_cfg(int LD, int *nt, int *r) {
+// Small graphs get smaller tiles so that there are still >= ~1000 workgroups for 256 CUs.
+static void fused_cfg(int LD, int64_t own_edges, int *nt, int *r) {
     *nt = 256;
     *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
+    if (LD <= 4 && own_edges < 1500000) *r = 2;
+    if (LD <= 4 && own_edges < 400000) *nt = 128;
     const char *e = getenv("GRAPHEM_HIP_FUSED_CFG");
     if (e && LD <= 4) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 128 || a == 256) && (b == 2 || b == 4 || b == 8)) { *nt = a; *r = b; }
     }
 }
-int gh_fused_tile(int LD) {
+int gh_fused_tile(int LD, int64_t own_edges) {
     int nt, r;
-    fused_cfg(LD, &nt, &r);
+    fused_cfg(LD, own_edges, &nt, &r);
     return nt * r;
 }
 
@@ -46,8 +49,8 @@ template <int D, int LD, int R, int NT>
 __global__ __launch_bounds__(NT) void spring_scan_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
     const int32_t *__restrict__ first_edge, const int32_t *__restrict__ vblock, int64_t row_lo, float L_min,
-    float neg_k, float *__restrict__ Fs, const float *__restrict__ qt, int S, uint64_t *__restrict__ cand,
-    int32_t *__restrict__ cnt) {
+    float neg_k, float *__restrict__ Fs, const float *__restrict__ qt, const float *__restrict__ qscan, int S,
+    uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
     constexpr int TILE = NT * R;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     constexpr int HITBUF = TILE * LD * 4 / 16;  // hit records reuse the midpoint tile's LDS
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     __syncthreads();
 
     // ---- phase B: the tile becomes this workgroup's references
-    gh_f2 m[R / 2][D];
+    gh_f2 m[R / 2][D], c0[R / 2];
     uint32_t id[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -85,9 +88,11 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
             id[r] = (uint32_t)(fe0 + j);
         } else {
 #pragma unroll
-            for (int d = 0; d < LD; ++d) mv[d] = INFINITY;  // dist2 = inf never passes dist2 <= tau
+            for (int d = 0; d < LD; ++d) mv[d] = 0.0f;  // padding slot: c0 = +inf never passes the filter
             id[r] = 0xFFFFFFFFu;
         }
+        const float c = gh_ref_c0<D>(mv, j < nedges);
+        if (r & 1) c0[r / 2].y = c; else c0[r / 2].x = c;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if (r & 1) m[r / 2][d].y = mv[d];
@@ -100,9 +105,9 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
         if (s_lo > 0) __syncthreads();  // the previous group's records are still being read
-        gh_stage_queries<QS, NT>(qt, s_lo, nq, qsh);
+        gh_stage_queries<QS, NT>(qscan, s_lo, nq, qsh);
         __syncthreads();
-        gh_scan_queries<D, R, HITBUF>(m, id, qsh, nq, s_lo, hkey, hq, &hcount, cand, cnt);
+        gh_scan_queries<D, R, HITBUF>(m, c0, id, qsh, nq, s_lo, qt, hkey, hq, &hcount, cand, cnt);
     }
     __syncthreads();
     gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
@@ -112,7 +117,7 @@ template <int D, int LD, int R, int NT>
 void launch(gh_engine *h) {
     spring_scan_kernel<D, LD, R, NT><<<dim3((unsigned)h->n_vblocks), dim3(NT), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
-        h->d_Fs, h->d_q, (int)h->S, h->d_cand, h->d_cnt);
+        h->d_Fs, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt);
 }
 
 }  // namespace
@@ -121,7 +126,7 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
     if (h->n_vblocks == 0) return GH_OK;
     gh_scope t(h, "spring_scan");
     int nt, r;
-    fused_cfg(h->LD, &nt, &r);
+    fused_cfg(h->LD, h->part.edge_hi - h->part.edge_lo, &nt, &r);
 #define GH_FUSED_D(NTT, RR)                                   \
     switch (h->D) {                                           \
         case 2: launch<2, 4, RR, NTT>(h); break;              \

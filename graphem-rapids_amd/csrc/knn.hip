@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void knn_block_select_sort_kernel(
 template <int D, int R>
 __global__ __launch_bounds__(256) void knn_scan_kernel(
     const float *__restrict__ mid, int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride,
-    const float *__restrict__ qt, int S, int qgroup, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
+    const float *__restrict__ qt, const float *__restrict__ qscan, int S, int qgroup,
+    uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
     static_assert(R % 2 == 0, "references are processed in packed pairs");
     constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
     if (threadIdx.x == 0) hcount = 0;
     const int s_lo = blockIdx.y * qgroup;
     const int nq = min(S - s_lo, qgroup);
-    gh_stage_queries<QS>(qt, s_lo, nq, qsh);
-    gh_f2 m[R / 2][D];
+    gh_stage_queries<QS>(qscan, s_lo, nq, qsh);
+    gh_f2 m[R / 2][D], c0[R / 2];
     uint32_t id[R];
     const int64_t tile = (int64_t)blockIdx.x * (256 * R);
 #pragma unroll
@@ -309,9 +310,11 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
             id[r] = (uint32_t)(e_lo + j * stride);
         } else {
 #pragma unroll
-            for (int d = 0; d < LD; ++d) mv[d] = INFINITY;  // dist2 = inf never passes dist2 <= tau
+            for (int d = 0; d < LD; ++d) mv[d] = 0.0f;  // padding slot: c0 = +inf never passes the filter
             id[r] = 0xFFFFFFFFu;
         }
+        const float c = gh_ref_c0<D>(mv, j < M);
+        if (r & 1) c0[r / 2].y = c; else c0[r / 2].x = c;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if (r & 1) m[r / 2][d].y = mv[d];
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
         }
     }
     __syncthreads();
-    gh_scan_queries<D, R, GH_SCAN_HITBUF>(m, id, qsh, nq, s_lo, hkey, hq, &hcount, cand, cnt);
+    gh_scan_queries<D, R, GH_SCAN_HITBUF>(m, c0, id, qsh, nq, s_lo, qt, hkey, hq, &hcount, cand, cnt);
     __syncthreads();
     gh_flush_hits<GH_SCAN_HITBUF>(hkey, hq, &hcount, cand, cnt);
 }
@@ -331,7 +334,8 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
 // only when the buffer could overflow (twice in practice) and at the end.
 template <int LD>
 __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restrict__ midsub, int64_t M1, int D,
-                                                            float *__restrict__ qt, int QS, int QT, int K) {
+                                                            float *__restrict__ qt, float *__restrict__ qscan,
+                                                            int QS, int QT, int K) {
     constexpr int BUF = 4096, NPT = BUF / 256;
     constexpr int RPT = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;  // rows per thread per pass (2048 / 1024 / 512 rows)
     __shared__ uint64_t buf[BUF];
@@ -411,7 +415,15 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
     }
     __syncthreads();
     cut(cnt < BUF ? cnt : BUF);
-    if (threadIdx.x == 0) qt[qi * QS + QT] = tau;
+    if (threadIdx.x == 0) {
+        qt[qi * QS + QT] = tau;
+        // scan record of the pre-filter (scan_core.h): (-2q, t),  t = tau - |q|^2 + eps*(2|q|^2 + tau)
+        float qn = 0.0f;
+        for (int d = 0; d < D; ++d) qn = fmaf(qs[d], qs[d], qn);
+        for (int d = 0; d < QS; ++d) qscan[qi * QS + d] = d < D ? -2.0f * qs[d] : 0.0f;
+        const float eps = gh_filter_eps(D);
+        qscan[qi * QS + QT] = fmaf(eps, fmaf(2.0f, qn, tau), tau - qn);
+    }
 }
 
 // One workgroup per query: K smallest of the candidate list; final -> K best keys, else tighten tau.
@@ -475,7 +487,7 @@ void launch_scan(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, 
     if (qgroup > GH_SCAN_QGROUP) qgroup = GH_SCAN_QGROUP;
     groups = (int)((h->S + qgroup - 1) / qgroup);
     knn_scan_kernel<D, R><<<dim3((unsigned)tiles, (unsigned)groups), dim3(256), 0, h->stream>>>(
-        mid, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, (int)h->S, qgroup, h->d_cand, h->d_cnt);
+        mid, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, h->d_qscan, (int)h->S, qgroup, h->d_cand, h->d_cnt);
 }
 
 template <int R>
@@ -508,10 +520,14 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
 }
 
 // Stride of the threshold subset: the final pass then sees ~K*stride candidates per query
-// (mean; the list holds 4096), the threshold kernel streams E/stride rows per query.
-int64_t subset_stride(int64_t Mtot, int K) {
+// (mean; the list holds GH_CAND_CAP), the threshold kernel streams E/stride rows per query.
+// A workgroup of the final pass parks its hits in LDS: S*K*stride*tile/E of them on average,
+// kept near 300 so the buffer (>= 1024 entries) does not overflow into the slow direct path.
+int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile) {
     int64_t r = 1408 / K;
     if (r > 128) r = 128;
+    const int64_t by_hits = (int64_t)(300.0 * (double)Mtot / ((double)S * K * tile));
+    if (r > by_hits) r = by_hits;
     if (r < 2) r = 2;
     while (r > 2 && Mtot / r < 4 * (int64_t)K) r /= 2;  // keep the subset well above K rows
     return r;
@@ -538,7 +554,7 @@ bool gh_knn_scan_path(const gh_engine *h) {
 gh_status gh_knn_prepare(gh_engine *h) {
     const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
     const bool scan = gh_knn_scan_path(h);
-    const int64_t st = scan ? subset_stride(Mtot, h->K) : 1;
+    const int64_t st = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h->LD, Mtot)) : 1;
     const int64_t M1 = scan ? (Mtot + st - 1) / st : 0;
     const int mode = h->sample_pending ? h->sample_mode : 0;
     h->sample_pending = false;
@@ -554,14 +570,14 @@ gh_status gh_knn_prepare(gh_engine *h) {
 // tau of every query from the compact subset (gh_knn_prepare made it).  Needs gh_knn_scan_path(h).
 gh_status gh_knn_thresholds(gh_engine *h) {
     const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
-    const int64_t st = subset_stride(Mtot, h->K);
+    const int64_t st = subset_stride(Mtot, h->K, h->S, gh_fused_tile(h->LD, Mtot));
     const int64_t M1 = (Mtot + st - 1) / st;
     const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
     gh_scope t(h, "knn_threshold");
     switch (h->LD) {
-        case 4: knn_threshold_kernel<4><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, QS, QT, h->K); break;
-        case 8: knn_threshold_kernel<8><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, QS, QT, h->K); break;
-        default: knn_threshold_kernel<16><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, QS, QT, h->K); break;
+        case 4: knn_threshold_kernel<4><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, h->d_qscan, QS, QT, h->K); break;
+        case 8: knn_threshold_kernel<8><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, h->d_qscan, QS, QT, h->K); break;
+        default: knn_threshold_kernel<16><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, h->d_qscan, QS, QT, h->K); break;
     }
     GH_LAUNCH_CHECK();
     return GH_OK;
