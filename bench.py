@@ -48,6 +48,20 @@ def make_workload(name, seed=0):
     return n, D, k, S, edges, pos
 
 
+def pmc_traffic(workload, kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, gfx950 correction applied; tools/profile_round.sh writes the file).
+    bench.py cannot run the profiler on itself, so this is the latest committed measurement, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "final", f"traffic_{workload}.json")))
+    if not files:
+        return None, None
+    rec = json.load(open(files[-1]))
+    if rec.get("kernel") != kernel:
+        return None, None
+    return rec["traffic_bytes"], os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(n, D, k, S, edges, pos, budget_s=20.0):
     """The CPU oracle (a port of the reference's algorithm, OpenMP over the KNN queries) timed on
     this host for a bounded number of iterations of the SAME workload."""
@@ -155,6 +169,10 @@ def main():
                         "pipe": "fp32 VALU, packed v_pk_*_f32 (vector fp32 peak = dense fp32 MFMA peak)",
                         "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_PEAK,
                         "traffic": None, "avg_launch_us": scan_us, "algorithmic_flops_per_launch": flops_scan}
+            if world == 1:
+                tb, src = pmc_traffic(args.workload, dom)
+                roofline["traffic"] = tb
+                roofline["traffic_source"] = src
         b_iter = 16.0 * E + 36.0 * n * D                       # B_iter = 16E + 36nD
         hbm = {"bound": "hbm", "achieved": b_iter / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                "frac": b_iter / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_iter": b_iter, "traffic": None}

@@ -318,20 +318,22 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
 }
 
 // Spring forces of the own rows -> d_Fs and this rank's K best keys per query -> d_partial.
-static gh_status step_begin(gh_engine *h) {
+// fuse_intersect: single-rank step, the KNN kernels also run the intersection phase.
+static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
+    h->intersect_done = false;
     if (h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused) {
         GH_TRY(gh_knn_prepare(h));
         GH_TRY(gh_knn_thresholds(h));
         GH_TRY(gh_launch_spring_scan(h));
-        return gh_knn_finish(h, false);
+        return gh_knn_finish(h, false, fuse_intersect);
     }
     GH_TRY(gh_launch_spring_mid(h));
-    return gh_knn_local(h);
+    return gh_knn_local(h, fuse_intersect);
 }
 
 static gh_status step_merge(gh_engine *h, const uint64_t *gathered, int world) {
     GH_TRY(gh_knn_merge(h, gathered, world));
-    GH_TRY(gh_launch_intersect(h));
+    if (!h->intersect_done) GH_TRY(gh_launch_intersect(h));
     GH_TRY(gh_launch_integrate(h));
     return GH_OK;
 }
@@ -346,7 +348,7 @@ extern "C" gh_status gh_step(gh_handle h, const int32_t *sampled) {
     GH_TRY(check_handle(h));
     GH_TRY(check_k(h));
     GH_TRY(set_sample(h, sampled, nullptr));
-    GH_TRY(step_begin(h));
+    GH_TRY(step_begin(h, true));
     GH_TRY(step_merge(h, h->d_partial, 1));
     return step_finish(h);
 }
@@ -371,7 +373,7 @@ extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_st
     }
     for (int32_t t = 0; t < iters; ++t) {
         GH_TRY(set_sample(h, nullptr, use_stream ? h->d_stream_ids + (size_t)t * h->S : nullptr));
-        GH_TRY(step_begin(h));
+        GH_TRY(step_begin(h, true));
         GH_TRY(step_merge(h, h->d_partial, 1));
         GH_TRY(step_finish(h));
     }
@@ -391,7 +393,7 @@ extern "C" gh_status gh_step_begin(gh_handle h, const int32_t *sampled) {
     GH_TRY(check_handle(h));
     GH_TRY(check_k(h));
     GH_TRY(set_sample(h, sampled, nullptr));
-    return step_begin(h);
+    return step_begin(h, false);
 }
 extern "C" gh_status gh_set_stream(gh_handle h, void *hip_stream, int32_t use_own) {
     GH_TRY(check_handle(h));
@@ -432,7 +434,7 @@ extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32
     GH_TRY(check_k(h));
     if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
     GH_TRY(set_sample(h, sampled, nullptr));
-    GH_TRY(step_begin(h));  // the same kernels a step runs (spring forces are a by-product)
+    GH_TRY(step_begin(h, false));  // the same kernels a step runs (spring forces are a by-product)
     std::vector<uint64_t> keys((size_t)h->S * h->K);
     GH_HIP(hipMemcpyAsync(keys.data(), h->d_partial, sizeof(uint64_t) * keys.size(), hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipStreamSynchronize(h->stream));

@@ -74,6 +74,7 @@ struct gh_engine {
     int32_t *d_sampled_cur = nullptr; // ids of the current iteration (d_sampled or a row of d_stream_ids)
     int32_t *d_stream_ids = nullptr;  // (iters, S) uploaded sample stream of gh_run
     size_t stream_ids_cap = 0;
+    bool intersect_done = false;  // the KNN kernels of this step already ran the intersection phase
     bool sample_pending = false;  // ids of this iteration still to be produced (inside knn_setup_kernel)
     int sample_mode = 0;          // 1 device sampler, 2 arange
     float *d_iscratch = nullptr;  // (S * k, LD) per-pair scratch of the intersection kernel
@@ -108,11 +109,11 @@ struct gh_scope {
 };
 
 // knn.hip
-gh_status gh_knn_local(gh_engine *h);                      // d_sampled, d_mid -> d_partial (unfused)
+gh_status gh_knn_local(gh_engine *h, bool fuse_intersect);  // d_sampled, d_mid -> d_partial (unfused)
 bool gh_knn_scan_path(const gh_engine *h);
 gh_status gh_knn_prepare(gh_engine *h);
 gh_status gh_knn_thresholds(gh_engine *h);
-gh_status gh_knn_finish(gh_engine *h, bool have_mid);
+gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
 // fused.hip
 int gh_fused_tile(int LD, int64_t own_edges);              // edges per fused workgroup
 gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel

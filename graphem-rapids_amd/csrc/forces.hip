@@ -4,6 +4,7 @@
 // (pt.py:796-804), plus the sampler that stands in for torch.randperm (pt.py:409).
 #include "common.h"
 #include "engine.h"
+#include "intersect_core.h"
 
 namespace {
 
@@ -224,10 +225,6 @@ __global__ __launch_bounds__(256) void integrate_given_kernel(const float *__res
 //   k_inter * (x - c) / (|x - c| + 1e-6)^2,   c = (((p1 + p2) + q1) + q2) / 4
 // (pt.py:722-734).  Contributions are summed in fp64 atomics: with the handful of terms
 // a vertex receives the fp64 sum is exact, hence independent of arrival order.
-__device__ __forceinline__ float orient2d(const float *a, const float *b, const float *c) {
-    return (b[0] - a[0]) * (c[1] - a[1]) - (b[1] - a[1]) * (c[0] - a[0]);
-}
-
 __global__ __launch_bounds__(256) void intersect_kernel(const float *__restrict__ pos, int D, int LD,
                                                        const int32_t *__restrict__ edges,
                                                        const int32_t *__restrict__ sampled,
@@ -240,27 +237,7 @@ __global__ __launch_bounds__(256) void intersect_kernel(const float *__restrict_
     const int64_t r = t / k;
     // neighbour c of query r is key column c+1: column 0 is dropped blindly (pt.py:421)
     const int32_t i = sampled[r], j = (int32_t)gh_key_id(keys[r * (k + 1) + (t - r * k) + 1]);
-    if (!(i < j)) return;
-    const int32_t v[4] = {edges[2 * (int64_t)i], edges[2 * (int64_t)i + 1], edges[2 * (int64_t)j], edges[2 * (int64_t)j + 1]};
-    if (v[0] == v[2] || v[0] == v[3] || v[1] == v[2] || v[1] == v[3]) return;
-    if (D < 2) return;
-    const float *p1 = pos + (int64_t)v[0] * LD, *p2 = pos + (int64_t)v[1] * LD;
-    const float *q1 = pos + (int64_t)v[2] * LD, *q2 = pos + (int64_t)v[3] * LD;
-    const float o1 = orient2d(p1, p2, q1), o2 = orient2d(p1, p2, q2);
-    const float o3 = orient2d(q1, q2, p1), o4 = orient2d(q1, q2, p2);
-    if (!(o1 * o2 < 0.0f && o3 * o4 < 0.0f)) return;
-    float *diff = scratch + t * LD;  // per-thread scratch row (any D)
-    for (int role = 0; role < 4; ++role) {
-        const float *x = pos + (int64_t)v[role] * LD;
-        for (int d = 0; d < D; ++d) {
-            const float cen = (((p1[d] + p2[d]) + q1[d]) + q2[d]) / 4.0f;
-            diff[d] = x[d] - cen;
-        }
-        const float dist = sqrtf(gh_sumsq_rt(diff, D)) + 1e-6f;
-        const float dd = dist * dist;
-        for (int d = 0; d < D; ++d) atomicAdd(&acc[(int64_t)v[role] * LD + d], (double)((k_inter * diff[d]) / dd));
-        if (atomicExch(&tflag[v[role]], 1) == 0) touched[atomicAdd(tcount, 1)] = v[role];
-    }
+    gh_intersect_pair(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, scratch + t * LD);
 }
 
 // acc (double) -> dense fp32 F for the touched vertices (per-phase entry point).

@@ -20,12 +20,33 @@
 #include "common.h"
 #include "engine.h"
 #include "scan_core.h"
+#include "intersect_core.h"
 
 #include <math.h>
 #include <type_traits>
 #include <stdlib.h>
 
 namespace {
+
+// Arguments of the intersection phase, for kernels that finish a query and process its k pairs
+// in the same launch (single-rank runs).  pos == nullptr: do not intersect.
+struct inter_args {
+    const float *pos;
+    const int32_t *edges;
+    const int32_t *sampled;
+    int D, LD, k;
+    float k_inter;
+    double *acc;
+    int32_t *tflag, *touched, *tcount;
+    float *scratch;
+};
+
+__device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi, const uint64_t *best) {
+    // neighbour c of the query is key column c+1: column 0 is dropped blindly (pt.py:421)
+    for (int c = threadIdx.x; c < ia.k; c += blockDim.x)
+        gh_intersect_pair(ia.pos, ia.D, ia.LD, ia.edges, ia.sampled[qi], (int32_t)gh_key_id(best[c + 1]), ia.k_inter,
+                          ia.acc, ia.tflag, ia.touched, ia.tcount, ia.scratch + (qi * ia.k + c) * ia.LD);
+}
 
 // ---------------------------------------------------------------------------------
 // One launch sets a KNN search up: (a) this iteration's sample ids -- given, drawn by the device
@@ -155,8 +176,9 @@ __device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64
 // K <= GH_EXTRACT_MAX_K.
 __global__ __launch_bounds__(256) void knn_block_select_kernel(
     const float *__restrict__ mid, const float *__restrict__ pos, const int32_t *__restrict__ edges, int LD, int D,
-    int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride, const float *__restrict__ qt, int QS, int K, const int32_t *__restrict__ only_flagged,
-    uint64_t *__restrict__ out_keys /* (S, K) or null */, float *__restrict__ tau_out /* qt + tau offset, or null */) {
+    int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride, const float *__restrict__ qt, int QS, int K,
+    const int32_t *__restrict__ only_flagged, uint64_t *__restrict__ out_keys /* (S, K) or null */,
+    float *__restrict__ tau_out /* qt + tau offset, or null */, inter_args ia) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
@@ -207,6 +229,7 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(
     if (out_keys)
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
     if (tau_out && threadIdx.x == 0) tau_out[qi * QS] = best[K - 1] != GH_KEY_INF ? gh_key_d2(best[K - 1]) : INFINITY;
+    if (ia.pos) intersect_query(ia, qi, best);
 }
 
 // The same selection for large K (> GH_EXTRACT_MAX_K): running threshold + LDS compaction +
@@ -430,7 +453,8 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
 __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ cand, int32_t *__restrict__ cnt,
                                                          int K, int final_level, float *__restrict__ tau, int QS,
                                                          uint64_t *__restrict__ out_keys,
-                                                         int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt) {
+                                                         int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
+                                                         inter_args ia) {
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[2][4];
     constexpr int NPT = GH_CAND_CAP / 256;
@@ -446,6 +470,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     block_extract_adaptive<NPT>(cand + qi * GH_CAND_CAP, c, K, best, red);
     if (final_level) {
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
+        if (ia.pos) intersect_query(ia, qi, best);  // an overflowed query returned above: the fallback does it
     } else if (threadIdx.x == 0) {
         tau[qi * QS] = gh_key_d2(best[K - 1]);
     }
@@ -503,14 +528,24 @@ void launch_scan_d(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride
 }
 
 // mid == nullptr: gather the endpoints from positions instead (slow; the exact fallback only).
+inter_args make_inter_args(gh_engine *h, bool on) {
+    inter_args ia{};
+    if (on) {
+        ia = inter_args{h->d_pos, h->d_edges, h->d_sampled_cur, h->D, h->LD, h->k, h->prm.k_inter,
+                        h->d_acc, h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch};
+    }
+    return ia;
+}
+
+// with_intersect only takes effect in the extraction kernel (K <= GH_EXTRACT_MAX_K).
 void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, int64_t id_stride,
-                         const int32_t *only_flagged, uint64_t *out_keys, bool write_tau) {
+                         const int32_t *only_flagged, uint64_t *out_keys, bool write_tau, bool with_intersect) {
     const int QS = gh_qs(h->D, h->LD);
     float *tau_out = write_tau ? h->d_q + gh_qtau(h->D, h->LD) : nullptr;
     if (h->K <= GH_EXTRACT_MAX_K) {
         knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
             mid, h->d_pos, h->d_edges, h->LD, h->D, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, QS, h->K,
-            only_flagged, out_keys, tau_out);
+            only_flagged, out_keys, tau_out, make_inter_args(h, with_intersect));
     } else {
         const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)h->LD;
         knn_block_select_sort_kernel<<<dim3((unsigned)h->S), dim3(256), smem, h->stream>>>(
@@ -533,11 +568,12 @@ int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile) {
     return r;
 }
 
-gh_status launch_select(gh_engine *h, bool final_level) {
-    gh_scope t(h, "knn_select");
+gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect) {
+    gh_scope t(h, with_intersect ? "knn_select_intersect" : "knn_select");
     knn_select_kernel<<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(
         h->d_cand, h->d_cnt, h->K, final_level ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), gh_qs(h->D, h->LD),
-        h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S);
+        h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S,
+        make_inter_args(h, with_intersect));
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
@@ -585,23 +621,29 @@ gh_status gh_knn_thresholds(gh_engine *h) {
 
 // K best keys of every query from its final candidate list; queries whose list overflowed are
 // redone exactly over all own edges (from d_mid when have_mid, else by gathering endpoints).
-gh_status gh_knn_finish(gh_engine *h, bool have_mid) {
+// fuse_intersect (single-rank steps): the same launches also run the intersection phase of each
+// query they finish (h->intersect_done tells the caller).
+gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect) {
     const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
-    GH_TRY_ST(launch_select(h, true));
+    const bool fuse = fuse_intersect && h->K <= GH_EXTRACT_MAX_K;
+    GH_TRY_ST(launch_select(h, true, fuse));
     gh_scope t(h, "knn_overflow_fallback");
-    launch_block_select(h, have_mid ? h->d_mid : nullptr, Mtot, 1, 1, h->d_ovf, h->d_partial, false);
+    launch_block_select(h, have_mid ? h->d_mid : nullptr, Mtot, 1, 1, h->d_ovf, h->d_partial, false, fuse);
     GH_LAUNCH_CHECK();
+    h->intersect_done = fuse;
     return GH_OK;
 }
 
 // Unfused search over the materialised midpoints d_mid -> d_partial.
-gh_status gh_knn_local(gh_engine *h) {
+gh_status gh_knn_local(gh_engine *h, bool fuse_intersect) {
     const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
     GH_TRY_ST(gh_knn_prepare(h));
     if (!gh_knn_scan_path(h)) {
+        const bool fuse = fuse_intersect && h->K <= GH_EXTRACT_MAX_K;
         gh_scope t(h, "knn_block_select");
-        launch_block_select(h, h->d_mid, Mtot, 1, 1, nullptr, h->d_partial, false);
+        launch_block_select(h, h->d_mid, Mtot, 1, 1, nullptr, h->d_partial, false, fuse);
         GH_LAUNCH_CHECK();
+        h->intersect_done = fuse;
         return GH_OK;
     }
     GH_TRY_ST(gh_knn_thresholds(h));
@@ -610,7 +652,7 @@ gh_status gh_knn_local(gh_engine *h) {
         launch_scan_d<8>(h, h->d_mid, Mtot, 1, 1);
         GH_LAUNCH_CHECK();
     }
-    return gh_knn_finish(h, true);
+    return gh_knn_finish(h, true, fuse_intersect);
 }
 
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {

@@ -67,6 +67,7 @@ __device__ __forceinline__ void gh_scan_queries(const gh_f2 (&m)[R / 2][D], cons
     float4 rec[QS / 4], nxt[QS / 4];
 #pragma unroll
     for (int i = 0; i < QS / 4; ++i) nxt[i] = qsh[i];
+#pragma unroll 2
     for (int s = 0; s < nq; ++s) {
 #pragma unroll
         for (int i = 0; i < QS / 4; ++i) rec[i] = nxt[i];
