@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--workload", default="rr1m", choices=sorted(WORKLOADS))
     ap.add_argument("--sampler", default="device", choices=["device", "host"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", action="store_true",
+                    help="use the multi-GPU driver (RCCL collectives) even for one rank: rehearsal of the N>1 path")
     args = ap.parse_args()
 
     import torch
@@ -103,10 +105,14 @@ def main():
     n, D, k, S, edges, pos = make_workload(args.workload)
     E = len(edges)
 
-    if world > 1:
+    use_dist = world > 1 or args.dist
+    if use_dist:
         import torch.distributed as dist
         from graphem_rapids_amd.distributed import PartitionedLayout
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, rank=rank, world=world,
                                 device_id=local_rank)
         lay.set_positions(pos)
@@ -139,7 +145,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -191,14 +197,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "graph": WORKLOADS[args.workload][0], "n_vertices": n,
                        "n_edges": E, "n_components": D, "n_neighbors": k, "sample_size": S,
-                       "sampler": args.sampler, "parallelism": f"rows/{world}"},
+                       "sampler": args.sampler, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else "")},
             "roofline": roofline, "roofline_iter_hbm": hbm, "kernels": kern,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, D, k, S, edges, pos)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -313,3 +313,76 @@ def test_unsorted_edge_list_takes_the_gather_path():
     eng.step(sampled)
     assert np.abs(eng.get_positions() - oracle.step(pos, shuffled, sampled, 10)).max() <= 1e-4
     eng.close()
+
+
+def test_rccl_driver_single_rank():
+    """The real multi-GPU driver (PartitionedLayout + HipShardEngine + RCCL collectives through
+    torch.distributed 'nccl') with world size 1 on this GPU: in-place position all-gather,
+    int64 key all-gather, fp64 all-reduce, engine on torch's stream.  Must equal the plain engine."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from graphem_rapids_amd import _native
+    from graphem_rapids_amd.distributed import PartitionedLayout
+    n, D, k, S = 25000, 3, 10, 256
+    edges, pos, _ = _random_case(n, D, 8, k, S, seed=77)
+    rng = np.random.default_rng(5)
+    stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(3)]).astype(np.int32)
+    ref_eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=9)
+    ref_eng.set_positions(pos)
+    ref_eng.run(3, stream)
+    ref_eng.run(2)           # device sampler, iterations 3 and 4
+    ref = ref_eng.get_positions()
+    ref_eng.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29577"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=9, rank=0, world=1, device_id=0)
+        lay.set_positions(pos)
+        lay.run(3, stream)
+        lay.run(2)
+        torch.cuda.synchronize()
+        got = lay.get_positions()
+    finally:
+        dist.destroy_process_group()
+    assert np.abs(got - ref).max() <= 2e-6
+
+
+def test_large_k_takes_the_sort_kernel():
+    """n_neighbors + 1 > 64 selects with the LDS sort kernel instead of block-min extraction."""
+    from graphem_rapids_amd import _native
+    edges, pos, sampled = _random_case(3000, 3, 8, 80, 50, seed=12)
+    eng = _native.Engine(3000, 3, edges, 1.0, 0.2, 0.5, 80, 50)
+    eng.set_positions(pos)
+    assert np.array_equal(eng.knn_midpoints(sampled), oracle.knn_midpoints(pos, edges, sampled, 80))
+    eng.step(sampled)
+    assert np.abs(eng.get_positions() - oracle.step(pos, edges, sampled, 80)).max() <= 1e-4
+    eng.close()
+    # and on a graph large enough for the scan path, where K > 64 must fall back to the per-query kernel
+    edges, pos, sampled = _random_case(20000, 3, 8, 70, 32, seed=13)
+    eng = _native.Engine(20000, 3, edges, 1.0, 0.2, 0.5, 70, 32)
+    eng.set_positions(pos)
+    assert np.array_equal(eng.knn_midpoints(sampled), oracle.knn_midpoints(pos, edges, sampled, 70))
+    eng.close()
+
+
+def test_many_queries_and_no_sampling_on_the_scan_path():
+    """S > 256 (several query groups inside the fused kernel) and S >= E (arange, pt.py:412)."""
+    from graphem_rapids_amd import _native
+    edges, pos, _ = _random_case(20000, 3, 8, 10, 700, seed=14)
+    sampled = np.random.default_rng(2).permutation(len(edges))[:700].astype(np.int32)
+    eng = _native.Engine(20000, 3, edges, 1.0, 0.2, 0.5, 10, 700)
+    eng.set_positions(pos)
+    assert np.array_equal(eng.knn_midpoints(sampled), oracle.knn_midpoints(pos, edges, sampled, 10))
+    eng.step(sampled)
+    assert np.abs(eng.get_positions() - oracle.step(pos, edges, sampled, 10)).max() <= 1e-4
+    eng.close()
+    edges, pos, _ = _random_case(5000, 2, 8, 6, 10 ** 6, seed=15)   # sample_size >= E = 20000
+    eng = _native.Engine(5000, 2, edges, 1.0, 0.2, 0.5, 6, 10 ** 6)
+    eng.set_positions(pos)
+    eng.step()
+    allq = np.arange(len(edges), dtype=np.int32)
+    assert np.abs(eng.get_positions() - oracle.step(pos, edges, allq, 6)).max() <= 1e-4
+    eng.close()
