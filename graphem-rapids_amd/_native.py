@@ -20,7 +20,7 @@ SYMBOLS = [
     "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_step_merge",
     "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
     "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts", "gh_set_stream",
-    "gh_positions_rows_allocated",
+    "gh_positions_rows_allocated", "gh_knn_points",
 ]
 
 
@@ -90,6 +90,8 @@ def load():
     L.gh_set_stream.restype = ctypes.c_int
     L.gh_positions_rows_allocated.argtypes = [vp]
     L.gh_positions_rows_allocated.restype = i64
+    L.gh_knn_points.argtypes = [ctypes.c_int, vp, i64, vp, i64, i32, i32, vp]
+    L.gh_knn_points.restype = ctypes.c_int
     L.gh_knn_last_counts.argtypes = [vp, vp, vp, vp]
     L.gh_knn_last_counts.restype = ctypes.c_int
     L.gh_device_count.argtypes = []
@@ -266,6 +268,19 @@ class Engine:
             self._chk(self.lib.gh_timing_get(self.handle, i, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(cnt)))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+
+def knn_points(query, reference, k, device_id=0):
+    """(n_query, k) int64 ids of the k nearest reference rows (gh_knn_points)."""
+    query = np.ascontiguousarray(query, dtype=np.float32)
+    reference = np.ascontiguousarray(reference, dtype=np.float32)
+    if query.ndim != 2 or reference.ndim != 2 or query.shape[1] != reference.shape[1]:
+        raise ValueError("query and reference must be 2-D with the same number of columns")
+    out = np.empty((query.shape[0], int(k)), dtype=np.int64)
+    st = load().gh_knn_points(int(device_id), ptr(query), query.shape[0], ptr(reference), reference.shape[0],
+                              query.shape[1], int(k), ptr(out))
+    raise_for(st, None)
+    return out
 
 
 def device_count():

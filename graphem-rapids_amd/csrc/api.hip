@@ -524,6 +524,42 @@ extern "C" gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int
     return GH_OK;
 }
 
+extern "C" gh_status gh_knn_points(int device_id, const float *q, int64_t nq, const float *ref, int64_t nref,
+                                   int32_t D, int32_t k, int64_t *out) {
+    auto fail = [&](gh_status st, const std::string &msg) { g_create_error = msg; return st; };
+    if (!q || !ref || !out || nq < 0 || nref < 0 || D <= 0 || k <= 0) return fail(GH_ERR_INVALID, "bad argument");
+    if ((int64_t)k > nref) return fail(GH_ERR_K_TOO_LARGE, "selected index k out of range");
+    if (k > GH_SEL_BUF - GH_SEL_CHUNK) return fail(GH_ERR_INVALID, "k too large for the HIP backend (max 2048)");
+    if (nref >= ((int64_t)1 << 31)) return fail(GH_ERR_INVALID, "too many reference points");
+    if (hipSetDevice(device_id) != hipSuccess) return fail(GH_ERR_RUNTIME, "invalid device ordinal " + std::to_string(device_id));
+    float *d_q = nullptr, *d_ref = nullptr;
+    uint64_t *d_keys = nullptr;
+    std::vector<uint64_t> keys((size_t)nq * k);
+    gh_status st = GH_OK;
+    std::string err;
+    auto cleanup = [&]() { if (d_q) (void)hipFree(d_q); if (d_ref) (void)hipFree(d_ref); if (d_keys) (void)hipFree(d_keys); };
+    if (hipMalloc((void **)&d_q, sizeof(float) * (size_t)std::max<int64_t>(nq * D, 1)) != hipSuccess ||
+        hipMalloc((void **)&d_ref, sizeof(float) * (size_t)std::max<int64_t>(nref * D, 1)) != hipSuccess ||
+        hipMalloc((void **)&d_keys, sizeof(uint64_t) * std::max<size_t>(keys.size(), 1)) != hipSuccess) {
+        cleanup();
+        return fail(GH_ERR_NOMEM, "hipMalloc failed");
+    }
+    if (hipMemcpy(d_q, q, sizeof(float) * (size_t)nq * D, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ref, ref, sizeof(float) * (size_t)nref * D, hipMemcpyHostToDevice) != hipSuccess) {
+        cleanup();
+        return fail(GH_ERR_HIP, "upload failed");
+    }
+    st = gh_knn_points_device(nullptr, d_q, nq, d_ref, nref, D, k, d_keys, &err);
+    if (st == GH_OK && hipMemcpy(keys.data(), d_keys, sizeof(uint64_t) * keys.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+        st = GH_ERR_HIP;
+        err = "download failed";
+    }
+    cleanup();
+    if (st != GH_OK) return fail(st, err);
+    for (size_t i = 0; i < keys.size(); ++i) out[i] = (int64_t)(keys[i] & 0xFFFFFFFFu);
+    return GH_OK;
+}
+
 extern "C" int32_t gh_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

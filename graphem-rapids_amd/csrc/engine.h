@@ -114,6 +114,8 @@ bool gh_knn_scan_path(const gh_engine *h);
 gh_status gh_knn_prepare(gh_engine *h);
 gh_status gh_knn_thresholds(gh_engine *h);
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
+gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq, const float *d_ref, int64_t nref,
+                               int D, int K, uint64_t *d_keys, std::string *err);
 // fused.hip
 int gh_fused_tile(int LD, int64_t own_edges);              // edges per fused workgroup
 gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel

@@ -674,3 +674,25 @@ gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {
     h->d_keys_cur = h->d_merged;
     return GH_OK;
 }
+
+// Plain point-set KNN (the reference's _compute_knn_chunked / _compute_knn_torch, pt.py:426-483,
+// 543-593, as a library call): K smallest (dist2, id) keys of every query row among the
+// reference rows, by the per-query kernels above with the point arrays standing in for the
+// midpoint array (row stride D) and the query records (QS = D).
+gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq, const float *d_ref, int64_t nref,
+                               int D, int K, uint64_t *d_keys, std::string *err) {
+    if (nq == 0) return GH_OK;
+    inter_args none{};
+    if (K <= GH_EXTRACT_MAX_K) {
+        knn_block_select_kernel<<<dim3((unsigned)nq), dim3(256), sizeof(float) * (size_t)D, stream>>>(
+            d_ref, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D, K, nullptr, d_keys, nullptr, none);
+    } else {
+        const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)D;
+        if (smem > 64 * 1024) { *err = "dimension too large for the point KNN kernel"; return GH_ERR_INVALID; }
+        knn_block_select_sort_kernel<<<dim3((unsigned)nq), dim3(256), smem, stream>>>(
+            d_ref, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D, K, nullptr, d_keys, nullptr);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); return GH_ERR_HIP; }
+    return GH_OK;
+}

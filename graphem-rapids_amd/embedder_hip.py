@@ -240,6 +240,24 @@ class GraphEmbedderHIP:
     def _compute_intersection_forces(self, knn_indices, sampled_indices):
         return self._engine.intersection_forces(sampled_indices, knn_indices)
 
+    # ---- point-set KNN helpers callers and tests reach for (pt.py:260-322, 426-483, 543-593) --------
+    def _get_adaptive_chunk_size(self, n_query, n_ref, backend):
+        """The engine never chunks the query set; kept for interface parity (always > 0)."""
+        return max(1, min(int(self.batch_size), int(n_query)) if self.batch_size else int(n_query))
+
+    def _compute_knn_torch(self, query_points, reference_points, k, chunk_size=None):
+        """(n_query, k) long tensor of nearest reference rows, ascending distance (pt.py:543-593)."""
+        q = query_points.detach().to("cpu", torch.float32).numpy() if isinstance(query_points, torch.Tensor) \
+            else np.asarray(query_points, dtype=np.float32)
+        r = reference_points.detach().to("cpu", torch.float32).numpy() if isinstance(reference_points, torch.Tensor) \
+            else np.asarray(reference_points, dtype=np.float32)
+        idx = _native.knn_points(q, r, k, device_id=self.device.index)
+        return torch.from_numpy(idx).to(self.device)
+
+    def _compute_knn_chunked(self, query_points, reference_points, k):
+        """Same result as _compute_knn_torch: there is one KNN implementation here (pt.py:426-483)."""
+        return self._compute_knn_torch(query_points, reference_points, k)
+
     def kernel_timings(self):
         return self._engine.timings()
 

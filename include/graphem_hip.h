@@ -142,6 +142,14 @@ gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, double *total
  * (any of the three (S,) host pointers may be NULL).  Blocking. */
 gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final_counts, int32_t *overflow);
 
+/* Plain point-set KNN without a handle: the reference's _compute_knn_chunked /
+ * _compute_knn_torch (pt.py:426-483, 543-593).  q (nq, D), ref (nref, D) host float32 row-major;
+ * out (nq, k) int64: ids of the k nearest reference rows, ascending distance (exact squared
+ * Euclidean distance, ties on the smaller id).  k > nref -> GH_ERR_K_TOO_LARGE like torch.topk.
+ * On failure gh_last_error(NULL) has the message.  Blocking. */
+gh_status gh_knn_points(int device_id, const float *q, int64_t nq, const float *ref, int64_t nref,
+                        int32_t n_components, int32_t k, int64_t *out);
+
 /* Device / build facts for the host mirror's get_backend_info(). */
 int32_t gh_device_count(void);
 const char *gh_version(void);

@@ -123,3 +123,26 @@ def test_high_dimension_random_init_path():
     emb = gra.GraphEmbedderHIP(_rr(100, 4, 1), n_components=250, n_neighbors=5, sample_size=32, verbose=False)
     out = emb.run_layout(2)
     assert out.shape == (100, 250) and np.isfinite(out).all()
+
+
+def test_point_knn_helpers():
+    """_compute_knn_chunked / _compute_knn_torch / _get_adaptive_chunk_size (reference
+    tests/test_pytorch_backend.py:454-494, 525-558): shape, range, agreement, and exactness."""
+    import torch
+    import graphem_rapids_amd as gra
+    emb = gra.GraphEmbedderHIP(_rr(), n_components=2, verbose=False)
+    q = torch.randn(10, 2, device=emb.device, dtype=emb.dtype)
+    ref = torch.randn(20, 2, device=emb.device, dtype=emb.dtype)
+    a = emb._compute_knn_chunked(q, ref, 3)
+    b = emb._compute_knn_torch(q, ref, 3, 5)
+    assert tuple(a.shape) == (10, 3) and a.dtype == torch.long and a.device.type == "cuda"
+    assert int(a.min()) >= 0 and int(a.max()) < 20 and torch.equal(a, b)
+    d = torch.cdist(q.cpu().double(), ref.cpu().double())
+    assert torch.equal(a.cpu(), torch.topk(d, 3, dim=1, largest=False).indices)
+    assert emb._get_adaptive_chunk_size(100, 1000, "torch") > 0
+    big_q, big_r = torch.randn(300, 7), torch.randn(5000, 7)
+    got = emb._compute_knn_chunked(big_q, big_r, 80).cpu()  # k > 64: sort kernel
+    want = torch.topk(torch.cdist(big_q.double(), big_r.double()), 80, dim=1, largest=False).indices
+    assert (got == want).float().mean() > 0.999  # fp32 vs fp64 distances may swap near-ties
+    with pytest.raises(RuntimeError):
+        emb._compute_knn_chunked(q, ref, 21)
