@@ -228,8 +228,8 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_merged, S * (size_t)h->K, true);
     GH_A(d_iscratch, S * (size_t)h->k * h->LD, false);
     h->nblocks_update = (int)((h->rows + 255) / 256);
-    GH_A(d_blockstats, (size_t)std::max(h->nblocks_update, 1) * 2 * h->LD, true);
-    GH_A(d_stats, (size_t)2 * h->LD, true);
+    GH_A(d_blockstats, (size_t)std::max(std::max(h->nblocks_update, h->n_vblocks), 1) * 2 * h->LD, true);
+    GH_A(d_stats, (size_t)(2 + 2 * gh_fix_blocks(h->LD)) * h->LD, true);
 #undef GH_A
     h->d_sampled_cur = h->d_sampled;
     auto up = [&](void *dst, const void *src, size_t bytes) {
@@ -321,6 +321,7 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
 // fuse_intersect: single-rank step, the KNN kernels also run the intersection phase.
 static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
     h->intersect_done = false;
+    h->new0_ready = false;
     if (h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused) {
         GH_TRY(gh_knn_prepare(h));
         GH_TRY(gh_knn_thresholds(h));
@@ -410,6 +411,7 @@ extern "C" gh_status gh_step_merge(gh_handle h, const uint64_t *gathered, int32_
     return step_merge(h, gathered, world);
 }
 extern "C" double *gh_stats_partial_device(gh_handle h) { return h ? h->d_stats : nullptr; }
+extern "C" int32_t gh_stats_rows(gh_handle h) { return h ? 2 + 2 * gh_fix_blocks(h->LD) : 0; }
 extern "C" gh_status gh_step_finish(gh_handle h) {
     GH_TRY(check_handle(h));
     return step_finish(h);

@@ -16,6 +16,8 @@
 #define GH_CNT_STRIDE 32
 // Spare rows behind the n positions so equal all-gather chunks fit for any world size <= this.
 #define GH_POS_PAD_ROWS 1024
+// Row pairs of corrections behind the (2, LD) column statistics: one per stats_fix workgroup.
+inline int gh_fix_blocks(int LD) { return LD <= 16 ? 2 * LD : 0; }
 // Below this many reference edges the per-query block kernel scans everything itself.
 #define GH_SCAN_MIN_EDGES 16384
 
@@ -74,6 +76,7 @@ struct gh_engine {
     int32_t *d_sampled_cur = nullptr; // ids of the current iteration (d_sampled or a row of d_stream_ids)
     int32_t *d_stream_ids = nullptr;  // (iters, S) uploaded sample stream of gh_run
     size_t stream_ids_cap = 0;
+    bool new0_ready = false;      // the fused kernel of this step wrote d_new = pos + Fs and its block sums
     bool intersect_done = false;  // the KNN kernels of this step already ran the intersection phase
     bool sample_pending = false;  // ids of this iteration still to be produced (inside knn_setup_kernel)
     int sample_mode = 0;          // 1 device sampler, 2 arange
@@ -92,7 +95,8 @@ struct gh_engine {
     // normalisation
     double *d_blockstats = nullptr; // (nblocks, 2, LD)
     int nblocks_update = 0;
-    double *d_stats = nullptr;      // (2, LD): sum, sum of squares (all-reduced by the caller when partitioned)
+    double *d_stats = nullptr;      // (2 + 2*gh_fix_blocks(LD), LD): sum, sum of squares, then correction row pairs;
+                                    // summed elementwise over the ranks by the caller when partitioned
 
     // timing
     bool timing = false;

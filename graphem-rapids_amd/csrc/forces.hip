@@ -163,6 +163,65 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double *__restr
     if (threadIdx.x == 0) stats[c] = ((red[0] + red[1]) + red[2]) + red[3];
 }
 
+// Column sums after the fused kernel: blockstats holds the sums of new0 = pos + Fs; the vertices the
+// intersection phase touched must instead be new = pos + (Fs + Fi) (pt.py:796-799).
+// gh_fix_blocks(LD) = 2*LD workgroups: each reduces one entry of the (2, LD) statistics each, in a
+// fixed order; every workgroup also takes a slice of the touched list, stores the corrected rows
+// and leaves its column sums of (new - new0) and (new^2 - new0^2) in its own row pair of the
+// statistics buffer (rows 2.. of d_stats); normalise_kernel adds all rows up.  new0 is recomputed
+// from pos and Fs, never read back.
+template <int LD>
+__global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict__ blockstats, int nblocks,
+                                                       const float *__restrict__ pos, const float *__restrict__ Fs,
+                                                       const double *__restrict__ acc,
+                                                       const int32_t *__restrict__ touched,
+                                                       const int32_t *__restrict__ tcount, int64_t row_lo,
+                                                       int64_t rows, float *__restrict__ out_new,
+                                                       double *__restrict__ stats) {
+    __shared__ double red[4][2 * LD];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        const int c = blockIdx.x;  // gridDim.x == 2 * LD
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += blockstats[(int64_t)b * 2 * LD + c];
+        const double a = gh_wave_sum(s);
+        if (lane == 0) red[w][0] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) stats[c] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        __syncthreads();
+    }
+    double dx[LD], dxx[LD];
+#pragma unroll
+    for (int d = 0; d < LD; ++d) { dx[d] = 0.0; dxx[d] = 0.0; }
+    const int nt = *tcount;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nt; t += gridDim.x * blockDim.x) {
+        const int64_t x = touched[t];
+        const int64_t i = x - row_lo;
+        if (i < 0 || i >= rows) continue;
+        float p[LD], f[LD], nw[LD];
+        gh_load_row<LD>(pos, x, p);
+        gh_load_row<LD>(Fs, i, f);
+#pragma unroll
+        for (int d = 0; d < LD; ++d) {
+            const float n0 = p[d] + f[d];
+            const float tot = f[d] + (float)acc[x * LD + d];
+            nw[d] = p[d] + tot;
+            dx[d] += (double)nw[d] - (double)n0;
+            dxx[d] += (double)nw[d] * (double)nw[d] - (double)n0 * (double)n0;
+        }
+        gh_store_row<LD>(out_new, i, nw);
+    }
+#pragma unroll
+    for (int d = 0; d < LD; ++d) {
+        const double a = gh_wave_sum(dx[d]), b = gh_wave_sum(dxx[d]);
+        if (lane == 0) { red[w][d] = a; red[w][LD + d] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * LD)
+        stats[(2 + 2 * blockIdx.x) * LD + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
 // pt.py:802-804: centre by the column mean, divide by (unbiased std + 1e-6).
 // stats = global (sum, sum of squares) over all n rows; every thread derives the same
 // mean / std from them.  Writes rows [row_lo, row_lo+rows) of pos.
@@ -171,7 +230,7 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
                                                        float *__restrict__ pos, double *__restrict__ acc,
                                                        int32_t *__restrict__ tflag,
                                                        const int32_t *__restrict__ touched,
-                                                       const int32_t *__restrict__ tcount) {
+                                                       const int32_t *__restrict__ tcount, int nfix) {
     // also zero what the intersection phase touched (acc != nullptr): the integrate kernel that
     // read those accumulators has finished; tcount itself is reset by the next KNN setup
     if (acc) {
@@ -187,7 +246,11 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
     for (int d = threadIdx.x; d < LD; d += blockDim.x) {
         float mean = 0.0f, sd = 1.0f;
         if (d < D) {
-            const double sum = stats[d], sq = stats[LD + d];
+            double sum = stats[d], sq = stats[LD + d];
+            for (int b = 0; b < nfix; ++b) {  // corrections of the touched rows (zero when unused)
+                sum += stats[(2 + 2 * b) * LD + d];
+                sq += stats[(3 + 2 * b) * LD + d];
+            }
             const double m = sum / (double)n;
             double var = (sq - sum * m) / (double)(n - 1);
             if (var < 0.0) var = 0.0;
@@ -349,6 +412,23 @@ gh_status gh_launch_mid_only(gh_engine *h) { return launch_mid_gather(h); }
 
 // new = pos + (Fs + Fi) for the own rows -> d_new, column statistics -> d_stats.
 gh_status gh_launch_integrate(gh_engine *h) {
+    if (h->new0_ready && h->rows > 0) {  // the fused kernel already wrote pos + Fs and its partial sums
+        h->new0_ready = false;
+        gh_scope t(h, "stats_fix");
+#define GH_FIX_CASE(LL)                                                                                      \
+    stats_fix_kernel<LL><<<dim3(gh_fix_blocks(LL)), dim3(256), 0, h->stream>>>(                                  \
+        h->d_blockstats, h->n_vblocks, h->d_pos, h->d_Fs, h->d_acc, h->d_touched, h->d_tcount, h->part.row_lo, \
+        h->rows, h->d_new, h->d_stats)
+        if (h->LD == 4) GH_FIX_CASE(4);
+        else if (h->LD == 8) GH_FIX_CASE(8);
+        else GH_FIX_CASE(16);
+#undef GH_FIX_CASE
+        GH_LAUNCH_CHECK();
+        return GH_OK;
+    }
+    h->new0_ready = false;
+    // unfused path: no correction rows
+    GH_HIP(hipMemsetAsync(h->d_stats + 2 * h->LD, 0, sizeof(double) * 2 * gh_fix_blocks(h->LD) * h->LD, h->stream));
     if (h->rows == 0) {
         GH_HIP(hipMemsetAsync(h->d_stats, 0, sizeof(double) * 2 * h->LD, h->stream));
         return GH_OK;
@@ -426,6 +506,7 @@ gh_status gh_launch_inter_cleanup(gh_engine *h) {
 }
 
 gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi) {
+    GH_HIP(hipMemsetAsync(h->d_stats, 0, sizeof(double) * (2 + 2 * gh_fix_blocks(h->LD)) * h->LD, h->stream));
     // whole graph on one rank only (per-phase entry point)
     const int64_t total = h->n * h->LD;
     integrate_given_kernel<<<dim3(grid_for(total, 256)), dim3(256), 0, h->stream>>>(h->d_pos, d_Fs, d_Fi, total,
@@ -443,7 +524,7 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup) {
     if (grid > 2048) grid = 2048;
     normalise_kernel<<<dim3(grid), dim3(256), sizeof(float) * 2 * h->LD, h->stream>>>(
         h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos,
-        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount);
+        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount, gh_fix_blocks(h->LD));
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

@@ -445,7 +445,9 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
         for (int d = 0; d < D; ++d) qn = fmaf(qs[d], qs[d], qn);
         for (int d = 0; d < QS; ++d) qscan[qi * QS + d] = d < D ? -2.0f * qs[d] : 0.0f;
         const float eps = gh_filter_eps(D);
-        qscan[qi * QS + QT] = fmaf(eps, fmaf(2.0f, qn, tau), tau - qn);
+        // + 1e-30: a must-pass value is then strictly negative even when every magnitude is 0 (the
+        // MFMA form of the filter tests sign bits)
+        qscan[qi * QS + QT] = fmaf(eps, fmaf(2.0f, qn, tau), tau - qn) + 1e-30f;
     }
 }
 
@@ -559,6 +561,10 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
 // A workgroup of the final pass parks its hits in LDS: S*K*stride*tile/E of them on average,
 // kept near 300 so the buffer (>= 1024 entries) does not overflow into the slow direct path.
 int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile) {
+    if (const char *e = getenv("GRAPHEM_HIP_SUBSET_STRIDE")) {  // tuning override
+        const long v = atol(e);
+        if (v >= 2 && v <= Mtot / (4 * (int64_t)K)) return v;
+    }
     int64_t r = 1408 / K;
     if (r > 128) r = 128;
     const int64_t by_hits = (int64_t)(300.0 * (double)Mtot / ((double)S * K * tile));

@@ -119,3 +119,83 @@ __device__ __forceinline__ void gh_flush_hits(const uint64_t *hkey, const int *h
     const int nh = min(*hcount, HITBUF);
     for (int i = threadIdx.x; i < nh; i += NT) gh_append_candidate(cand, cnt, hq[i], hkey[i]);
 }
+
+// ---------------------------------------------------------------------------------
+// The same pre-filter on the matrix pipe (D <= 3).  For a group of 16 queries and 16 references
+//     F[q][r] = (-t_q) + sum_k A[q][k] * B[k][r],   A[q] = (-2q_x, -2q_y, -2q_z, 1),
+//                                                    B[.][r] = (m_x, m_y, m_z, c0_r)
+// is one v_mfma_f32_16x16x4_f32 with C = -t: a (16 x 4) x (4 x 16) GEMM tile, and a reference can
+// only be a candidate of a query if F <= 0.  fp32 MFMA is an exact k-ordered fma chain, so the
+// error margin built into t and c0 (gh_filter_eps) covers it.  256 pairs cost 32 cycles of the
+// MFMA pipe plus 3 VALU instructions (min3, min, compare), against 12 packed VALU instructions:
+// the VALU is left to the spring math of the co-resident workgroups.
+// Layout (guide: A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15], D lane l reg i =
+// D[(l>>4)*4+i][l&15]): each wave owns G groups of 16 references, one float per lane and group
+// (bq[g] = component l>>4 of reference l&15 of group g); queries are staged transposed in LDS
+// (qT[k][q], tneg[q]).  Hits are re-derived exactly as in gh_scan_queries.
+typedef float gh_f4 __attribute__((ext_vector_type(4)));
+
+template <int D, int G, int HITBUF>
+__device__ __forceinline__ void gh_scan_queries_mfma(const float (&bq)[G], uint32_t id0 /* id of ref (group 0, col 0) */,
+                                                     int nvalid /* valid refs of this wave */, const float *qT,
+                                                     const float *tneg, int nq, int s_lo,
+                                                     const float *__restrict__ qt, uint64_t *hkey, int *hq,
+                                                     int *hcount, uint64_t *__restrict__ cand,
+                                                     int32_t *__restrict__ cnt) {
+    static_assert(D <= 3, "one K=4 MFMA per tile");
+    static_assert(G % 8 == 0, "eight MFMAs are kept in flight");
+    constexpr int QS = 4, QT = 3;
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 15, kq = lane >> 4;
+    const int ngroups = (nq + 15) >> 4;
+    for (int qg = 0; qg < ngroups; ++qg) {
+        // A operand: component kq of query qg*16 + col (k = 3 is the constant 1)
+        const float a = kq < 3 ? qT[kq * GH_SCAN_QGROUP + qg * 16 + col] : 1.0f;
+        // C operand: -t of the four queries this lane's accumulator rows belong to
+        const float4 tn = *reinterpret_cast<const float4 *>(tneg + qg * 16 + kq * 4);
+        const gh_f4 c = {tn.x, tn.y, tn.z, tn.w};
+#pragma unroll
+        for (int g0 = 0; g0 < G; g0 += 8) {
+            gh_f4 acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[g0 + u], c, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                // F <= 0 somewhere  <=>  some sign bit set (t carries a +1e-30 bias, so a passing
+                // F is never +0): one v_or3, one v_or, one integer compare per 256 pairs
+                const int bits = __float_as_int(acc[u].x) | __float_as_int(acc[u].y) | __float_as_int(acc[u].z) |
+                                 __float_as_int(acc[u].w);
+                if (__builtin_amdgcn_ballot_w64(bits < 0) != 0) {  // rare, wave-uniform
+                    const int g = g0 + u;
+                    // exact coordinates of this lane's reference: components live in lanes col, 16+col, 32+col
+                    float mref[3];
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) mref[d] = __shfl(bq[g], d * 16 + col, GH_WAVE);
+                    const int jref = g * 16 + col;
+                    if (bits < 0 && jref < nvalid) {
+                        const float av[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int ql = qg * 16 + kq * 4 + i;
+                            if (__float_as_int(av[i]) < 0 && ql < nq) {
+                                const int sg = s_lo + ql;
+                                float d2 = 0.0f;
+#pragma unroll
+                                for (int d = 0; d < D; ++d) {
+                                    const float df = qt[(int64_t)sg * QS + d] - mref[d];
+                                    d2 = fmaf(df, df, d2);
+                                }
+                                if (d2 <= qt[(int64_t)sg * QS + QT]) {
+                                    const int p = atomicAdd(hcount, 1);
+                                    const uint64_t key = gh_key(d2, id0 + (uint32_t)jref);
+                                    if (p < HITBUF) { hkey[p] = key; hq[p] = sg; }
+                                    else gh_append_candidate(cand, cnt, sg, key);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}

@@ -11,7 +11,8 @@ positions and the whole edge list.  Per iteration:
     gather  (RCCL)    all-gather of the keys                       S*(k+1)*8 B per rank
     part 2  (local)   merge keys -> global KNN; intersection forces (redundant on every rank,
                       O(S*k)); integrate own rows; own column sums
-    reduce  (RCCL)    all-reduce of 2*ld doubles (sum, sum of squares)
+    reduce  (RCCL)    all-reduce of the column statistics (66 x ld doubles: sums, sums of
+                      squares and the correction rows of the touched vertices)
     part 3  (local)   normalise own rows in the full position array
     gather  (RCCL)    in-place all-gather of the position row blocks   chunk*ld*4 B per rank
 
@@ -56,7 +57,7 @@ class HipShardEngine:
         rows = e.positions_rows_allocated()
         self.pos = device_view(e.positions_device_ptr(), (rows, e.ld), torch.float32, self.device, e)
         self.partial = device_view(e.knn_partial_device_ptr(), (e.S, k + 1), torch.int64, self.device, e)
-        self.stats = device_view(e.stats_partial_device_ptr(), (2, e.ld), torch.float64, self.device, e)
+        self.stats = device_view(e.stats_partial_device_ptr(), (e.stats_rows(), e.ld), torch.float64, self.device, e)
 
     def set_positions(self, pos):
         self.eng.set_positions(pos)

@@ -123,8 +123,9 @@ uint64_t *gh_knn_partial_device(gh_handle h);      /* (S, k+1) uint64 keys, asce
  * caller buffer).  Merges them, computes intersection forces, integrates own rows and
  * leaves this rank's column sums in gh_stats_partial_device(). */
 gh_status gh_step_merge(gh_handle h, const uint64_t *gathered, int32_t world);
-double *gh_stats_partial_device(gh_handle h);      /* (2, ld) doubles: sum, sum of squares */
-/* Part 3: after the caller all-reduced the stats: normalise own rows in place in the
+double *gh_stats_partial_device(gh_handle h);      /* (gh_stats_rows, ld) doubles, to be summed elementwise over ranks */
+int32_t gh_stats_rows(gh_handle h);
+/* Part 3: after the caller all-reduced (SUM) the whole statistics buffer: normalise own rows in place in the
  * full position array; the caller then all-gathers the row blocks. */
 gh_status gh_step_finish(gh_handle h);
 
