@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_new, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_knn, h->d_merged, h->d_first_edge, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -224,7 +224,6 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_ovf, S, true);
     GH_A(d_dbg_cnt, 2 * S, true);
     GH_A(d_partial, S * (size_t)h->K, true);
-    GH_A(d_knn, S * (size_t)h->k, true);
     GH_A(d_merged, S * (size_t)h->K, true);
     GH_A(d_iscratch, S * (size_t)h->k * h->LD, false);
     h->nblocks_update = (int)((h->rows + 255) / 256);
@@ -322,6 +321,12 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
 static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
     h->intersect_done = false;
     h->new0_ready = false;
+    if (h->S == 0 || h->k == 0) {  // nothing sampled / no neighbours asked for: spring forces only
+        h->sample_pending = false;
+        h->intersect_done = true;
+        GH_HIP(hipMemsetAsync(h->d_tcount, 0, sizeof(int32_t), h->stream));
+        return gh_launch_spring_mid(h);
+    }
     if (h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused) {
         GH_TRY(gh_knn_prepare(h));
         GH_TRY(gh_knn_thresholds(h));

@@ -88,7 +88,6 @@ struct gh_engine {
     int32_t *d_ovf = nullptr;     // (S)
     int32_t *d_dbg_cnt = nullptr; // (2, S) candidate-list lengths seen by the last subset / final select
     uint64_t *d_partial = nullptr;// (S, K) this rank's best keys, ascending
-    int32_t *d_knn = nullptr;     // (S, k) neighbour ids (per-phase entry point output only)
     uint64_t *d_merged = nullptr; // (S, K) keys merged over the ranks (world > 1)
     const uint64_t *d_keys_cur = nullptr;  // keys the intersection phase reads: d_partial or d_merged
 
@@ -123,9 +122,9 @@ gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq,
 // fused.hip
 int gh_fused_tile(int LD, int64_t own_edges);              // edges per fused workgroup
 gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel
-gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -> d_knn
+gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -> d_keys_cur
 // forces.hip
-gh_status gh_launch_intersect(gh_engine *h);               // d_sampled, d_knn -> d_acc/d_touched
+gh_status gh_launch_intersect(gh_engine *h);               // d_sampled, d_keys_cur -> d_acc/d_touched
 gh_status gh_launch_inter_cleanup(gh_engine *h);
 gh_status gh_launch_spring_mid(gh_engine *h);              // -> d_Fs, d_mid
 gh_status gh_launch_mid_only(gh_engine *h);                // -> d_mid

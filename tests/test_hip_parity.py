@@ -386,3 +386,20 @@ def test_many_queries_and_no_sampling_on_the_scan_path():
     allq = np.arange(len(edges), dtype=np.int32)
     assert np.abs(eng.get_positions() - oracle.step(pos, edges, allq, 6)).max() <= 1e-4
     eng.close()
+
+
+def test_zero_neighbours_or_zero_samples_run_spring_only():
+    """n_neighbors = 0 or sample_size = 0: no KNN / intersection phase, the step is spring + normalise."""
+    from graphem_rapids_amd import _native
+    edges, pos, _ = _random_case(4000, 3, 6, 10, 64, seed=3)
+    zero = np.zeros_like(pos)
+    want = oracle.integrate_normalise(pos, oracle.spring_forces(pos, edges, 1.0, 0.2), zero)
+    for k, S in [(0, 64), (10, 0)]:
+        eng = _native.Engine(4000, 3, edges, 1.0, 0.2, 0.5, k, S)
+        eng.set_positions(pos)
+        eng.step()
+        eng.run(1)
+        eng.set_positions(pos)
+        eng.step()
+        assert np.abs(eng.get_positions() - want).max() <= 2e-6
+        eng.close()
