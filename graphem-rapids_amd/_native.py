@@ -20,7 +20,8 @@ SYMBOLS = [
     "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_step_merge",
     "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
     "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts", "gh_set_stream",
-    "gh_positions_rows_allocated", "gh_knn_points", "gh_stats_rows",
+    "gh_positions_rows_allocated", "gh_knn_points", "gh_stats_rows", "gh_spmv_symnorm",
+    "gh_spectral_last_error",
 ]
 
 
@@ -90,6 +91,10 @@ def load():
     L.gh_set_stream.restype = ctypes.c_int
     L.gh_positions_rows_allocated.argtypes = [vp]
     L.gh_positions_rows_allocated.restype = i64
+    L.gh_spmv_symnorm.argtypes = [vp, i64, vp, vp, vp, vp, vp]
+    L.gh_spmv_symnorm.restype = ctypes.c_int
+    L.gh_spectral_last_error.argtypes = []
+    L.gh_spectral_last_error.restype = ctypes.c_char_p
     L.gh_stats_rows.argtypes = [vp]
     L.gh_stats_rows.restype = i32
     L.gh_knn_points.argtypes = [ctypes.c_int, vp, i64, vp, i64, i32, i32, vp]

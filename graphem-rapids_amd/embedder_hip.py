@@ -61,8 +61,9 @@ class GraphEmbedderHIP:
             global CPU generator exactly as the reference's CPU backend does (pt.py:409);
             'device' uses the engine's on-GPU sampler (no host work in the loop);
             'auto' = 'torch' up to 2**20 edges, 'device' above.
-        init : 'laplacian' (pt.py:337-379) or 'random' (the reference's own fallback,
-            pt.py:369) for graphs where eigsh is impractical.
+        init : 'laplacian' (scipy eigsh exactly as pt.py:337-379), 'laplacian_hip' (the same
+            eigenvectors by Lanczos on the GPU, spectral.py: seconds where eigsh takes minutes), or
+            'random' (the reference's own fallback, pt.py:369).
         """
         if seed is not None:  # pt.py:106-111
             np.random.seed(seed)
@@ -126,6 +127,14 @@ class GraphEmbedderHIP:
 
         if init == "laplacian":
             p0 = self._compute_laplacian_embedding()
+        elif init == "laplacian_hip":
+            from .spectral import laplacian_embedding_hip
+            try:
+                p0 = laplacian_embedding_hip(self.adjacency, self.n_components, device=str(self.device),
+                                             seed=0 if seed is None else seed)
+            except ValueError as exc:  # n_components + 1 >= n: the reference falls back to random too
+                self.logger.warning("Eigendecomposition failed: %s", exc)
+                p0 = (np.random.randn(self.n, self.n_components) * 0.1).astype(np.float32)
         elif init == "random":
             p0 = (np.random.randn(self.n, self.n_components) * 0.1).astype(np.float32)
         else:

@@ -151,6 +151,16 @@ gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final
 gh_status gh_knn_points(int device_id, const float *q, int64_t nq, const float *ref, int64_t nref,
                         int32_t n_components, int32_t k, int64_t *out);
 
+/* ---- spectral initialisation (_compute_laplacian_embedding, pt.py:337-379) ----
+ * y = (2I - L) x for the normalised Laplacian L of a symmetric, unweighted graph in CSR form:
+ * y_i = x_i + s_i * sum_j s_j x_j over the neighbours j of i (s = degree^-1/2), y_i = 2 x_i for an
+ * isolated vertex.  The operator of the Lanczos iteration in graphem-rapids_amd/spectral.py.
+ * All pointers are DEVICE pointers; fp64; asynchronous on hip_stream (NULL = default stream).
+ * gh_spectral_last_error() has the message of a failed call. */
+gh_status gh_spmv_symnorm(void *hip_stream, int64_t n, const int64_t *indptr, const int32_t *indices,
+                          const double *inv_sqrt_deg, const double *x, double *y);
+const char *gh_spectral_last_error(void);
+
 /* Device / build facts for the host mirror's get_backend_info(). */
 int32_t gh_device_count(void);
 const char *gh_version(void);
