@@ -6,6 +6,8 @@ hand-written HIP kernels for gfx950 behind the C ABI in include/graphem_hip.h.
 """
 from .backend_selection import BackendConfig, check_hip_availability, get_optimal_backend, estimate_memory_usage
 from .embedder_hip import GraphEmbedderHIP
+from .memory_management import (MemoryManager, cleanup_gpu_memory, get_gpu_memory_info, get_optimal_chunk_size,
+                                monitor_memory_usage)
 from .generators import (erdos_renyi_graph, generate_random_regular, erdos_renyi_edges, random_regular_edges,
                          edges_to_adjacency, load_snap_edge_list)
 
@@ -45,4 +47,5 @@ def graphem_seed_selection(embedder, k, num_iterations=20):
 __all__ = ["create_graphem", "get_backend_info", "GraphEmbedderHIP", "BackendConfig", "get_optimal_backend",
            "check_hip_availability", "estimate_memory_usage", "erdos_renyi_graph", "generate_random_regular",
            "erdos_renyi_edges", "random_regular_edges", "edges_to_adjacency", "load_snap_edge_list",
-           "graphem_seed_selection"]
+           "graphem_seed_selection", "MemoryManager", "cleanup_gpu_memory", "get_gpu_memory_info",
+           "get_optimal_chunk_size", "monitor_memory_usage"]

@@ -146,3 +146,58 @@ def test_point_knn_helpers():
     assert (got == want).float().mean() > 0.999  # fp32 vs fp64 distances may swap near-ties
     with pytest.raises(RuntimeError):
         emb._compute_knn_chunked(q, ref, 21)
+
+
+def test_factory_and_integration_properties():
+    """Properties of the reference's integration tests (tests/test_integration.py:44-46, 136-138,
+    169-174, 253-270): spread, per-dimension variance, parameter sensitivity, odd batch/sample sizes."""
+    import graphem_rapids_amd as gra
+    for adj in (gra.erdos_renyi_graph(300, 0.03, seed=1), gra.generate_random_regular(200, 4, seed=2)):
+        emb = gra.create_graphem(adj, n_components=3, backend="hip", verbose=False, seed=3)
+        pos = emb.run_layout(num_iterations=10)
+        radii = np.linalg.norm(pos, axis=1)
+        assert np.isfinite(pos).all() and radii.std() > 0.1 and radii.max() < 100
+        assert (pos.var(axis=0) > 1e-6).all()
+    adj = gra.generate_random_regular(150, 4, seed=5)
+    a = gra.create_graphem(adj, n_components=2, verbose=False, seed=7, k_attr=0.1, k_inter=0.2).run_layout(8)
+    b = gra.create_graphem(adj, n_components=2, verbose=False, seed=7, k_attr=0.8, k_inter=1.5).run_layout(8)
+    assert np.abs(a - b).mean() > 1e-3
+    emb = gra.create_graphem(adj, n_components=2, verbose=False, seed=7, batch_size=64, sample_size=100)
+    assert emb.batch_size == 64 and emb.sample_size == 100
+    assert np.isfinite(emb.run_layout(4)).all()
+
+
+def test_update_positions_loop_equals_run_layout():
+    """Scripts in the reference loop update_positions() themselves (benchmarks/run_benchmarks.py:292-293)."""
+    import torch
+    import graphem_rapids_amd as gra
+    adj = gra.generate_random_regular(120, 4, seed=9)
+    a = gra.create_graphem(adj, n_components=3, verbose=False, seed=11, init="random", sampler="torch")
+    b = gra.create_graphem(adj, n_components=3, verbose=False, seed=11, init="random", sampler="torch")
+    torch.manual_seed(5)
+    for _ in range(4):
+        a.update_positions()
+    torch.manual_seed(5)
+    b.run_layout(4)
+    assert np.array_equal(a.get_positions(), b.get_positions())
+
+
+def test_seed_selection_contract():
+    """influence.graphem_seed_selection (influence.py:10-37): k vertices with the largest radius."""
+    import graphem_rapids_amd as gra
+    adj = gra.generate_random_regular(100, 4, seed=1)
+    emb = gra.create_graphem(adj, n_components=3, verbose=False, seed=2)
+    seeds = gra.graphem_seed_selection(emb, 7, num_iterations=3)
+    r = np.linalg.norm(emb.positions, axis=1)
+    assert seeds == np.argsort(-r)[:7].tolist()
+
+
+def test_two_hexagons_separate():
+    """tests/test_integration.py:274-311 of the reference: disconnected components drift apart."""
+    import graphem_rapids_amd as gra
+    e = np.array([[0, 1], [1, 2], [2, 3], [3, 4], [4, 5], [5, 0], [6, 7], [7, 8], [8, 9], [9, 10], [10, 11], [11, 6]])
+    adj = sp.csr_matrix((np.ones(len(e)), (e[:, 0], e[:, 1])), shape=(12, 12))
+    adj = adj + adj.T
+    pos = gra.create_graphem(adj, n_components=2, backend="hip", verbose=False).run_layout(num_iterations=8)
+    assert pos.shape == (12, 2) and np.isfinite(pos).all()
+    assert np.linalg.norm(pos[:6].mean(0) - pos[6:].mean(0)) > 1e-2

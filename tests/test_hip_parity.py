@@ -403,3 +403,28 @@ def test_zero_neighbours_or_zero_samples_run_spring_only():
         eng.step()
         assert np.abs(eng.get_positions() - want).max() <= 2e-6
         eng.close()
+
+
+def test_full_size_rr_1m_bench_workload():
+    """The benchmark workload itself (random-regular n = 1 M, d = 8, E = 4 M): exact KNN ids, exact spring
+    forces and one step against the oracle; then the size-independent invariants after device-sampled steps."""
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    n = 1_000_000
+    edges = gra.random_regular_edges(n, 8, seed=0).astype(np.int32)
+    rng = np.random.default_rng(0)
+    pos = (rng.standard_normal((n, 3)) * 0.1).astype(np.float32)
+    sampled = rng.permutation(len(edges))[:256].astype(np.int32)
+    eng = _native.Engine(n, 3, edges, 1.0, 0.2, 0.5, 10, 256)
+    eng.set_positions(pos)
+    assert np.array_equal(eng.knn_midpoints(sampled), oracle.knn_midpoints(pos, edges, sampled, 10))
+    sub, fin, ovf = eng.knn_last_counts()
+    assert ovf.sum() == 0 and fin.max() < 8192          # the filtered scan, not the fallback, produced this
+    assert np.array_equal(eng.spring_forces(), oracle.spring_forces(pos, edges, 1.0, 0.2))
+    eng.step(sampled)
+    assert np.abs(eng.get_positions() - oracle.step(pos, edges, sampled, 10)).max() <= 1e-4
+    eng.run(10)
+    o64 = eng.get_positions().astype(np.float64)
+    assert np.isfinite(o64).all() and np.abs(o64.mean(0)).max() < 1e-5
+    np.testing.assert_allclose(o64.std(0, ddof=1), 1.0, atol=1e-4)
+    eng.close()

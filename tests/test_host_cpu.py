@@ -119,3 +119,25 @@ def test_hip_backend_fails_loudly_without_gpu():
     import graphem_rapids_amd as gra
     with pytest.raises(RuntimeError):
         gra.create_graphem(gra.generate_random_regular(20, 4, 0), n_components=2, verbose=False, init="random")
+
+
+def test_memory_utilities_keep_the_reference_interface():
+    import gc
+    import graphem_rapids_amd as gra
+    calls = []
+    orig = gc.collect
+    gc.collect = lambda *a, **k: calls.append(1) or 0
+    try:
+        with gra.MemoryManager(cleanup_on_exit=True) as mm:
+            assert mm.initial_memory is not None
+        gra.cleanup_gpu_memory()
+
+        @gra.monitor_memory_usage
+        def f(x):
+            return x + 1
+        assert f(1) == 2
+    finally:
+        gc.collect = orig
+    assert not calls, "the memory utilities must never call gc.collect()"
+    assert gra.get_optimal_chunk_size(1234, 3) == 1234
+    assert set(gra.get_gpu_memory_info()) >= {"available", "total", "free", "allocated", "cached"}
