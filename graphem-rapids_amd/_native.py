@@ -32,7 +32,10 @@ class GhParams(ctypes.Structure):
 
 class GhPartition(ctypes.Structure):
     _fields_ = [("row_lo", ctypes.c_int64), ("row_hi", ctypes.c_int64),
-                ("edge_lo", ctypes.c_int64), ("edge_hi", ctypes.c_int64)]
+                ("edge_lo", ctypes.c_int64), ("edge_hi", ctypes.c_int64), ("edge_rule", ctypes.c_int32)]
+
+
+EDGES_RANGE, EDGES_HASHED = 0, 1  # gh_partition.edge_rule (include/graphem_hip.h)
 
 
 _lib = None
@@ -140,7 +143,8 @@ class Engine:
                        int(seed) & 0xFFFFFFFFFFFFFFFF)
         part = None
         if partition is not None:
-            part = ctypes.pointer(GhPartition(*[int(x) for x in partition]))
+            vals = [int(x) for x in partition]  # (row_lo, row_hi, edge_lo, edge_hi[, edge_rule])
+            part = ctypes.pointer(GhPartition(*(vals + [EDGES_RANGE] * (5 - len(vals)))))
         st = self.lib.gh_create(ctypes.byref(self.handle), int(device_id), self.n, self.D, self.E, ptr(edges),
                                 ctypes.byref(prm), part)
         if st != GH_OK:

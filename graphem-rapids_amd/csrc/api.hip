@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_new, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -113,9 +113,11 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     h->k = params->n_neighbors; h->K = h->k + 1;
     h->S = std::min<int64_t>(params->sample_size, E);
     if (part) h->part = *part;
-    else h->part = gh_partition{0, n, 0, E};
+    else h->part = gh_partition{0, n, 0, E, GH_EDGES_RANGE};
+    if (h->part.edge_rule == GH_EDGES_HASHED) h->part.edge_lo = h->part.edge_hi = 0;  // not used by this rule
     if (h->part.row_lo < 0 || h->part.row_hi > n || h->part.row_lo > h->part.row_hi || h->part.edge_lo < 0 ||
-        h->part.edge_hi > E || h->part.edge_lo > h->part.edge_hi) {
+        h->part.edge_hi > E || h->part.edge_lo > h->part.edge_hi ||
+        (h->part.edge_rule != GH_EDGES_RANGE && h->part.edge_rule != GH_EDGES_HASHED)) {
         delete h;
         return fail(GH_ERR_INVALID, "partition out of range");
     }
@@ -130,7 +132,18 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
 
     // Pull lists of the own rows in the reference's summation order (pt.py:633-634):
     // first the edges where the vertex is endpoint 0, then those where it is endpoint 1,
-    // each in edge-list order.
+    // each in edge-list order.  Bit 31 of an entry marks the edges this row OWNS (emits the
+    // midpoint of, and searches in the KNN phase).  Ownership rule GH_EDGES_RANGE: the edges
+    // [edge_lo, edge_hi), each owned by its endpoint 0.  GH_EDGES_HASHED (partitioned engines):
+    // a hash of the edge id picks the owning endpoint, so every rank owns ~E/world edges
+    // whatever the vertex numbering (with endpoint-0 ownership the low-numbered ranks of a
+    // u<v edge list hold most of the edges).
+    const bool hashed = h->part.edge_rule == GH_EDGES_HASHED;
+    auto owner_is_v = [](int64_t e) {
+        uint32_t x = (uint32_t)e * 0x9E3779B1u;
+        x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13;
+        return (x >> 31) != 0;
+    };
     std::vector<int32_t> rowptr((size_t)h->rows + 1, 0);
     const int64_t lo = h->part.row_lo, hi = h->part.row_hi;
     for (int64_t e = 0; e < E; ++e) {
@@ -141,37 +154,67 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     for (int64_t i = 0; i < h->rows; ++i) rowptr[(size_t)i + 1] += rowptr[(size_t)i];
     h->adj_len = rowptr[(size_t)h->rows];
     std::vector<int32_t> adj((size_t)std::max<int64_t>(h->adj_len, 1));
+    std::vector<int32_t> adj_eid(hashed ? (size_t)std::max<int64_t>(h->adj_len, 1) : 0);
     {
         std::vector<int32_t> cur(rowptr.begin(), rowptr.end() - 1);
         for (int64_t e = 0; e < E; ++e) {
             const int32_t u = edges[2 * e], v = edges[2 * e + 1];
-            if (u >= lo && u < hi) adj[(size_t)cur[(size_t)(u - lo)]++] = v;
+            if (u >= lo && u < hi) {
+                const size_t at = (size_t)cur[(size_t)(u - lo)]++;
+                const bool own = hashed ? !owner_is_v(e) : (e >= h->part.edge_lo && e < h->part.edge_hi);
+                adj[at] = (int32_t)((uint32_t)v | (own ? 0x80000000u : 0u));
+                if (hashed) adj_eid[at] = (int32_t)e;
+            }
         }
         for (int64_t e = 0; e < E; ++e) {
             const int32_t u = edges[2 * e], v = edges[2 * e + 1];
-            if (v >= lo && v < hi) adj[(size_t)cur[(size_t)(v - lo)]++] = u;
+            if (v >= lo && v < hi) {
+                const size_t at = (size_t)cur[(size_t)(v - lo)]++;
+                const bool own = hashed && owner_is_v(e);
+                adj[at] = (int32_t)((uint32_t)u | (own ? 0x80000000u : 0u));
+                if (hashed) adj_eid[at] = (int32_t)e;
+            }
         }
     }
 
-    // Edges sorted by first endpoint (always true for the reference's CSR-order edge list):
-    // the edges a row owns are then contiguous and the spring kernel can emit their midpoints.
-    bool sorted = true;
-    for (int64_t e = 1; e < E && sorted; ++e) sorted = edges[2 * e] >= edges[2 * (e - 1)];
+    // d_first_edge[i]: where the midpoints of row i's owned edges go.  Range rule, edges sorted by
+    // first endpoint (always true for the reference's CSR-order edge list): the owned edges of a
+    // row are consecutive ids and the offset is the first of them.  Hashed rule: a prefix count
+    // into the list own_eids of owned edge ids in (row, pull list) order.
     std::vector<int32_t> first_edge((size_t)h->rows + 1, 0);
-    if (sorted) {
-        int64_t e = 0;
-        for (int64_t i = 0; i <= h->rows; ++i) {
-            const int64_t x = lo + i;
-            while (e < E && edges[2 * e] < x) ++e;
-            first_edge[(size_t)i] = (int32_t)e;
+    std::vector<int32_t> own_eids;
+    if (hashed) {
+        own_eids.reserve((size_t)(E / std::max<int64_t>(1, n / std::max<int64_t>(h->rows, 1)) + 16));
+        for (int64_t i = 0; i < h->rows; ++i) {
+            first_edge[(size_t)i] = (int32_t)own_eids.size();
+            for (int32_t j = rowptr[(size_t)i]; j < rowptr[(size_t)i + 1]; ++j)
+                if ((uint32_t)adj[(size_t)j] >> 31) own_eids.push_back(adj_eid[(size_t)j]);
         }
-        h->fused_mid = first_edge[0] == h->part.edge_lo && first_edge[(size_t)h->rows] == h->part.edge_hi;
+        first_edge[(size_t)h->rows] = (int32_t)own_eids.size();
+        h->own_count = (int64_t)own_eids.size();
+        h->mid_base = 0;
+        h->fused_mid = true;
+        std::vector<int32_t>().swap(adj_eid);
+    } else {
+        bool sorted = true;
+        for (int64_t e = 1; e < E && sorted; ++e) sorted = edges[2 * e] >= edges[2 * (e - 1)];
+        if (sorted) {
+            int64_t e = 0;
+            for (int64_t i = 0; i <= h->rows; ++i) {
+                const int64_t x = lo + i;
+                while (e < E && edges[2 * e] < x) ++e;
+                first_edge[(size_t)i] = (int32_t)e;
+            }
+            h->fused_mid = first_edge[0] == h->part.edge_lo && first_edge[(size_t)h->rows] == h->part.edge_hi;
+        }
+        h->own_count = h->part.edge_hi - h->part.edge_lo;
+        h->mid_base = h->part.edge_lo;
     }
     // Vertex ranges of the fused spring+scan workgroups: as many consecutive own rows as hold at
     // most TILE owned edges (and at most 1024 rows, 4 per thread).
     std::vector<int32_t> vblock;
     {
-        const int tile = gh_fused_tile(h->LD, h->part.edge_hi - h->part.edge_lo);
+        const int tile = gh_fused_tile(h->LD, h->own_count);
         const bool dim_ok = D == 2 || D == 3 || D == 4 || D == 8 || D == 16;
         bool ok = h->fused_mid && dim_ok;
         if (ok) {
@@ -203,9 +246,10 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_rowptr, (size_t)h->rows + 1, false);
     GH_A(d_adj, (size_t)h->adj_len, false);
     GH_A(d_first_edge, (size_t)h->rows + 1, true);
-    GH_A(d_mid, (size_t)(h->part.edge_hi - h->part.edge_lo) * h->LD, true);
+    GH_A(d_mid, (size_t)h->own_count * h->LD, true);
     GH_A(d_Fs, (size_t)h->rows * h->LD, true);
-    GH_A(d_midsub, (size_t)((h->part.edge_hi - h->part.edge_lo) / 2 + 2) * h->LD, true);
+    GH_A(d_midsub, (size_t)(h->own_count / 2 + 2) * h->LD, true);
+    if (hashed) GH_A(d_own_eids, own_eids.size() + 1, true);
     GH_A(d_vblock, vblock.size(), false);
     GH_A(d_pos, (size_t)h->pos_rows * h->LD, true);
     GH_A(d_new, (size_t)h->rows * h->LD, true);
@@ -239,6 +283,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         !up(h->d_adj, adj.data(), sizeof(int32_t) * (size_t)h->adj_len) ||
         !up(h->d_first_edge, first_edge.data(), sizeof(int32_t) * first_edge.size()) ||
         !up(h->d_vblock, vblock.data(), sizeof(int32_t) * vblock.size()) ||
+        (hashed && !up(h->d_own_eids, own_eids.data(), sizeof(int32_t) * own_eids.size())) ||
         hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "upload of the graph failed";
         return bail(GH_ERR_HIP);

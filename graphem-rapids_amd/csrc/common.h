@@ -106,19 +106,24 @@ __device__ __forceinline__ double gh_wave_sum(double v) {
 template <int D, int LD, bool WRITE_MID>
 __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const int32_t *__restrict__ adj,
                                             int beg, int end, int64_t self, const float *px, float L_min,
-                                            float neg_k, float *F, float *__restrict__ mid, int64_t mid_row0,
-                                            int nfirst) {
+                                            float neg_k, float *F, float *__restrict__ mid, int64_t mid_row0) {
     // Neighbours are fetched C at a time so C independent row gathers are in flight per lane;
-    // the forces are still accumulated strictly in list order.  The first nfirst neighbours
-    // are the edges (self, y) with self < y: their midpoints (pt.py:785) cost nothing here,
-    // both endpoints being in registers, and spare the KNN scan its own random gathers.
+    // the forces are still accumulated strictly in list order.  Bit 31 of a list entry says that
+    // this vertex OWNS the edge to that neighbour: the midpoint (pt.py:785) of an owned edge costs
+    // nothing here, both endpoints being in registers, and spares the KNN scan its own random
+    // gathers; owned midpoints go to consecutive rows of `mid` starting at mid_row0.
     constexpr int C = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;
 #pragma unroll
     for (int d = 0; d < LD; ++d) F[d] = 0.0f;
     for (int base = beg; base < end; base += C) {
         int64_t ys[C];
+        bool own[C];
 #pragma unroll
-        for (int j = 0; j < C; ++j) ys[j] = base + j < end ? (int64_t)adj[base + j] : self;
+        for (int j = 0; j < C; ++j) {
+            const uint32_t a = base + j < end ? (uint32_t)adj[base + j] : (uint32_t)self;
+            ys[j] = (int64_t)(a & 0x7FFFFFFFu);
+            own[j] = base + j < end && (a >> 31) != 0;
+        }
         float py[C][LD];
 #pragma unroll
         for (int j = 0; j < C; ++j) gh_load_row<LD>(pos, ys[j], py[j]);
@@ -132,11 +137,11 @@ __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const
                 const float fm = neg_k * (dist - L_min);
 #pragma unroll
                 for (int d = 0; d < D; ++d) F[d] = F[d] + fm * (diff[d] / dist);
-                if (WRITE_MID && base + j - beg < nfirst) {
+                if (WRITE_MID && own[j]) {
                     float mrow[LD];
 #pragma unroll
                     for (int d = 0; d < LD; ++d) mrow[d] = d < D ? (px[d] + py[j][d]) / 2.0f : 0.0f;
-                    gh_store_row<LD>(mid, mid_row0 + (base + j - beg), mrow);
+                    gh_store_row<LD>(mid, mid_row0++, mrow);
                 }
             }
         }

@@ -48,9 +48,14 @@ struct gh_engine {
     int32_t *d_rowptr = nullptr;  // (rows + 1) pull lists of own rows, reference summation order
     int32_t *d_adj = nullptr;     // neighbours
     int64_t adj_len = 0;
-    int32_t *d_first_edge = nullptr; // (rows + 1) first edge id of each own row (edge list sorted by first endpoint)
+    int32_t *d_first_edge = nullptr; // (rows + 1) offset of each own row's owned edges: the first owned edge id
+                                     // (rule A: smaller endpoint owns) or a prefix count into d_own_eids (rule B)
+    int32_t *d_own_eids = nullptr;   // rule B (balanced ownership of partitioned engines): ids of the owned edges
+                                     // in (row, list) order; null under rule A
+    int64_t own_count = 0;           // edges this rank owns (midpoints in d_mid, searched by its KNN kernels)
+    int64_t mid_base = 0;            // d_mid row of an owned edge = d_first_edge offset - mid_base
     bool fused_mid = false;       // own edge range == edges owned by own rows: spring kernel writes midpoints
-    float *d_mid = nullptr;       // (edge_hi - edge_lo, LD) midpoints of the own edges, current iteration
+    float *d_mid = nullptr;       // (own_count, LD) midpoints of the own edges, current iteration
     float *d_Fs = nullptr;        // (rows, LD) spring forces of the own rows
     float *d_midsub = nullptr;    // (ceil(own edges / 2), LD) compact midpoints of the threshold subsets
     int32_t *d_vblock = nullptr;  // (n_vblocks + 1) vertex ranges of the fused spring+scan workgroups

@@ -30,14 +30,9 @@ __global__ __launch_bounds__(256) void spring_kernel(
     const int64_t x = row_lo + i;
     float px[LD], F[LD];
     gh_load_row<LD>(pos, x, px);
-    int nfirst = 0;
     int64_t mid_row0 = 0;
-    if (WRITE_MID) {
-        const int fe = first_edge[i];
-        nfirst = first_edge[i + 1] - fe;
-        mid_row0 = fe - edge_lo;
-    }
-    spring_pull<D, LD, WRITE_MID>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mid, mid_row0, nfirst);
+    if (WRITE_MID) mid_row0 = first_edge[i] - edge_lo;  // d_mid row of the first edge this row owns
+    spring_pull<D, LD, WRITE_MID>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mid, mid_row0);
     gh_store_row<LD>(outF, i + f_row0, F);
 }
 
@@ -98,13 +93,15 @@ __global__ __launch_bounds__(256) void integrate_generic_kernel(
 // Midpoints of the edges [e_lo, e_lo + M) by gathering both endpoints (used when the edge
 // list is not sorted by first endpoint, or a partition does not follow row ownership).
 __global__ __launch_bounds__(256) void mid_gather_kernel(const float *__restrict__ pos,
-                                                        const int32_t *__restrict__ edges, int64_t e_lo, int64_t M,
-                                                        int D, int LD, float *__restrict__ mid) {
+                                                        const int32_t *__restrict__ edges, int64_t e_lo,
+                                                        const int32_t *__restrict__ eids, int64_t M, int D, int LD,
+                                                        float *__restrict__ mid) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= M * LD) return;
     const int64_t j = t / LD;
     const int d = (int)(t % LD);
-    const int64_t u = edges[2 * (e_lo + j)], v = edges[2 * (e_lo + j) + 1];
+    const int64_t e = eids ? (int64_t)eids[j] : e_lo + j;
+    const int64_t u = edges[2 * e], v = edges[2 * e + 1];
     mid[t] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
 }
 
@@ -120,7 +117,7 @@ __global__ __launch_bounds__(256) void spring_generic_kernel(
     float *dst = outF + (i + f_row0) * LD;
     for (int d = 0; d < LD; ++d) dst[d] = 0.0f;
     for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-        const int64_t y = adj[j];
+        const int64_t y = (uint32_t)adj[j] & 0x7FFFFFFFu;  // bit 31 = ownership flag
         for (int d = 0; d < D; ++d) diff[d] = pos[y * LD + d] - pos[x * LD + d];
         const float dist = sqrtf(gh_sumsq_rt(diff, D)) + 1e-6f;
         const float fm = neg_k * (dist - L_min);
@@ -365,7 +362,7 @@ gh_status launch_spring(gh_engine *h, float *outF, int64_t f_row0) {
     const float neg_k = -h->prm.k_attr;
 #define GH_SPRING_CASE(DD, LL)                                                                              \
     spring_kernel<DD, LL, WRITE_MID><<<dim3(grid), dim3(256), 0, h->stream>>>(                              \
-        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->part.edge_lo, h->part.row_lo, h->rows,         \
+        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->mid_base, h->part.row_lo, h->rows,         \
         h->prm.L_min, neg_k, outF, f_row0, h->d_mid)
     switch (h->D) {
         case 2: GH_SPRING_CASE(2, 4); break;
@@ -384,11 +381,11 @@ gh_status launch_spring(gh_engine *h, float *outF, int64_t f_row0) {
 }
 
 gh_status launch_mid_gather(gh_engine *h) {
-    const int64_t M = h->part.edge_hi - h->part.edge_lo;
+    const int64_t M = h->own_count;
     if (M == 0) return GH_OK;
     gh_scope t(h, "mid_gather");
-    mid_gather_kernel<<<dim3(grid_for(M * h->LD, 256)), dim3(256), 0, h->stream>>>(h->d_pos, h->d_edges, h->part.edge_lo,
-                                                                                  M, h->D, h->LD, h->d_mid);
+    mid_gather_kernel<<<dim3(grid_for(M * h->LD, 256)), dim3(256), 0, h->stream>>>(
+        h->d_pos, h->d_edges, h->part.edge_lo, h->d_own_eids, M, h->D, h->LD, h->d_mid);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

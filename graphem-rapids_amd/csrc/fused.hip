@@ -61,9 +61,7 @@ __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const 
         const int64_t x = row_lo + i;
         float px[LD], F[LD], nw[LD];
         gh_load_row<LD>(pos, x, px);
-        const int fe = first_edge[i];
-        spring_pull<D, LD, true>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mids, fe - fe0,
-                                 first_edge[i + 1] - fe);
+        spring_pull<D, LD, true>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mids, first_edge[i] - fe0);
         gh_store_row<LD>(Fs, i, F);
 #pragma unroll
         for (int d = 0; d < LD; ++d) {
@@ -98,15 +96,16 @@ __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const dou
 template <int D, int LD, int R, int NT>
 __global__ __launch_bounds__(NT) void spring_scan_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
-    const int32_t *__restrict__ first_edge, const int32_t *__restrict__ vblock, int64_t row_lo, float L_min,
-    float neg_k, float *__restrict__ Fs, float *__restrict__ out_new, double *__restrict__ blockstats,
-    const float *__restrict__ qt, const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand,
-    int32_t *__restrict__ cnt) {
+    const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
+    const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
+    float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
+    const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
     constexpr int TILE = NT * R;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     constexpr int HITBUF = TILE * LD * 4 / 16;  // hit records reuse the midpoint tile's LDS
     __shared__ float4 tile[TILE * LD / 4];
     __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)];
+    __shared__ float taush[GH_SCAN_QGROUP];
     __shared__ int hcount;
     float *mids = reinterpret_cast<float *>(tile);
 
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
         float mv[LD];
         if (j < nedges) {
             gh_load_row<LD>(mids, j, mv);
-            id[r] = (uint32_t)(fe0 + j);
+            id[r] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
         } else {
 #pragma unroll
             for (int d = 0; d < LD; ++d) mv[d] = 0.0f;  // padding slot: c0 = +inf never passes the filter
@@ -152,9 +151,9 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
         if (s_lo > 0) __syncthreads();  // the previous group's records are still being read
-        gh_stage_queries<QS, NT>(qscan, s_lo, nq, qsh);
+        gh_stage_queries<QS, (D <= 3 ? 3 : LD), NT>(qscan, qt, s_lo, nq, qsh, taush);
         __syncthreads();
-        gh_scan_queries<D, R, HITBUF>(m, c0, id, qsh, nq, s_lo, qt, hkey, hq, &hcount, cand, cnt);
+        gh_scan_queries<D, R, HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt);
     }
     __syncthreads();
     gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
@@ -165,10 +164,10 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
 template <int D>
 __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
-    const int32_t *__restrict__ first_edge, const int32_t *__restrict__ vblock, int64_t row_lo, float L_min,
-    float neg_k, float *__restrict__ Fs, float *__restrict__ out_new, double *__restrict__ blockstats,
-    const float *__restrict__ qt, const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand,
-    int32_t *__restrict__ cnt) {
+    const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
+    const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
+    float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
+    const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
     constexpr int LD = 4, TILE = 1024, G = 16;
     constexpr int HITBUF = TILE * LD * 4 / 16;
     __shared__ float4 tile[TILE * LD / 4];
@@ -237,14 +236,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
 template <int D>
 void launch_mfma(gh_engine *h) {
     spring_scan_mfma_kernel<D><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
-        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
+        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
         h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt);
 }
 
 template <int D, int LD, int R, int NT>
 void launch(gh_engine *h) {
     spring_scan_kernel<D, LD, R, NT><<<dim3((unsigned)h->n_vblocks), dim3(NT), 0, h->stream>>>(
-        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
+        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
         h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt);
 }
 
@@ -254,7 +253,7 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
     if (h->n_vblocks == 0) return GH_OK;
     gh_scope t(h, "spring_scan");
     int nt, r;
-    fused_cfg(h->LD, h->part.edge_hi - h->part.edge_lo, &nt, &r);
+    fused_cfg(h->LD, h->own_count, &nt, &r);
 #define GH_FUSED_D(NTT, RR)                                   \
     switch (h->D) {                                           \
         case 2: launch<2, 4, RR, NTT>(h); break;              \
@@ -263,7 +262,7 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
     }
     // The MFMA form of the pre-filter is opt-in: measured 214-225 us against 164 us for the packed
     // VALU form on the 1M-vertex graph (AGPR read-back, MFMA->VALU latency, 100 VGPRs).
-    if (h->LD == 4 && h->D <= 3 && nt == 256 && r == 4 && getenv("GRAPHEM_HIP_MFMA")) {
+    if (h->LD == 4 && h->D <= 3 && nt == 256 && r == 4 && !h->d_own_eids && getenv("GRAPHEM_HIP_MFMA")) {
         if (h->D == 2) launch_mfma<2>(h); else launch_mfma<3>(h);
     } else if (h->LD == 4) {
         if (nt == 256 && r == 8) { GH_FUSED_D(256, 8) }

@@ -58,8 +58,8 @@ __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi
 __global__ __launch_bounds__(256) void knn_setup_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ edges, int32_t *__restrict__ sampled, int mode,
     int64_t E, uint64_t seed, uint64_t iter, int64_t S, int D, int LD, float *__restrict__ qt,
-    int32_t *__restrict__ cnt, int32_t *__restrict__ ovf, int64_t e_lo, int64_t M1, int64_t stride,
-    float *__restrict__ midsub, int32_t *__restrict__ tcount) {
+    int32_t *__restrict__ cnt, int32_t *__restrict__ ovf, int64_t e_lo, const int32_t *__restrict__ own_eids,
+    int64_t M1, int64_t stride, float *__restrict__ midsub, int32_t *__restrict__ tcount) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t == 0) *tcount = 0;  // the previous iteration's normalise kernel has consumed it
     if (t < S) {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void knn_setup_kernel(
     if (g >= M1 * LD) return;
     const int64_t j = g / LD;
     const int d = (int)(g % LD);
-    const int64_t e = e_lo + j * stride;
+    const int64_t e = own_eids ? (int64_t)own_eids[j * stride] : e_lo + j * stride;
     const int64_t u = edges[2 * e], v = edges[2 * e + 1];
     midsub[g] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
 }
@@ -109,47 +109,74 @@ __device__ __forceinline__ int next_pow2(int x) {
     return p;
 }
 
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t o = __shfl_xor(v, off, GH_WAVE);
-        v = o < v ? o : v;
-    }
-    return v;
+// Wave-wide minimum of 64-bit keys on the DPP datapath (quad swaps, half-row and row mirrors:
+// VALU-rate, no LDS crossbar round trips as with __shfl_xor), then the four row minima through
+// v_readlane.  Every lane returns the minimum.
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
 }
-
-// K smallest of the keys a 256-thread workgroup holds in registers (NPT per thread, unused
-// slots = GH_KEY_INF), written ascending to out[0..K) in LDS.  K rounds of a block-wide
-// minimum: keys are unique (the id is part of the key), so the owner of a round's minimum
-// retires it by equality.  ~200 cycles per round, against ~50 barrier phases for a sort.
-template <int NPT>
-__device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *out, uint64_t (*red)[4]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int r = 0; r < K; ++r) {
-        uint64_t m = keys[0];
-#pragma unroll
-        for (int j = 1; j < NPT; ++j) m = keys[j] < m ? keys[j] : m;
-        m = wave_min_u64(m);
-        if (lane == 0) red[r & 1][w] = m;
-        __syncthreads();
-        uint64_t bm = red[r & 1][0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i) bm = red[r & 1][i] < bm ? red[r & 1][i] : bm;
-        if (threadIdx.x == 0) out[r] = bm;
-        if (bm != GH_KEY_INF) {
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) keys[j] = keys[j] == bm ? GH_KEY_INF : keys[j];
-        }
-    }
-    __syncthreads();
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t min_u64(uint64_t a, uint64_t b) { return b < a ? b : a; }
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+    v = min_u64(v, dpp_u64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = min_u64(v, dpp_u64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = min_u64(v, dpp_u64<0x141>(v));  // row_half_mirror
+    v = min_u64(v, dpp_u64<0x140>(v));  // row_mirror: every lane holds its row's minimum
+    return min_u64(min_u64(readlane_u64(v, 0), readlane_u64(v, 16)),
+                   min_u64(readlane_u64(v, 32), readlane_u64(v, 48)));
 }
 
 #define GH_EXTRACT_MAX_K 64
 
+// K smallest of the keys a 256-thread workgroup holds in registers (NPT per thread, unused
+// slots = GH_KEY_INF), written ascending to out[0..K) in LDS.  Each of the four waves extracts
+// the K smallest of ITS keys on its own -- K rounds of a wave-wide minimum, no barrier; keys are
+// unique (the id is part of the key), so the owner of a round's minimum retires it by equality
+// -- and the 4K survivors are ranked by counting.  wsc: 4 * GH_EXTRACT_MAX_K keys of LDS scratch.
+template <int NPT>
+__device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *out, uint64_t *wsc) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = 0; r < K; ++r) {
+        uint64_t m = keys[0];
+#pragma unroll
+        for (int j = 1; j < NPT; ++j) m = min_u64(m, keys[j]);
+        m = wave_min_u64(m);
+        if (lane == 0) wsc[w * K + r] = m;
+        if (m == GH_KEY_INF) {  // wave-uniform: this wave has run dry
+            for (int rr = r + 1 + lane; rr < K; rr += 64) wsc[w * K + rr] = GH_KEY_INF;
+            break;
+        }
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) keys[j] = keys[j] == m ? GH_KEY_INF : keys[j];
+    }
+    __syncthreads();
+    const int t = threadIdx.x, n4 = 4 * K;
+    if (t < n4) {
+        const uint64_t key = wsc[t];
+        int rank = 0;
+        for (int j = 0; j < n4; ++j) {
+            const uint64_t o = wsc[j];
+            rank += (o < key || (o == key && j < t)) ? 1 : 0;  // equal keys are GH_KEY_INF fillers only
+        }
+        if (rank < K) out[rank] = key;
+    }
+    __syncthreads();
+}
+
+
+
 // K smallest of the c keys in src (LDS or global), by the smallest per-thread register count
 // that holds them: the cost of a round is proportional to the keys each thread rescans.
 template <int MAXNPT>
-__device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64_t *out, uint64_t (*red)[4]) {
+__device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64_t *out, uint64_t *red) {
     auto run = [&](auto npt_tag) {
         constexpr int NPT = decltype(npt_tag)::value;
         uint64_t keys[NPT];
@@ -175,14 +202,15 @@ __device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64
 // at once; a chunk with a survivor re-extracts the best K from (survivors + previous best).
 // K <= GH_EXTRACT_MAX_K.
 __global__ __launch_bounds__(256) void knn_block_select_kernel(
-    const float *__restrict__ mid, const float *__restrict__ pos, const int32_t *__restrict__ edges, int LD, int D,
+    const float *__restrict__ mid, const float *__restrict__ pos, const int32_t *__restrict__ edges,
+    const int32_t *__restrict__ eids /* ids of the scanned edges, or null: e_lo + j*stride */, int LD, int D,
     int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride, const float *__restrict__ qt, int QS, int K,
     const int32_t *__restrict__ only_flagged, uint64_t *__restrict__ out_keys /* (S, K) or null */,
     float *__restrict__ tau_out /* qt + tau offset, or null */, inter_args ia) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
-    __shared__ uint64_t red[2][4];
+    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
     constexpr int NPT = 8;
 
     const int64_t qi = blockIdx.x;
@@ -200,7 +228,7 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(
             const int64_t r = base + j * 256 + threadIdx.x;
             uint64_t key = GH_KEY_INF;
             if (r < M) {
-                const int64_t e = e_lo + r * stride;
+                const int64_t e = eids ? (int64_t)eids[r * stride] : e_lo + r * stride;
                 float s = 0.0f;
                 if (mid) {
                     const float *mr = mid + (r * mem_stride) * LD;
@@ -235,7 +263,8 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(
 // The same selection for large K (> GH_EXTRACT_MAX_K): running threshold + LDS compaction +
 // bitonic sort.  K <= GH_SEL_BUF - GH_SEL_CHUNK.
 __global__ __launch_bounds__(256) void knn_block_select_sort_kernel(
-    const float *__restrict__ mid, const float *__restrict__ pos, const int32_t *__restrict__ edges, int LD, int D,
+    const float *__restrict__ mid, const float *__restrict__ pos, const int32_t *__restrict__ edges,
+    const int32_t *__restrict__ eids /* ids of the scanned edges, or null: e_lo + j*stride */, int LD, int D,
     int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride, const float *__restrict__ qt, int QS, int K, const int32_t *__restrict__ only_flagged,
     uint64_t *__restrict__ out_keys, float *__restrict__ tau_out) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(256) void knn_block_select_sort_kernel(
         for (int j = threadIdx.x; j < GH_SEL_CHUNK; j += blockDim.x) {
             const int64_t r = base + j;
             if (r < M) {
-                const int64_t e = e_lo + r * stride;
+                const int64_t e = eids ? (int64_t)eids[r * stride] : e_lo + r * stride;
                 float s = 0.0f;
                 if (mid) {
                     const float *mr = mid + (r * mem_stride) * LD;
@@ -306,13 +335,14 @@ __global__ __launch_bounds__(256) void knn_block_select_sort_kernel(
 
 template <int D, int R>
 __global__ __launch_bounds__(256) void knn_scan_kernel(
-    const float *__restrict__ mid, int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride,
+    const float *__restrict__ mid, int64_t e_lo, const int32_t *__restrict__ eids, int64_t M, int64_t mem_stride, int64_t stride,
     const float *__restrict__ qt, const float *__restrict__ qscan, int S, int qgroup,
     uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
     static_assert(R % 2 == 0, "references are processed in packed pairs");
     constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)];
+    __shared__ float taush[GH_SCAN_QGROUP];
     __shared__ uint64_t hkey[GH_SCAN_HITBUF];
     __shared__ int hq[GH_SCAN_HITBUF];
     __shared__ int hcount;
@@ -320,7 +350,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
     if (threadIdx.x == 0) hcount = 0;
     const int s_lo = blockIdx.y * qgroup;
     const int nq = min(S - s_lo, qgroup);
-    gh_stage_queries<QS>(qscan, s_lo, nq, qsh);
+    gh_stage_queries<QS, (D <= 3 ? 3 : LD)>(qscan, qt, s_lo, nq, qsh, taush);
     gh_f2 m[R / 2][D], c0[R / 2];
     uint32_t id[R];
     const int64_t tile = (int64_t)blockIdx.x * (256 * R);
@@ -330,7 +360,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
         float mv[LD];
         if (j < M) {
             gh_load_row<LD>(mid, j * mem_stride, mv);
-            id[r] = (uint32_t)(e_lo + j * stride);
+            id[r] = eids ? (uint32_t)eids[j * stride] : (uint32_t)(e_lo + j * stride);
         } else {
 #pragma unroll
             for (int d = 0; d < LD; ++d) mv[d] = 0.0f;  // padding slot: c0 = +inf never passes the filter
@@ -345,7 +375,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
         }
     }
     __syncthreads();
-    gh_scan_queries<D, R, GH_SCAN_HITBUF>(m, c0, id, qsh, nq, s_lo, qt, hkey, hq, &hcount, cand, cnt);
+    gh_scan_queries<D, R, GH_SCAN_HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt);
     __syncthreads();
     gh_flush_hits<GH_SCAN_HITBUF>(hkey, hq, &hcount, cand, cnt);
 }
@@ -363,7 +393,7 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
     constexpr int RPT = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;  // rows per thread per pass (2048 / 1024 / 512 rows)
     __shared__ uint64_t buf[BUF];
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
-    __shared__ uint64_t red[2][4];
+    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
     __shared__ int cnt;
     __shared__ float qs[LD];
     const int64_t qi = blockIdx.x;
@@ -458,7 +488,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
                                                          int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
                                                          inter_args ia) {
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
-    __shared__ uint64_t red[2][4];
+    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
     constexpr int NPT = GH_CAND_CAP / 256;
     const int64_t qi = blockIdx.x;
     const int c = cnt[qi * GH_CNT_STRIDE];
@@ -514,7 +544,7 @@ void launch_scan(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, 
     if (qgroup > GH_SCAN_QGROUP) qgroup = GH_SCAN_QGROUP;
     groups = (int)((h->S + qgroup - 1) / qgroup);
     knn_scan_kernel<D, R><<<dim3((unsigned)tiles, (unsigned)groups), dim3(256), 0, h->stream>>>(
-        mid, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, h->d_qscan, (int)h->S, qgroup, h->d_cand, h->d_cnt);
+        mid, h->part.edge_lo, h->d_own_eids, M, mem_stride, id_stride, h->d_q, h->d_qscan, (int)h->S, qgroup, h->d_cand, h->d_cnt);
 }
 
 template <int R>
@@ -546,27 +576,32 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
     float *tau_out = write_tau ? h->d_q + gh_qtau(h->D, h->LD) : nullptr;
     if (h->K <= GH_EXTRACT_MAX_K) {
         knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
-            mid, h->d_pos, h->d_edges, h->LD, h->D, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, QS, h->K,
-            only_flagged, out_keys, tau_out, make_inter_args(h, with_intersect));
+            mid, h->d_pos, h->d_edges, h->d_own_eids, h->LD, h->D, h->part.edge_lo, M,
+            mem_stride, id_stride, h->d_q, QS, h->K, only_flagged, out_keys, tau_out, make_inter_args(h, with_intersect));
     } else {
         const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)h->LD;
         knn_block_select_sort_kernel<<<dim3((unsigned)h->S), dim3(256), smem, h->stream>>>(
-            mid, h->d_pos, h->d_edges, h->LD, h->D, h->part.edge_lo, M, mem_stride, id_stride, h->d_q, QS, h->K,
-            only_flagged, out_keys, tau_out);
+            mid, h->d_pos, h->d_edges, h->d_own_eids, h->LD, h->D, h->part.edge_lo, M,
+            mem_stride, id_stride, h->d_q, QS, h->K, only_flagged, out_keys, tau_out);
     }
 }
 
-// Stride of the threshold subset: the final pass then sees ~K*stride candidates per query
-// (mean; the list holds GH_CAND_CAP), the threshold kernel streams E/stride rows per query.
-// A workgroup of the final pass parks its hits in LDS: S*K*stride*tile/E of them on average,
-// kept near 300 so the buffer (>= 1024 entries) does not overflow into the slow direct path.
+// Stride of the threshold subset.  The threshold kernel streams M/stride rows per query
+// (measured: ~21 us + 0.41 us per 1000 rows), the final pass then meets ~K*stride candidates per
+// query, each a divergent exact re-check + LDS append in the scan (measured: ~0.25 us per unit of
+// stride at S*K = 2816, scaling with S*K).  The sum is smallest near sqrt(4.6 * M / (S*K)):
+// 81 for the 1M-vertex graph (M = 4M), 26 for M = 400K.  Bounds: the list holds GH_CAND_CAP
+// candidates (mean K*stride kept <= 4096), a workgroup parks its hits in LDS (mean
+// S*K*stride*tile/M kept near 300 for a buffer of >= 1024), and the subset stays well above K rows.
 int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile) {
     if (const char *e = getenv("GRAPHEM_HIP_SUBSET_STRIDE")) {  // tuning override
         const long v = atol(e);
         if (v >= 2 && v <= Mtot / (4 * (int64_t)K)) return v;
     }
-    int64_t r = 1408 / K;
-    if (r > 128) r = 128;
+    int64_t r = (int64_t)sqrt(4.6 * (double)Mtot / ((double)S * K));
+    const int64_t by_list = 4096 / K;
+    if (r > by_list) r = by_list;
+    if (r > 256) r = 256;
     const int64_t by_hits = (int64_t)(300.0 * (double)Mtot / ((double)S * K * tile));
     if (r > by_hits) r = by_hits;
     if (r < 2) r = 2;
@@ -586,15 +621,18 @@ gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect) {
 
 }  // namespace
 
+// Edges this rank searches: the range [edge_lo, edge_hi), or the list d_own_eids (hashed ownership).
+static int64_t own_edges(const gh_engine *h) { return h->own_count; }
+
 bool gh_knn_scan_path(const gh_engine *h) {
-    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    const int64_t Mtot = own_edges(h);
     return Mtot >= GH_SCAN_MIN_EDGES && h->LD <= 16 && h->D >= 2 && h->K <= GH_EXTRACT_MAX_K && h->S <= 0x7FFFFFFF;
 }
 
 // Sample ids (if still pending), query records, list reset and -- on the scan path -- the compact
 // threshold subset: one launch.
 gh_status gh_knn_prepare(gh_engine *h) {
-    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    const int64_t Mtot = own_edges(h);
     const bool scan = gh_knn_scan_path(h);
     const int64_t st = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h->LD, Mtot)) : 1;
     const int64_t M1 = scan ? (Mtot + st - 1) / st : 0;
@@ -604,14 +642,14 @@ gh_status gh_knn_prepare(gh_engine *h) {
     const int64_t threads = h->S + M1 * h->LD;
     knn_setup_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_edges, h->d_sampled_cur, mode, h->E, h->prm.seed, h->iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
-        h->d_ovf, h->part.edge_lo, M1, st, h->d_midsub, h->d_tcount);
+        h->d_ovf, h->part.edge_lo, h->d_own_eids, M1, st, h->d_midsub, h->d_tcount);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
 
 // tau of every query from the compact subset (gh_knn_prepare made it).  Needs gh_knn_scan_path(h).
 gh_status gh_knn_thresholds(gh_engine *h) {
-    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    const int64_t Mtot = own_edges(h);
     const int64_t st = subset_stride(Mtot, h->K, h->S, gh_fused_tile(h->LD, Mtot));
     const int64_t M1 = (Mtot + st - 1) / st;
     const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
@@ -630,7 +668,7 @@ gh_status gh_knn_thresholds(gh_engine *h) {
 // fuse_intersect (single-rank steps): the same launches also run the intersection phase of each
 // query they finish (h->intersect_done tells the caller).
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect) {
-    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    const int64_t Mtot = own_edges(h);
     const bool fuse = fuse_intersect && h->K <= GH_EXTRACT_MAX_K;
     GH_TRY_ST(launch_select(h, true, fuse));
     gh_scope t(h, "knn_overflow_fallback");
@@ -642,7 +680,7 @@ gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect) {
 
 // Unfused search over the materialised midpoints d_mid -> d_partial.
 gh_status gh_knn_local(gh_engine *h, bool fuse_intersect) {
-    const int64_t Mtot = h->part.edge_hi - h->part.edge_lo;
+    const int64_t Mtot = own_edges(h);
     GH_TRY_ST(gh_knn_prepare(h));
     if (!gh_knn_scan_path(h)) {
         const bool fuse = fuse_intersect && h->K <= GH_EXTRACT_MAX_K;
@@ -691,12 +729,12 @@ gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq,
     inter_args none{};
     if (K <= GH_EXTRACT_MAX_K) {
         knn_block_select_kernel<<<dim3((unsigned)nq), dim3(256), sizeof(float) * (size_t)D, stream>>>(
-            d_ref, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D, K, nullptr, d_keys, nullptr, none);
+            d_ref, nullptr, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D, K, nullptr, d_keys, nullptr, none);
     } else {
         const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)D;
         if (smem > 64 * 1024) { *err = "dimension too large for the point KNN kernel"; return GH_ERR_INVALID; }
         knn_block_select_sort_kernel<<<dim3((unsigned)nq), dim3(256), smem, stream>>>(
-            d_ref, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D, K, nullptr, d_keys, nullptr);
+            d_ref, nullptr, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D, K, nullptr, d_keys, nullptr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); return GH_ERR_HIP; }

@@ -19,11 +19,15 @@ __device__ __forceinline__ void gh_append_candidate(uint64_t *__restrict__ cand,
 }
 
 // Stage nq query records (plus one spare for the prefetch) of the group starting at s_lo.
-template <int QS, int NT = 256>
-__device__ __forceinline__ void gh_stage_queries(const float *__restrict__ qt, int s_lo, int nq, float4 *qsh) {
-    const float4 *src = reinterpret_cast<const float4 *>(qt) + (int64_t)s_lo * (QS / 4);
+// taush gets the exact thresholds tau of the same queries (element QT of the records qt): the
+// rare exact path of the scan then needs no global load.
+template <int QS, int QT, int NT = 256>
+__device__ __forceinline__ void gh_stage_queries(const float *__restrict__ qscan, const float *__restrict__ qt,
+                                                 int s_lo, int nq, float4 *qsh, float *taush) {
+    const float4 *src = reinterpret_cast<const float4 *>(qscan) + (int64_t)s_lo * (QS / 4);
     for (int i = threadIdx.x; i < (nq + 1) * (QS / 4); i += NT)
         qsh[i] = i < nq * (QS / 4) ? src[i] : make_float4(0.f, 0.f, 0.f, -1.f);
+    for (int i = threadIdx.x; i < nq; i += NT) taush[i] = qt[(int64_t)(s_lo + i) * QS + QT];
 }
 
 // Relative slack of the pre-filter below.  |filter value - exact fma-chain dist2| is bounded by
@@ -58,7 +62,7 @@ __device__ __forceinline__ float gh_ref_c0(const float *mv, bool valid) {
 template <int D, int R, int HITBUF>
 __device__ __forceinline__ void gh_scan_queries(const gh_f2 (&m)[R / 2][D], const gh_f2 (&c0)[R / 2],
                                                 const uint32_t (&id)[R], const float4 *qsh, int nq, int s_lo,
-                                                const float *__restrict__ qt, uint64_t *hkey, int *hq,
+                                                const float *taush, uint64_t *hkey, int *hq,
                                                 int *hcount, uint64_t *__restrict__ cand,
                                                 int32_t *__restrict__ cnt) {
     constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
@@ -90,8 +94,8 @@ __device__ __forceinline__ void gh_scan_queries(const gh_f2 (&m)[R / 2][D], cons
             const int sg = s_lo + s;
             float q[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) q[d] = qt[(int64_t)sg * QS + d];
-            const float tau = qt[(int64_t)sg * QS + QT];
+            for (int d = 0; d < D; ++d) q[d] = -0.5f * qv[d];  // the record holds -2q: exact both ways
+            const float tau = taush[s];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float ar = (r & 1) ? a[r / 2].y : a[r / 2].x;

@@ -2,9 +2,12 @@
 multi-GPU code, so this is new functionality whose oracle is "N ranks == 1 rank").
 
 One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).  Rank r owns the
-vertex rows [r*chunk, (r+1)*chunk) and the edges whose first endpoint it owns (the edge list is
-sorted by first endpoint, so that is a contiguous edge range).  Every rank holds all n
-positions and the whole edge list.  Per iteration:
+vertex rows [r*chunk, (r+1)*chunk) and a disjoint share of the edges: by default each edge
+belongs to one of its two endpoints, picked by a fixed hash of the edge id, and so to the rank
+holding that endpoint's row (`edge_ownership="hashed"`: ~E/world edges per rank whatever the
+vertex numbering); with `edge_ownership="range"` a rank owns the edges whose first endpoint it
+holds (a contiguous range of the sorted edge list -- for a u<v edge list rank 0 then holds
+most of the edges).  Every rank holds all n positions and the whole edge list.  Per iteration:
 
     part 1  (local)   spring pull of own rows + midpoints of own edges; exact KNN of the S
                       sampled midpoints among the OWN edges -> S x (k+1) keys
@@ -39,6 +42,24 @@ def partition_edges(edges, row_lo, row_hi):
     if len(e0) > 1 and np.any(e0[1:] < e0[:-1]):
         raise ValueError("the edge list must be sorted by first endpoint (CSR row order)")
     return int(np.searchsorted(e0, row_lo, side="left")), int(np.searchsorted(e0, row_hi, side="left"))
+
+
+def edge_owner_is_second(edge_ids):
+    """The hash of the C library's GH_EDGES_HASHED rule (csrc/api.hip, gh_create): True where an
+    edge is owned by its second endpoint."""
+    x = (np.asarray(edge_ids, dtype=np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(13)
+    return (x >> np.uint64(31)) != 0
+
+
+def owned_edge_ids(edges, row_lo, row_hi):
+    """Ids of the edges a rank with rows [row_lo, row_hi) owns under the hashed rule."""
+    edges = np.asarray(edges).reshape(-1, 2)
+    second = edge_owner_is_second(np.arange(len(edges)))
+    owner = np.where(second, edges[:, 1], edges[:, 0])
+    return np.nonzero((owner >= row_lo) & (owner < row_hi))[0]
 
 
 class HipShardEngine:
@@ -80,15 +101,23 @@ class HipShardEngine:
 
 class PartitionedLayout:
     def __init__(self, n, D, edges, L_min=1.0, k_attr=0.2, k_inter=0.5, n_neighbors=10, sample_size=256, seed=0,
-                 rank=None, world=None, device_id=0, engine_factory=None, group=None):
+                 rank=None, world=None, device_id=0, engine_factory=None, group=None, edge_ownership="auto"):
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.group = group
         self.n, self.D = int(n), int(D)
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
         self.chunk, self.row_lo, self.row_hi = partition_rows(self.n, self.world, self.rank)
-        self.edge_lo, self.edge_hi = partition_edges(edges, self.row_lo, self.row_hi)
-        part = (self.row_lo, self.row_hi, self.edge_lo, self.edge_hi)
+        if edge_ownership == "auto":  # one rank owns everything either way: keep the cheaper contiguous ids
+            edge_ownership = "hashed" if self.world > 1 else "range"
+        if edge_ownership not in ("hashed", "range"):
+            raise ValueError(f"edge_ownership must be 'auto', 'hashed' or 'range', got {edge_ownership!r}")
+        self.edge_ownership = edge_ownership
+        if edge_ownership == "hashed":
+            part = (self.row_lo, self.row_hi, 0, 0, 1)
+        else:
+            self.edge_lo, self.edge_hi = partition_edges(edges, self.row_lo, self.row_hi)
+            part = (self.row_lo, self.row_hi, self.edge_lo, self.edge_hi, 0)
         factory = engine_factory or HipShardEngine
         self.engine = factory(self.n, self.D, edges, L_min, k_attr, k_inter, n_neighbors, min(sample_size, len(edges)),
                               seed, part, device_id)

@@ -49,12 +49,21 @@ typedef struct {
 } gh_params;
 
 /* Row partition for multi-GPU runs (no reference counterpart).
- * A rank integrates vertices [row_lo, row_hi) and scans edges [edge_lo, edge_hi)
- * in the KNN phase; it still holds all n positions and all E edges.
- * Single GPU: row_lo = 0, row_hi = n, edge_lo = 0, edge_hi = E. */
+ * A rank integrates vertices [row_lo, row_hi) and searches the edges it OWNS in the
+ * KNN phase; it still holds all n positions and all E edges.  Every edge must be owned
+ * by exactly one rank of the job:
+ *   GH_EDGES_RANGE   the rank owns edges [edge_lo, edge_hi) (the caller cuts the ranges);
+ *   GH_EDGES_HASHED  each edge belongs to one of its endpoints, chosen by a fixed hash of
+ *                    the edge id, and so to the rank whose rows hold that endpoint: every
+ *                    rank owns ~E/world edges whatever the vertex numbering.  The row
+ *                    ranges of the ranks must tile [0, n); edge_lo/edge_hi are ignored.
+ * Single GPU: row_lo = 0, row_hi = n, edge_lo = 0, edge_hi = E, GH_EDGES_RANGE. */
+#define GH_EDGES_RANGE 0
+#define GH_EDGES_HASHED 1
 typedef struct {
     int64_t row_lo, row_hi;
     int64_t edge_lo, edge_hi;
+    int32_t edge_rule;
 } gh_partition;
 
 /* ---- lifetime -------------------------------------------------------------- */

@@ -15,7 +15,12 @@ class CpuShardEngine:
         self.n, self.D, self.k, self.S = n, D, k, S
         self.edges = np.ascontiguousarray(edges, dtype=np.int32)
         self.prm = (L_min, k_attr, k_inter)
-        self.row_lo, self.row_hi, self.edge_lo, self.edge_hi = partition
+        self.row_lo, self.row_hi, edge_lo, edge_hi = partition[:4]
+        if len(partition) > 4 and partition[4] == 1:  # hashed ownership (include/graphem_hip.h GH_EDGES_HASHED)
+            from graphem_rapids_amd.distributed import owned_edge_ids
+            self.own_ids = owned_edge_ids(self.edges, self.row_lo, self.row_hi).astype(np.int64)
+        else:
+            self.own_ids = np.arange(edge_lo, edge_hi, dtype=np.int64)
         self.ld = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else (D + 3) // 4 * 4
         self.pos = torch.zeros((n + self.PAD_ROWS, self.ld), dtype=torch.float32)
         self.partial = torch.zeros((S, k + 1), dtype=torch.int64)
@@ -42,11 +47,11 @@ class CpuShardEngine:
         self.Fs = oracle.spring_forces(p, self.edges, self.prm[0], self.prm[1])[self.row_lo:self.row_hi]
         mid = oracle.midpoints(p, self.edges)
         q = mid[self.sampled]
-        loc = mid[self.edge_lo:self.edge_hi]
+        loc = mid[self.own_ids]
         keys = np.full((self.S, self.k + 1), np.iinfo(np.int64).max, dtype=np.int64)  # INF key pattern 0x7FFF..: sorts last
         if len(loc):
             d2 = ((q[:, None, :] - loc[None, :, :]) ** 2).sum(-1, dtype=np.float32)
-            ids = np.arange(self.edge_lo, self.edge_hi, dtype=np.int64)
+            ids = self.own_ids
             key = (d2.view(np.uint32).astype(np.int64) << 32) | ids[None, :]
             key.sort(axis=1)
             m = min(self.k + 1, key.shape[1])

@@ -30,9 +30,9 @@ def _worker(rank, world, port, case, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from graphem_rapids_amd.distributed import PartitionedLayout
     from cpu_shard_engine import CpuShardEngine
-    n, D, edges, pos, stream, k, S = case
+    n, D, edges, pos, stream, k, S = case[:7]
     lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=3, rank=rank, world=world,
-                            engine_factory=CpuShardEngine)
+                            engine_factory=CpuShardEngine, edge_ownership=case[7] if len(case) > 7 else "auto")
     lay.set_positions(pos)
     lay.run(len(stream), stream)
     np.save(os.path.join(out_dir, f"pos_w{world}_r{rank}.npy"), lay.get_positions())
@@ -51,11 +51,11 @@ def _case(n=403, D=3, deg=6, k=6, S=40, iters=3):
     return n, D, edges, pos, stream, k, S
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_layout_matches_single_rank_and_oracle(world, tmp_path):
+@pytest.mark.parametrize("world,rule", [(2, "hashed"), (3, "hashed"), (2, "range")])
+def test_partitioned_layout_matches_single_rank_and_oracle(world, rule, tmp_path):
     import oracle
-    case = _case()
-    n, D, edges, pos, stream, k, S = case
+    case = _case() + (rule,)
+    n, D, edges, pos, stream, k, S = case[:7]
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
     mp.spawn(_worker, args=(1, _free_port(), case, str(tmp_path)), nprocs=1, join=True)
     single = np.load(tmp_path / "pos_w1_r0.npy")
@@ -67,6 +67,22 @@ def test_partitioned_layout_matches_single_rank_and_oracle(world, tmp_path):
         assert np.abs(got - ref).max() < 1e-4                        # and == the oracle
         auto = np.load(tmp_path / f"auto_w{world}_r{r}.npy")
         assert np.array_equal(auto, np.load(tmp_path / f"auto_w{world}_r0.npy"))  # every rank holds the same positions
+
+
+def test_hashed_ownership_partitions_the_edges_evenly():
+    """GH_EDGES_HASHED: every edge has exactly one owner rank and the shares are near E/world even
+    for a u<v edge list (where endpoint-0 ownership gives rank 0 of 2 three quarters of the edges)."""
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd.distributed import owned_edge_ids, partition_edges, partition_rows
+    n, world = 20000, 4
+    edges = gra.random_regular_edges(n, 8, seed=2)
+    ids = [owned_edge_ids(edges, *partition_rows(n, world, r)[1:]) for r in range(world)]
+    allids = np.sort(np.concatenate(ids))
+    assert np.array_equal(allids, np.arange(len(edges)))
+    shares = np.array([len(x) for x in ids]) / len(edges)
+    assert np.abs(shares - 1 / world).max() < 0.02
+    lo, hi = partition_edges(edges, *partition_rows(n, world, 0)[1:])
+    assert (hi - lo) / len(edges) > 0.4      # the imbalance the hashed rule removes
 
 
 def test_partition_helpers():

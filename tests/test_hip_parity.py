@@ -252,15 +252,20 @@ def test_device_sampler():
     assert np.isfinite(a).all()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_engines_equal_single_engine(world):
+@pytest.mark.parametrize("world,rule,n,D", [(2, "range", 30011, 3), (3, "range", 30011, 3),
+                                            (2, "hashed", 30011, 3), (3, "hashed", 30011, 3),
+                                            (3, "hashed", 2001, 3),     # few edges: per-query search of d_mid
+                                            (2, "hashed", 9001, 5),     # D without a templated spring kernel
+                                            (3, "hashed", 20001, 16)])
+def test_partitioned_engines_equal_single_engine(world, rule, n, D):
     """The split step (gh_step_begin / gh_step_merge / gh_step_finish) with row partitions: `world`
     engines on ONE GPU, collectives emulated with device copies, must reproduce the unpartitioned
-    engine (the oracle of the multi-GPU mode is the 1-GPU result)."""
+    engine (the oracle of the multi-GPU mode is the 1-GPU result), under both edge
+    ownership rules of gh_partition."""
     import torch
     from graphem_rapids_amd import _native
-    from graphem_rapids_amd.distributed import HipShardEngine, partition_edges, partition_rows
-    n, D, k, S = 30011, 3, 10, 256
+    from graphem_rapids_amd.distributed import HipShardEngine, owned_edge_ids, partition_edges, partition_rows
+    k, S = 10, 256
     edges, pos, _ = _random_case(n - 1, D, 8, k, S, seed=21)  # last vertex isolated
     pos = np.vstack([pos, np.zeros((1, D), np.float32)])
     rng = np.random.default_rng(4)
@@ -271,13 +276,20 @@ def test_partitioned_engines_equal_single_engine(world):
     ref = single.get_positions()
     single.close()
 
-    shards, parts = [], []
+    shards, parts, owned = [], [], 0
     for r in range(world):
         chunk, lo, hi = partition_rows(n, world, r)
-        elo, ehi = partition_edges(edges, lo, hi)
+        if rule == "hashed":
+            part = (lo, hi, 0, 0, _native.EDGES_HASHED)
+            owned += len(owned_edge_ids(edges, lo, hi))
+        else:
+            elo, ehi = partition_edges(edges, lo, hi)
+            part = (lo, hi, elo, ehi, _native.EDGES_RANGE)
+            owned += ehi - elo
         parts.append((lo, hi))
-        shards.append(HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, (lo, hi, elo, ehi), 0))
+        shards.append(HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, part, 0))
         shards[-1].set_positions(pos)
+    assert owned == len(edges)  # every edge searched by exactly one rank
     for t in range(3):
         for sh in shards:
             sh.step_begin(stream[t])
