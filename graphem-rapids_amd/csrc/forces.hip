@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void intersect_kernel(const float *__restrict_
     const int64_t r = t / k;
     // neighbour c of query r is key column c+1: column 0 is dropped blindly (pt.py:421)
     const int32_t i = sampled[r], j = (int32_t)gh_key_id(keys[r * (k + 1) + (t - r * k) + 1]);
-    gh_intersect_pair(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, scratch + t * LD);
+    gh_intersect_pair_any(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, scratch + t * LD);
 }
 
 // acc (double) -> dense fp32 F for the touched vertices (per-phase entry point).

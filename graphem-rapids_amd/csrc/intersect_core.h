@@ -40,3 +40,52 @@ __device__ inline void gh_intersect_pair(const float *__restrict__ pos, int D, i
         if (atomicExch(&tflag[v[role]], 1) == 0) touched[atomicAdd(tcount, 1)] = v[role];
     }
 }
+
+// The same pair with everything in registers (D known at compile time: four vector row loads, no
+// scratch round trips through memory).  Arithmetic and order as above, so results are identical.
+template <int D, int LD>
+__device__ __forceinline__ void gh_intersect_pair_t(const float *__restrict__ pos, const int32_t *__restrict__ edges,
+                                                    int32_t i, int32_t j, float k_inter, double *__restrict__ acc,
+                                                    int32_t *__restrict__ tflag, int32_t *__restrict__ touched,
+                                                    int32_t *__restrict__ tcount) {
+    if (!(i < j)) return;
+    const int2 ei = reinterpret_cast<const int2 *>(edges)[i], ej = reinterpret_cast<const int2 *>(edges)[j];
+    const int32_t v[4] = {ei.x, ei.y, ej.x, ej.y};
+    if (v[0] == v[2] || v[0] == v[3] || v[1] == v[2] || v[1] == v[3]) return;
+    float x[4][LD];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gh_load_row<LD>(pos, v[r], x[r]);
+    const float o1 = gh_orient2d(x[0], x[1], x[2]), o2 = gh_orient2d(x[0], x[1], x[3]);
+    const float o3 = gh_orient2d(x[2], x[3], x[0]), o4 = gh_orient2d(x[2], x[3], x[1]);
+    if (!(o1 * o2 < 0.0f && o3 * o4 < 0.0f)) return;
+    float cen[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) cen[d] = (((x[0][d] + x[1][d]) + x[2][d]) + x[3][d]) / 4.0f;
+#pragma unroll
+    for (int role = 0; role < 4; ++role) {
+        float diff[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) diff[d] = x[role][d] - cen[d];
+        const float dist = sqrtf(gh_sumsq<D>(diff)) + 1e-6f;
+        const float dd = dist * dist;
+#pragma unroll
+        for (int d = 0; d < D; ++d) atomicAdd(&acc[(int64_t)v[role] * LD + d], (double)((k_inter * diff[d]) / dd));
+        if (atomicExch(&tflag[v[role]], 1) == 0) touched[atomicAdd(tcount, 1)] = v[role];
+    }
+}
+
+// Dispatch on the embedding dimension: register form for the usual D, scratch form otherwise.
+__device__ __forceinline__ void gh_intersect_pair_any(const float *__restrict__ pos, int D, int LD,
+                                                      const int32_t *__restrict__ edges, int32_t i, int32_t j,
+                                                      float k_inter, double *__restrict__ acc,
+                                                      int32_t *__restrict__ tflag, int32_t *__restrict__ touched,
+                                                      int32_t *__restrict__ tcount, float *__restrict__ diff) {
+    switch (D) {
+        case 2: gh_intersect_pair_t<2, 4>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
+        case 3: gh_intersect_pair_t<3, 4>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
+        case 4: gh_intersect_pair_t<4, 4>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
+        case 8: gh_intersect_pair_t<8, 8>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
+        case 16: gh_intersect_pair_t<16, 16>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
+        default: gh_intersect_pair(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, diff);
+    }
+}

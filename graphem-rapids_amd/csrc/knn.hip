@@ -44,7 +44,7 @@ struct inter_args {
 __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi, const uint64_t *best) {
     // neighbour c of the query is key column c+1: column 0 is dropped blindly (pt.py:421)
     for (int c = threadIdx.x; c < ia.k; c += blockDim.x)
-        gh_intersect_pair(ia.pos, ia.D, ia.LD, ia.edges, ia.sampled[qi], (int32_t)gh_key_id(best[c + 1]), ia.k_inter,
+        gh_intersect_pair_any(ia.pos, ia.D, ia.LD, ia.edges, ia.sampled[qi], (int32_t)gh_key_id(best[c + 1]), ia.k_inter,
                           ia.acc, ia.tflag, ia.touched, ia.tcount, ia.scratch + (qi * ia.k + c) * ia.LD);
 }
 
@@ -136,13 +136,14 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 
 #define GH_EXTRACT_MAX_K 64
 
-// K smallest of the keys a 256-thread workgroup holds in registers (NPT per thread, unused
-// slots = GH_KEY_INF), written ascending to out[0..K) in LDS.  Each of the four waves extracts
+// K smallest of the keys an NT-thread workgroup holds in registers (NPT per thread, unused
+// slots = GH_KEY_INF), written ascending to out[0..K) in LDS.  Each of the NT/64 waves extracts
 // the K smallest of ITS keys on its own -- K rounds of a wave-wide minimum, no barrier; keys are
 // unique (the id is part of the key), so the owner of a round's minimum retires it by equality
-// -- and the 4K survivors are ranked by counting.  wsc: 4 * GH_EXTRACT_MAX_K keys of LDS scratch.
-template <int NPT>
+// -- and the survivors are ranked by counting.  wsc: (NT/64) * GH_EXTRACT_MAX_K keys of LDS scratch.
+template <int NPT, int NT = 256>
 __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *out, uint64_t *wsc) {
+    static_assert((NT / 64) * GH_EXTRACT_MAX_K <= NT || NT == 256, "one thread per surviving key in the merge");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int r = 0; r < K; ++r) {
         uint64_t m = keys[0];
@@ -158,7 +159,7 @@ __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *o
         for (int j = 0; j < NPT; ++j) keys[j] = keys[j] == m ? GH_KEY_INF : keys[j];
     }
     __syncthreads();
-    const int t = threadIdx.x, n4 = 4 * K;
+    const int t = threadIdx.x, n4 = (NT / 64) * K;
     if (t < n4) {
         const uint64_t key = wsc[t];
         int rank = 0;
@@ -175,23 +176,23 @@ __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *o
 
 // K smallest of the c keys in src (LDS or global), by the smallest per-thread register count
 // that holds them: the cost of a round is proportional to the keys each thread rescans.
-template <int MAXNPT>
+template <int MAXNPT, int NT = 256>
 __device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64_t *out, uint64_t *red) {
     auto run = [&](auto npt_tag) {
         constexpr int NPT = decltype(npt_tag)::value;
         uint64_t keys[NPT];
 #pragma unroll
         for (int j = 0; j < NPT; ++j) {
-            const int i = j * 256 + threadIdx.x;
+            const int i = j * NT + threadIdx.x;
             keys[j] = i < c ? src[i] : GH_KEY_INF;
         }
         __syncthreads();  // src may alias out's neighbourhood in LDS; everyone has loaded
-        block_extract_smallest<NPT>(keys, K, out, red);
+        block_extract_smallest<NPT, NT>(keys, K, out, red);
     };
-    if (c <= 256) run(std::integral_constant<int, 1>{});
-    else if (c <= 1024 || MAXNPT <= 4) run(std::integral_constant<int, (MAXNPT < 4 ? MAXNPT : 4)>{});
-    else if (c <= 2048 || MAXNPT <= 8) run(std::integral_constant<int, (MAXNPT < 8 ? MAXNPT : 8)>{});
-    else if (c <= 4096 || MAXNPT <= 16) run(std::integral_constant<int, (MAXNPT < 16 ? MAXNPT : 16)>{});
+    if (c <= NT || MAXNPT <= 1) run(std::integral_constant<int, 1>{});
+    else if (c <= 4 * NT || MAXNPT <= 4) run(std::integral_constant<int, (MAXNPT < 4 ? MAXNPT : 4)>{});
+    else if (c <= 8 * NT || MAXNPT <= 8) run(std::integral_constant<int, (MAXNPT < 8 ? MAXNPT : 8)>{});
+    else if (c <= 16 * NT || MAXNPT <= 16) run(std::integral_constant<int, (MAXNPT < 16 ? MAXNPT : 16)>{});
     else run(std::integral_constant<int, MAXNPT>{});
 }
 
@@ -201,20 +202,24 @@ __device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64
 // computes 8 keys into registers; keys that do not beat the current K-th key are dropped
 // at once; a chunk with a survivor re-extracts the best K from (survivors + previous best).
 // K <= GH_EXTRACT_MAX_K.
-__global__ __launch_bounds__(256) void knn_block_select_kernel(
-    const float *__restrict__ mid, const float *__restrict__ pos, const int32_t *__restrict__ edges,
-    const int32_t *__restrict__ eids /* ids of the scanned edges, or null: e_lo + j*stride */, int LD, int D,
-    int64_t e_lo, int64_t M, int64_t mem_stride, int64_t stride, const float *__restrict__ qt, int QS, int K,
-    const int32_t *__restrict__ only_flagged, uint64_t *__restrict__ out_keys /* (S, K) or null */,
-    float *__restrict__ tau_out /* qt + tau offset, or null */, inter_args ia) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats
-    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
-    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
-    constexpr int NPT = 8;
+struct search_args {  // what the exact per-query search reads
+    const float *mid;      // midpoint rows (row j <-> reference j), or null: gather the endpoints from pos
+    const float *pos;
+    const int32_t *edges;
+    const int32_t *eids;   // ids of the references, or null: e_lo + j*stride
+    int LD, D;
+    int64_t e_lo, M, mem_stride, stride;
+    const float *qt;       // query records (QS floats each, coordinates first)
+    int QS;
+};
 
-    const int64_t qi = blockIdx.x;
-    if (only_flagged && only_flagged[qi] == 0) return;
+// best[0..K) <- the K smallest keys of query qi; qs: LD floats of LDS, red: extraction scratch.
+__device__ void block_search_query(const search_args &a, int64_t qi, int K, float *qs, uint64_t *best, uint64_t *red) {
+    const float *__restrict__ mid = a.mid, *__restrict__ pos = a.pos, *__restrict__ qt = a.qt;
+    const int32_t *__restrict__ edges = a.edges, *__restrict__ eids = a.eids;
+    const int LD = a.LD, D = a.D, QS = a.QS;
+    const int64_t e_lo = a.e_lo, M = a.M, mem_stride = a.mem_stride, stride = a.stride;
+    constexpr int NPT = 8;
     for (int d = threadIdx.x; d < LD; d += blockDim.x) qs[d] = d < D ? qt[qi * QS + d] : 0.0f;
     for (int i = threadIdx.x; i < K; i += blockDim.x) best[i] = GH_KEY_INF;
     __syncthreads();
@@ -254,9 +259,23 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(
             block_extract_smallest<NPT + 1>(keys, K, best, red);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void knn_block_select_kernel(search_args a, int K,
+                                                               const int32_t *__restrict__ only_flagged,
+                                                               uint64_t *__restrict__ out_keys /* (S, K) or null */,
+                                                               float *__restrict__ tau_out /* qt + tau offset, or null */,
+                                                               inter_args ia) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
+    const int64_t qi = blockIdx.x;
+    if (only_flagged && only_flagged[qi] == 0) return;
+    block_search_query(a, qi, K, qs, best, red);
     if (out_keys)
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
-    if (tau_out && threadIdx.x == 0) tau_out[qi * QS] = best[K - 1] != GH_KEY_INF ? gh_key_d2(best[K - 1]) : INFINITY;
+    if (tau_out && threadIdx.x == 0) tau_out[qi * a.QS] = best[K - 1] != GH_KEY_INF ? gh_key_d2(best[K - 1]) : INFINITY;
     if (ia.pos) intersect_query(ia, qi, best);
 }
 
@@ -385,15 +404,14 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
 // upper bound of the true K-th distance, since the K-th order statistic of a subset can only be
 // larger.  Survivors of the running threshold are parked in LDS; the K smallest are extracted
 // only when the buffer could overflow (twice in practice) and at the end.
-template <int LD>
-__global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restrict__ midsub, int64_t M1, int D,
-                                                            float *__restrict__ qt, float *__restrict__ qscan,
-                                                            int QS, int QT, int K) {
-    constexpr int BUF = 4096, NPT = BUF / 256;
-    constexpr int RPT = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;  // rows per thread per pass (2048 / 1024 / 512 rows)
+template <int LD, int NT, int RPT /* rows per thread per pass */>
+__global__ __launch_bounds__(NT) void knn_threshold_kernel(const float *__restrict__ midsub, int64_t M1, int D,
+                                                           float *__restrict__ qt, float *__restrict__ qscan,
+                                                           int QS, int QT, int K) {
+    constexpr int BUF = 4096, NPT = BUF / NT;
     __shared__ uint64_t buf[BUF];
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
-    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[(NT / 64) * GH_EXTRACT_MAX_K];
     __shared__ int cnt;
     __shared__ float qs[LD];
     const int64_t qi = blockIdx.x;
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
     float tau = INFINITY;
 
     auto cut = [&](int c) {  // keep the K smallest of buf[0..c), tighten tau
-        block_extract_adaptive<NPT>(buf, c, K, best, red);
+        block_extract_adaptive<NPT, NT>(buf, c, K, best, red);
         if (threadIdx.x < K) buf[threadIdx.x] = best[threadIdx.x];
         if (threadIdx.x == 0) cnt = c < K ? c : K;
         tau = c >= K ? gh_key_d2(best[K - 1]) : INFINITY;
@@ -415,7 +433,7 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
 
     // pass 0: the first 2048 rows all survive (tau = inf) and establish the threshold
     const int64_t head = M1 < 2048 ? M1 : 2048;
-    for (int64_t r = threadIdx.x; r < head; r += 256) {
+    for (int64_t r = threadIdx.x; r < head; r += NT) {
         float mv[LD];
         gh_load_row<LD>(midsub, r, mv);
         float s = 0.0f;
@@ -424,19 +442,19 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
             const float t = q[d] - mv[d];
             s = fmaf(t, t, s);
         }
-        buf[atomicAdd(&cnt, 1)] = gh_key(s, (uint32_t)r);
+        buf[r] = gh_key(s, (uint32_t)r);
     }
     __syncthreads();
-    cut(cnt);
+    cut((int)head);
     // later passes: RPT rows per thread, the NEXT pass's loads are issued before this pass is
     // processed so the L2 latency overlaps the compute; survivors are rare
     float nxt[RPT][LD];
 #pragma unroll
     for (int j = 0; j < RPT; ++j) {
-        const int64_t r = head + j * 256 + threadIdx.x;
+        const int64_t r = head + j * NT + threadIdx.x;
         gh_load_row<LD>(midsub, r < M1 ? r : 0, nxt[j]);
     }
-    for (int64_t base = head; base < M1; base += 256 * RPT) {
+    for (int64_t base = head; base < M1; base += NT * RPT) {
         float mv[RPT][LD];
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
@@ -445,12 +463,12 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const int64_t r = base + 256 * RPT + j * 256 + threadIdx.x;
+            const int64_t r = base + NT * RPT + j * NT + threadIdx.x;
             gh_load_row<LD>(midsub, r < M1 ? r : 0, nxt[j]);
         }
 #pragma unroll
         for (int j = 0; j < RPT; ++j) {
-            const int64_t r = base + j * 256 + threadIdx.x;
+            const int64_t r = base + j * NT + threadIdx.x;
             float s = 0.0f;
 #pragma unroll
             for (int d = 0; d < LD; ++d) {
@@ -481,12 +499,17 @@ __global__ __launch_bounds__(256) void knn_threshold_kernel(const float *__restr
     }
 }
 
-// One workgroup per query: K smallest of the candidate list; final -> K best keys, else tighten tau.
+// One workgroup per query: K smallest of the candidate list; final -> K best keys (and the
+// intersection phase of the query when ia is set), else tighten tau.  A final list that overflowed
+// is not trustworthy: that query is searched exactly over all own edges right here (fb), which is
+// rare (thousands of edges within tau: tied distances) and slow, but needs no further launch.
 __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ cand, int32_t *__restrict__ cnt,
                                                          int K, int final_level, float *__restrict__ tau, int QS,
                                                          uint64_t *__restrict__ out_keys,
                                                          int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
-                                                         inter_args ia) {
+                                                         search_args fb, inter_args ia) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats (exact search only)
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
     constexpr int NPT = GH_CAND_CAP / 256;
@@ -495,14 +518,15 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; }
     if (c > GH_CAND_CAP || c < K) {
-        // overflow (or an impossible short list): the list is not trustworthy
-        if (final_level && threadIdx.x == 0) ovf[qi] = 1;
-        return;  // tau keeps its previous (still valid, looser) value
+        if (!final_level) return;  // tau keeps its previous (still valid, looser) value
+        if (threadIdx.x == 0) ovf[qi] = 1;
+        block_search_query(fb, qi, K, qs, best, red);
+    } else {
+        block_extract_adaptive<NPT>(cand + qi * GH_CAND_CAP, c, K, best, red);
     }
-    block_extract_adaptive<NPT>(cand + qi * GH_CAND_CAP, c, K, best, red);
     if (final_level) {
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
-        if (ia.pos) intersect_query(ia, qi, best);  // an overflowed query returned above: the fallback does it
+        if (ia.pos) intersect_query(ia, qi, best);
     } else if (threadIdx.x == 0) {
         tau[qi * QS] = gh_key_d2(best[K - 1]);
     }
@@ -569,6 +593,11 @@ inter_args make_inter_args(gh_engine *h, bool on) {
     return ia;
 }
 
+search_args make_search_args(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, int64_t id_stride) {
+    return search_args{mid, h->d_pos, h->d_edges, h->d_own_eids, h->LD, h->D, h->part.edge_lo, M, mem_stride, id_stride,
+                       h->d_q, gh_qs(h->D, h->LD)};
+}
+
 // with_intersect only takes effect in the extraction kernel (K <= GH_EXTRACT_MAX_K).
 void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, int64_t id_stride,
                          const int32_t *only_flagged, uint64_t *out_keys, bool write_tau, bool with_intersect) {
@@ -576,8 +605,8 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
     float *tau_out = write_tau ? h->d_q + gh_qtau(h->D, h->LD) : nullptr;
     if (h->K <= GH_EXTRACT_MAX_K) {
         knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
-            mid, h->d_pos, h->d_edges, h->d_own_eids, h->LD, h->D, h->part.edge_lo, M,
-            mem_stride, id_stride, h->d_q, QS, h->K, only_flagged, out_keys, tau_out, make_inter_args(h, with_intersect));
+            make_search_args(h, mid, M, mem_stride, id_stride), h->K, only_flagged, out_keys, tau_out,
+            make_inter_args(h, with_intersect));
     } else {
         const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)h->LD;
         knn_block_select_sort_kernel<<<dim3((unsigned)h->S), dim3(256), smem, h->stream>>>(
@@ -609,12 +638,13 @@ int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile) {
     return r;
 }
 
-gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect) {
+// fb_mid: midpoint rows for the exact search of overflowed queries, or null (gather the endpoints).
+gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect, const float *fb_mid) {
     gh_scope t(h, with_intersect ? "knn_select_intersect" : "knn_select");
-    knn_select_kernel<<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(
+    knn_select_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
         h->d_cand, h->d_cnt, h->K, final_level ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), gh_qs(h->D, h->LD),
         h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S,
-        make_inter_args(h, with_intersect));
+        make_search_args(h, fb_mid, h->own_count, 1, 1), make_inter_args(h, with_intersect));
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
@@ -654,26 +684,40 @@ gh_status gh_knn_thresholds(gh_engine *h) {
     const int64_t M1 = (Mtot + st - 1) / st;
     const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
     gh_scope t(h, "knn_threshold");
+    // Threads per query workgroup: one workgroup streams its M1 rows pass by pass and each pass is a
+    // memory round trip, so long subsets want more rows in flight (measured, LD = 4: 49K rows
+    // 39 us with 256 threads, 30 us with 512; 99K rows 61 -> 45 us with 1024); short ones and large
+    // K (more waves = a longer merge in the extraction) stay at 256.
+    int nt = (M1 < 24 * 1024 || h->K > 32) ? 256 : M1 < 64 * 1024 ? 512 : 1024;
+    int rpt = nt == 512 ? -1 : 0;  // 512 threads: half the rows per thread
+    if (const char *e = getenv("GRAPHEM_HIP_THRESH_CFG")) sscanf(e, "%d,%d", &nt, &rpt);  // tuning: "NT,RPT"
+#define GH_THR(LDv, NTv, RPTv)                                                                                       \
+    knn_threshold_kernel<LDv, NTv, RPTv><<<dim3((unsigned)h->S), dim3(NTv), 0, h->stream>>>(h->d_midsub, M1, h->D,    \
+                                                                                           h->d_q, h->d_qscan, QS, QT, h->K)
+#define GH_THR_LD(LDv, R0)                                                                                           \
+    const bool half = rpt == -1 || rpt == R0 / 2;                                                                    \
+    if (nt == 256) { if (half) GH_THR(LDv, 256, R0 / 2); else GH_THR(LDv, 256, R0); }                                \
+    else if (nt == 512) { if (half) GH_THR(LDv, 512, R0 / 2); else GH_THR(LDv, 512, R0); }                           \
+    else { if (half) GH_THR(LDv, 1024, R0 / 2); else GH_THR(LDv, 1024, R0); }
     switch (h->LD) {
-        case 4: knn_threshold_kernel<4><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, h->d_qscan, QS, QT, h->K); break;
-        case 8: knn_threshold_kernel<8><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, h->d_qscan, QS, QT, h->K); break;
-        default: knn_threshold_kernel<16><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(h->d_midsub, M1, h->D, h->d_q, h->d_qscan, QS, QT, h->K); break;
+        case 4: { GH_THR_LD(4, 8) } break;
+        case 8: { GH_THR_LD(8, 4) } break;
+        default: { GH_THR_LD(16, 2) } break;
     }
+#undef GH_THR_LD
+#undef GH_THR
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
 
 // K best keys of every query from its final candidate list; queries whose list overflowed are
-// redone exactly over all own edges (from d_mid when have_mid, else by gathering endpoints).
+// redone exactly over all own edges in the same launch (from d_mid when have_mid, else by
+// gathering endpoints).
 // fuse_intersect (single-rank steps): the same launches also run the intersection phase of each
 // query they finish (h->intersect_done tells the caller).
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect) {
-    const int64_t Mtot = own_edges(h);
     const bool fuse = fuse_intersect && h->K <= GH_EXTRACT_MAX_K;
-    GH_TRY_ST(launch_select(h, true, fuse));
-    gh_scope t(h, "knn_overflow_fallback");
-    launch_block_select(h, have_mid ? h->d_mid : nullptr, Mtot, 1, 1, h->d_ovf, h->d_partial, false, fuse);
-    GH_LAUNCH_CHECK();
+    GH_TRY_ST(launch_select(h, true, fuse, have_mid ? h->d_mid : nullptr));
     h->intersect_done = fuse;
     return GH_OK;
 }
@@ -729,7 +773,7 @@ gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq,
     inter_args none{};
     if (K <= GH_EXTRACT_MAX_K) {
         knn_block_select_kernel<<<dim3((unsigned)nq), dim3(256), sizeof(float) * (size_t)D, stream>>>(
-            d_ref, nullptr, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D, K, nullptr, d_keys, nullptr, none);
+            search_args{d_ref, nullptr, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D}, K, nullptr, d_keys, nullptr, none);
     } else {
         const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)D;
         if (smem > 64 * 1024) { *err = "dimension too large for the point KNN kernel"; return GH_ERR_INVALID; }
