@@ -75,7 +75,7 @@ static gh_status check_handle(gh_engine *h) {
 
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_new, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
-                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_cand, h->d_cnt,
+                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_cand, h->d_cnt,
                     h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -214,7 +214,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     // most TILE owned edges (and at most 1024 rows, 4 per thread).
     std::vector<int32_t> vblock;
     {
-        const int tile = gh_fused_tile(h->LD, h->own_count);
+        const int tile = gh_fused_tile(h);
         const bool dim_ok = D == 2 || D == 3 || D == 4 || D == 8 || D == 16;
         bool ok = h->fused_mid && dim_ok;
         if (ok) {
@@ -263,6 +263,8 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_sampled, S, true);
     GH_A(d_q, S * (size_t)(h->LD + 4), true);
     GH_A(d_qscan, S * (size_t)(h->LD + 4), true);
+    GH_A(d_qA, S * 16, true);
+    GH_A(d_qexact, S + 1, true);
     GH_A(d_cand, S * GH_CAND_CAP, false);
     GH_A(d_cnt, S * GH_CNT_STRIDE, true);
     GH_A(d_ovf, S, true);

@@ -88,6 +88,8 @@ struct gh_engine {
     float *d_iscratch = nullptr;  // (S * k, LD) per-pair scratch of the intersection kernel
     float *d_q = nullptr;         // (S, QS) query records: midpoint coordinates + tau (knn.hip gh_qs)
     float *d_qscan = nullptr;     // (S, QS) pre-filter records (-2q, t) written by the threshold kernel
+    uint16_t *d_qA = nullptr;     // (S, 16) f16 A-operand rows of the MFMA pre-filter (D <= 3), same kernel
+    int32_t *d_qexact = nullptr;  // [0] = count, [1..] = queries outside the f16 range (scanned exactly)
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
     int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line
     int32_t *d_ovf = nullptr;     // (S)
@@ -125,7 +127,7 @@ gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
 gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq, const float *d_ref, int64_t nref,
                                int D, int K, uint64_t *d_keys, std::string *err);
 // fused.hip
-int gh_fused_tile(int LD, int64_t own_edges);              // edges per fused workgroup
+int gh_fused_tile(const gh_engine *h);              // edges per fused workgroup
 gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -> d_keys_cur
 // forces.hip

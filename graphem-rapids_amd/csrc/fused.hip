@@ -26,20 +26,27 @@
 // are resident and their gather / VALU phases interleave better.
 // GRAPHEM_HIP_FUSED_CFG="NT,R" overrides the LD = 4 default for experiments.
 // Small graphs get smaller tiles so that there are still >= ~1000 workgroups for 256 CUs.
-static void fused_cfg(int LD, int64_t own_edges, int *nt, int *r) {
+// The split-f16 MFMA form of the pre-filter is exact and tested, but opt-in (GRAPHEM_HIP_MFMA=1): the
+// fused kernel is bound by the random row gathers of its spring phase (128 us of the 1M-vertex
+// graph's 164 us with the scan switched off; the chip gathers 8M random 16-byte rows of a 16 MB
+// table in 108 us at best, tools/micro/gather_bench.hip), under which the packed-VALU scan already
+// hides; the MFMA form scans in 12 us instead of ~60 but its larger register and LDS footprint
+// (115 VGPRs, 35 KB) lowers the occupancy that the gathers need: 175 us in total against 164 us.
+static bool fused_mfma(int LD, int D) { return LD == 4 && D <= 3 && getenv("GRAPHEM_HIP_MFMA") != nullptr; }
+static void fused_cfg(int LD, int D, int64_t own_edges, int *nt, int *r) {
     *nt = 256;
     *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
     if (LD <= 4 && own_edges < 1500000) *r = 2;
-    if (LD <= 4 && own_edges < 400000) *nt = 128;
+    if (LD <= 4 && own_edges < 400000 && !fused_mfma(LD, D)) *nt = 128;  // the MFMA form needs 256 threads
     const char *e = getenv("GRAPHEM_HIP_FUSED_CFG");
     if (e && LD <= 4) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 128 || a == 256) && (b == 2 || b == 4 || b == 8)) { *nt = a; *r = b; }
     }
 }
-int gh_fused_tile(int LD, int64_t own_edges) {
+int gh_fused_tile(const gh_engine *h) {
     int nt, r;
-    fused_cfg(LD, own_edges, &nt, &r);
+    fused_cfg(h->LD, h->D, h->own_count, &nt, &r);
     return nt * r;
 }
 
@@ -159,20 +166,28 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
 }
 
-// MFMA form of phase B (D <= 3, 256 threads, 1024-edge tiles): each wave owns 256 references of
-// the tile as 16 groups of 16, one float per lane and group (scan_core.h gh_scan_queries_mfma).
-template <int D>
+// MFMA form of phase B (D <= 3, 256 threads, tiles of 256*R edges): the pre-filter of scan_core.h
+// on v_mfma_f32_32x32x16_f16 with split-f16 operands.  Each wave owns 64*R references of the tile
+// as NB = 2R column blocks of 32 whose B operands live in registers for the whole scan; the
+// queries stream past as A operands, 32 per MFMA, read from LDS.  A lane owns one reference column
+// and 16 query rows of every 32x32 result: a min tree over its 16 accumulators and one compare
+// decide whether any of those pairs needs the exact re-check (fp32 fma chain on the fp32 midpoint
+// and query kept in LDS -- bit-identical to the VALU form and to the oracle).
+template <int D, int R>
 __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
     const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
     const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
     float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
-    const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
-    constexpr int LD = 4, TILE = 1024, G = 16;
-    constexpr int HITBUF = TILE * LD * 4 / 16;
-    __shared__ float4 tile[TILE * LD / 4];
-    __shared__ __align__(16) float qT[3 * GH_SCAN_QGROUP];
-    __shared__ __align__(16) float tneg[GH_SCAN_QGROUP];
+    const gh_h8 *__restrict__ qA, const int32_t *__restrict__ qexact, int S, uint64_t *__restrict__ cand,
+    int32_t *__restrict__ cnt) {
+    constexpr int LD = 4, NT = 256, TILE = NT * R, NB = 2 * R, HITBUF = 512;
+    static_assert(D <= 3, "one 16-deep contraction holds three split coordinates");
+    __shared__ float4 tile[TILE];                    // fp32 midpoints of the owned edges (x, y, z, 0)
+    __shared__ gh_h8 qa[GH_SCAN_QGROUP * 2];         // A rows: [query][half]
+    __shared__ float4 qrec[GH_SCAN_QGROUP];          // (q_0, q_1, q_2, tau) for the exact re-check
+    __shared__ uint64_t hkey[HITBUF];
+    __shared__ int hq[HITBUF];
     __shared__ int hcount;
     float *mids = reinterpret_cast<float *>(tile);
 
@@ -181,63 +196,122 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const int nedges = first_edge[v1] - fe0;
     if (threadIdx.x == 0) hcount = 0;
 
-    __shared__ double red[4 * 2 * LD];
+    __shared__ double red[(NT / 64) * 2 * LD];
     {
         double sx[LD], sxx[LD];
-        gh_phase_a<D, LD, 256>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx);
-        gh_block_stats<LD, 256>(sx, sxx, red, blockstats);  // contains the barrier that ends phase A
+        gh_phase_a<D, LD, NT>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx);
+        gh_block_stats<LD, NT>(sx, sxx, red, blockstats);  // contains the barrier that ends phase A
     }
 
-    // B operands: lane (kq = lane>>4, col = lane&15) holds component kq of reference w*256 + g*16 + col
+    // B operands of this wave's NB column blocks; a reference outside the f16 range never passes the
+    // MFMA filter and is scanned exactly by its lane (half 0) below
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int col = lane & 15, kq = lane >> 4;
-    float bq[G];
+    const int col = lane & 31, hsel = lane >> 5;
+    gh_h8 B[NB];
+    uint32_t bad = 0;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int j = w * 256 + g * 16 + col;
-        float v;
-        if (j < nedges) {
-            if (kq < 3) {
-                v = mids[j * LD + kq];
-            } else {
-                float mv[LD];
-                gh_load_row<LD>(mids, j, mv);
-                v = gh_ref_c0<D>(mv, true);
-            }
-        } else {
-            v = kq < 3 ? 0.0f : INFINITY;  // padding slot: F = +inf never passes
-        }
-        bq[g] = v;
+    for (int b = 0; b < NB; ++b) {
+        const int j = w * (64 * R) + b * 32 + col;
+        const float4 mv4 = tile[j < nedges ? j : 0];
+        const float mv[3] = {mv4.x, mv4.y, mv4.z};
+        if (!gh_mf_ref_col(mv, j < nedges, hsel, B[b])) bad |= 1u << b;
     }
-    __syncthreads();  // the tile's LDS becomes the hit buffer
-    uint64_t *hkey = reinterpret_cast<uint64_t *>(tile);
-    int *hq = reinterpret_cast<int *>(hkey + HITBUF);
-    const int nvalid = min(max(nedges - w * 256, 0), 256);
+    if (hsel) bad = 0;
+
+    auto park = [&](int s_lo, int s, int j) {  // exact decision on pair (query s of the group, reference j)
+        const float4 qr = qrec[s];
+        const float4 mv = tile[j];
+        const float q[3] = {qr.x, qr.y, qr.z}, m[3] = {mv.x, mv.y, mv.z};
+        float d2 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float df = q[d] - m[d];
+            d2 = fmaf(df, df, d2);
+        }
+        if (d2 <= qr.w) {
+            const uint32_t id = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
+            const int p = atomicAdd(&hcount, 1);
+            if (p < HITBUF) { hkey[p] = gh_key(d2, id); hq[p] = s_lo + s; }
+            else gh_append_candidate(cand, cnt, s_lo + s, gh_key(d2, id));
+        }
+    };
+
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
-        if (s_lo > 0) __syncthreads();
-        {   // transposed staging: qT[k][q] = -2 q_k, tneg[q] = -t (padding queries: -t = +inf)
-            const int q = threadIdx.x;
-            const float4 rec = q < nq ? reinterpret_cast<const float4 *>(qscan)[s_lo + q]
-                                      : make_float4(0.f, 0.f, 0.f, -INFINITY);
-            qT[q] = rec.x;
-            qT[GH_SCAN_QGROUP + q] = rec.y;
-            qT[2 * GH_SCAN_QGROUP + q] = rec.z;
-            tneg[q] = -rec.w;
+        if (s_lo > 0) __syncthreads();  // the previous group's rows are still being read
+        {
+            const int q = threadIdx.x;  // one query per thread: 32 B of A row, 16 B of exact record
+            if (q < nq) {
+                qa[2 * q] = qA[2 * (s_lo + q)];
+                qa[2 * q + 1] = qA[2 * (s_lo + q) + 1];
+                qrec[q] = reinterpret_cast<const float4 *>(qt)[s_lo + q];
+            } else {  // padding row: never passes
+                const _Float16 z = (_Float16)0.0f;
+                qa[2 * q] = (gh_h8){z, z, z, z, z, z, z, z};
+                qa[2 * q + 1] = (gh_h8){z, z, z, z, (_Float16)GH_MF_NEVER, z, z, z};
+                qrec[q] = make_float4(0.f, 0.f, 0.f, -1.f);
+            }
         }
         __syncthreads();
-        gh_scan_queries_mfma<D, G, HITBUF>(bq, (uint32_t)(fe0 + w * 256), nvalid, qT, tneg, nq, s_lo, qt, hkey, hq,
-                                           &hcount, cand, cnt);
+        const int nqb = (nq + 31) / 32;
+        const gh_f16x zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int qb = 0; qb < nqb; ++qb) {
+            const gh_h8 a = qa[2 * (qb * 32 + col) + hsel];
+            // the MFMA of block b+1 is issued before block b's result is tested: its 32 cycles in the
+            // matrix pipe run under the ~10 VALU instructions of the test
+            gh_f16x f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                gh_f16x fn = zero;
+                if (b + 1 < NB) fn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[b + 1], zero, 0, 0, 0);
+                // any F <= 0 <=> the smallest of the 16 values read as int32 is <= 0 (sign-magnitude
+                // floats order like integers across zero; -0 reads as INT_MIN)
+                int mn = min(__float_as_int(f[0]), __float_as_int(f[1]));
+#pragma unroll
+                for (int i = 2; i < 16; ++i) mn = min(mn, __float_as_int(f[i]));
+                asm volatile("" : "+v"(mn));  // opaque: else the compiler drops the tree for 16 tests + branches
+                if (mn <= 0) {  // rare: result row (i&3) + 8(i>>2) + 4*half, column = this lane's reference
+                    const int j = w * (64 * R) + b * 32 + col;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int s = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
+                        if (f[i] <= 0.0f && s < nq && j < nedges) park(s_lo, s, j);
+                    }
+                }
+                f = fn;
+            }
+        }
+        // outside the f16 range: exact scan of this group's listed queries over the whole tile ...
+        const int nex = qexact[0];
+        for (int x = 0; x < nex; ++x) {
+            const int s = qexact[1 + x] - s_lo;
+            if (s < 0 || s >= nq) continue;
+            for (int j = threadIdx.x; j < nedges; j += NT) park(s_lo, s, j);
+        }
+        // ... and of this lane's out-of-range references against every query of the group
+        if (bad) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (!(bad >> b & 1u)) continue;
+                const int j = w * (64 * R) + b * 32 + col;
+                for (int s = 0; s < nq; ++s) {
+                    const gh_h8 hi = qa[2 * s + 1];
+                    if ((float)hi[4] == GH_MF_NEVER) continue;  // a listed query: the loop above has done this pair
+                    park(s_lo, s, j);
+                }
+            }
+        }
     }
     __syncthreads();
-    gh_flush_hits<HITBUF, 256>(hkey, hq, &hcount, cand, cnt);
+    gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
 }
 
-template <int D>
+template <int D, int R>
 void launch_mfma(gh_engine *h) {
-    spring_scan_mfma_kernel<D><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
-        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
-        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt);
+    spring_scan_mfma_kernel<D, R><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
+        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min,
+        -h->prm.k_attr, h->d_Fs, h->d_new, h->d_blockstats, h->d_q, reinterpret_cast<const gh_h8 *>(h->d_qA),
+        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt);
 }
 
 template <int D, int LD, int R, int NT>
@@ -253,17 +327,17 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
     if (h->n_vblocks == 0) return GH_OK;
     gh_scope t(h, "spring_scan");
     int nt, r;
-    fused_cfg(h->LD, h->own_count, &nt, &r);
+    fused_cfg(h->LD, h->D, h->own_count, &nt, &r);
 #define GH_FUSED_D(NTT, RR)                                   \
     switch (h->D) {                                           \
         case 2: launch<2, 4, RR, NTT>(h); break;              \
         case 3: launch<3, 4, RR, NTT>(h); break;              \
         default: launch<4, 4, RR, NTT>(h); break;             \
     }
-    // The MFMA form of the pre-filter is opt-in: measured 214-225 us against 164 us for the packed
-    // VALU form on the 1M-vertex graph (AGPR read-back, MFMA->VALU latency, 100 VGPRs).
-    if (h->LD == 4 && h->D <= 3 && nt == 256 && r == 4 && !h->d_own_eids && getenv("GRAPHEM_HIP_MFMA")) {
-        if (h->D == 2) launch_mfma<2>(h); else launch_mfma<3>(h);
+    if (fused_mfma(h->LD, h->D) && nt == 256) {
+        if (r == 8) { if (h->D == 2) launch_mfma<2, 8>(h); else launch_mfma<3, 8>(h); }
+        else if (r == 4) { if (h->D == 2) launch_mfma<2, 4>(h); else launch_mfma<3, 4>(h); }
+        else { if (h->D == 2) launch_mfma<2, 2>(h); else launch_mfma<3, 2>(h); }
     } else if (h->LD == 4) {
         if (nt == 256 && r == 8) { GH_FUSED_D(256, 8) }
         else if (nt == 256 && r == 4) { GH_FUSED_D(256, 4) }

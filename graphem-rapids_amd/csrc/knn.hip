@@ -59,9 +59,10 @@ __global__ __launch_bounds__(256) void knn_setup_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ edges, int32_t *__restrict__ sampled, int mode,
     int64_t E, uint64_t seed, uint64_t iter, int64_t S, int D, int LD, float *__restrict__ qt,
     int32_t *__restrict__ cnt, int32_t *__restrict__ ovf, int64_t e_lo, const int32_t *__restrict__ own_eids,
-    int64_t M1, int64_t stride, float *__restrict__ midsub, int32_t *__restrict__ tcount) {
+    int64_t M1, int64_t stride, float *__restrict__ midsub, int32_t *__restrict__ tcount,
+    int32_t *__restrict__ qexact) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t == 0) *tcount = 0;  // the previous iteration's normalise kernel has consumed it
+    if (t == 0) { *tcount = 0; qexact[0] = 0; }  // the previous iteration's normalise kernel has consumed it
     if (t < S) {
         int32_t e32;
         if (mode == 1) { e32 = gh_sample_id(E, seed, iter, t); sampled[t] = e32; }
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
 template <int LD, int NT, int RPT /* rows per thread per pass */>
 __global__ __launch_bounds__(NT) void knn_threshold_kernel(const float *__restrict__ midsub, int64_t M1, int D,
                                                            float *__restrict__ qt, float *__restrict__ qscan,
-                                                           int QS, int QT, int K) {
+                                                           int QS, int QT, int K, _Float16 *__restrict__ qA,
+                                                           int32_t *__restrict__ qexact) {
     constexpr int BUF = 4096, NPT = BUF / NT;
     __shared__ uint64_t buf[BUF];
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
@@ -496,6 +498,11 @@ __global__ __launch_bounds__(NT) void knn_threshold_kernel(const float *__restri
         // + 1e-30: a must-pass value is then strictly negative even when every magnitude is 0 (the
         // MFMA form of the filter tests sign bits)
         qscan[qi * QS + QT] = fmaf(eps, fmaf(2.0f, qn, tau), tau - qn) + 1e-30f;
+        if (qA && D <= 3) {  // operand row of the MFMA form of the filter (scan_core.h)
+            _Float16 row[16];
+            if (!gh_mf_query_row(qs, D, tau, row)) qexact[1 + atomicAdd(&qexact[0], 1)] = (int32_t)qi;
+            for (int k = 0; k < 16; ++k) qA[qi * 16 + k] = row[k];
+        }
     }
 }
 
@@ -664,7 +671,7 @@ bool gh_knn_scan_path(const gh_engine *h) {
 gh_status gh_knn_prepare(gh_engine *h) {
     const int64_t Mtot = own_edges(h);
     const bool scan = gh_knn_scan_path(h);
-    const int64_t st = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h->LD, Mtot)) : 1;
+    const int64_t st = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h)) : 1;
     const int64_t M1 = scan ? (Mtot + st - 1) / st : 0;
     const int mode = h->sample_pending ? h->sample_mode : 0;
     h->sample_pending = false;
@@ -672,7 +679,7 @@ gh_status gh_knn_prepare(gh_engine *h) {
     const int64_t threads = h->S + M1 * h->LD;
     knn_setup_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_edges, h->d_sampled_cur, mode, h->E, h->prm.seed, h->iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
-        h->d_ovf, h->part.edge_lo, h->d_own_eids, M1, st, h->d_midsub, h->d_tcount);
+        h->d_ovf, h->part.edge_lo, h->d_own_eids, M1, st, h->d_midsub, h->d_tcount, h->d_qexact);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
@@ -680,7 +687,7 @@ gh_status gh_knn_prepare(gh_engine *h) {
 // tau of every query from the compact subset (gh_knn_prepare made it).  Needs gh_knn_scan_path(h).
 gh_status gh_knn_thresholds(gh_engine *h) {
     const int64_t Mtot = own_edges(h);
-    const int64_t st = subset_stride(Mtot, h->K, h->S, gh_fused_tile(h->LD, Mtot));
+    const int64_t st = subset_stride(Mtot, h->K, h->S, gh_fused_tile(h));
     const int64_t M1 = (Mtot + st - 1) / st;
     const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
     gh_scope t(h, "knn_threshold");
@@ -693,7 +700,8 @@ gh_status gh_knn_thresholds(gh_engine *h) {
     if (const char *e = getenv("GRAPHEM_HIP_THRESH_CFG")) sscanf(e, "%d,%d", &nt, &rpt);  // tuning: "NT,RPT"
 #define GH_THR(LDv, NTv, RPTv)                                                                                       \
     knn_threshold_kernel<LDv, NTv, RPTv><<<dim3((unsigned)h->S), dim3(NTv), 0, h->stream>>>(h->d_midsub, M1, h->D,    \
-                                                                                           h->d_q, h->d_qscan, QS, QT, h->K)
+                                                                                           h->d_q, h->d_qscan, QS, QT, h->K,           \
+        reinterpret_cast<_Float16 *>(h->d_qA), h->d_qexact)
 #define GH_THR_LD(LDv, R0)                                                                                           \
     const bool half = rpt == -1 || rpt == R0 / 2;                                                                    \
     if (nt == 256) { if (half) GH_THR(LDv, 256, R0 / 2); else GH_THR(LDv, 256, R0); }                                \

@@ -125,81 +125,101 @@ __device__ __forceinline__ void gh_flush_hits(const uint64_t *hkey, const int *h
 }
 
 // ---------------------------------------------------------------------------------
-// The same pre-filter on the matrix pipe (D <= 3).  For a group of 16 queries and 16 references
-//     F[q][r] = (-t_q) + sum_k A[q][k] * B[k][r],   A[q] = (-2q_x, -2q_y, -2q_z, 1),
-//                                                    B[.][r] = (m_x, m_y, m_z, c0_r)
-// is one v_mfma_f32_16x16x4_f32 with C = -t: a (16 x 4) x (4 x 16) GEMM tile, and a reference can
-// only be a candidate of a query if F <= 0.  fp32 MFMA is an exact k-ordered fma chain, so the
-// error margin built into t and c0 (gh_filter_eps) covers it.  256 pairs cost 32 cycles of the
-// MFMA pipe plus 3 VALU instructions (min3, min, compare), against 12 packed VALU instructions:
-// the VALU is left to the spring math of the co-resident workgroups.
-// Layout (guide: A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15], D lane l reg i =
-// D[(l>>4)*4+i][l&15]): each wave owns G groups of 16 references, one float per lane and group
-// (bq[g] = component l>>4 of reference l&15 of group g); queries are staged transposed in LDS
-// (qT[k][q], tneg[q]).  Hits are re-derived exactly as in gh_scan_queries.
-typedef float gh_f4 __attribute__((ext_vector_type(4)));
+// The same conservative pre-filter on the matrix pipe (D <= 3): f16 MFMA on SPLIT operands.
+//
+// For 32 queries x 32 references one v_mfma_f32_32x32x16_f16 evaluates
+//     F[s][j] = C0_j - 2 q_s . m_j - T_s          (candidate only if F <= 0)
+// with every fp32 input carried as a sum of f16 pieces, x = x_h + x_l (+ x_m), so that the 16
+// products of the contraction are EXACT in the fp32 accumulator (11 x 11 significand bits):
+//     k = 3d+0, 3d+1, 3d+2 (d = 0..2):  a_h*m_h, a_h*m_l, a_l*m_h      a = -2 q_d, m = m_d
+//     k = 9..11:   1 * (C0_h, C0_m, C0_l)        C0 = |m|^2 (1 - eps)
+//     k = 12..14:  (-T_h, -T_m, -T_l) * 1        T  = tau - |q|^2 + eps (|q|^2 + tau) + 2^-20
+//     k = 15:      0
+// What is lost: the a_l*m_l terms and the residues of the two-piece splits (<= 3 * 2^-22 |a||m| per
+// coordinate, or 2^-25 absolute when a low piece is a f16 subnormal) and the roundings of the 16
+// accumulations (<= 2^-20 (C0 + 2|q||m| + |T|)); together below 2^-18 (|q|^2 + |m|^2 + tau) + 2^-21.
+// eps = 2^-17 on both sides plus the absolute 2^-20 is twice that, and also covers the rounding of
+// the exact fma-chain distance the decision is finally taken on (gh_scan_queries' rare path, the
+// same here).  f16 range: pieces stay finite for |coordinate| <= GH_MF_RANGE and tau <= GH_MF_TAU_MAX
+// (C0 <= 3 * 64^2, |T| < 65504); anything outside is marked "never passes" (GH_MF_NEVER in the C0 or
+// -T slot, > any other term) and handled exactly by the caller: queries through the list qexact,
+// references by the lane that owns them.
+// Cost: 32 cycles of the matrix pipe + ~10 VALU instructions (min tree over the 16 accumulators,
+// compare, branch) per 1024 pairs, against 5 packed VALU instructions per 4 pairs per lane above.
+typedef _Float16 gh_h8 __attribute__((ext_vector_type(8)));
+typedef float gh_f16x __attribute__((ext_vector_type(16)));
+#define GH_MF_RANGE 64.0f
+#define GH_MF_TAU_MAX 49000.0f
+#define GH_MF_NEVER 60000.0f
+#define GH_MF_EPS 7.62939453125e-06f   /* 2^-17 */
+#define GH_MF_ABS 9.5367431640625e-07f /* 2^-20 */
 
-template <int D, int G, int HITBUF>
-__device__ __forceinline__ void gh_scan_queries_mfma(const float (&bq)[G], uint32_t id0 /* id of ref (group 0, col 0) */,
-                                                     int nvalid /* valid refs of this wave */, const float *qT,
-                                                     const float *tneg, int nq, int s_lo,
-                                                     const float *__restrict__ qt, uint64_t *hkey, int *hq,
-                                                     int *hcount, uint64_t *__restrict__ cand,
-                                                     int32_t *__restrict__ cnt) {
-    static_assert(D <= 3, "one K=4 MFMA per tile");
-    static_assert(G % 8 == 0, "eight MFMAs are kept in flight");
-    constexpr int QS = 4, QT = 3;
-    const int lane = threadIdx.x & 63;
-    const int col = lane & 15, kq = lane >> 4;
-    const int ngroups = (nq + 15) >> 4;
-    for (int qg = 0; qg < ngroups; ++qg) {
-        // A operand: component kq of query qg*16 + col (k = 3 is the constant 1)
-        const float a = kq < 3 ? qT[kq * GH_SCAN_QGROUP + qg * 16 + col] : 1.0f;
-        // C operand: -t of the four queries this lane's accumulator rows belong to
-        const float4 tn = *reinterpret_cast<const float4 *>(tneg + qg * 16 + kq * 4);
-        const gh_f4 c = {tn.x, tn.y, tn.z, tn.w};
-#pragma unroll
-        for (int g0 = 0; g0 < G; g0 += 8) {
-            gh_f4 acc[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[g0 + u], c, 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                // F <= 0 somewhere  <=>  some sign bit set (t carries a +1e-30 bias, so a passing
-                // F is never +0): one v_or3, one v_or, one integer compare per 256 pairs
-                const int bits = __float_as_int(acc[u].x) | __float_as_int(acc[u].y) | __float_as_int(acc[u].z) |
-                                 __float_as_int(acc[u].w);
-                if (__builtin_amdgcn_ballot_w64(bits < 0) != 0) {  // rare, wave-uniform
-                    const int g = g0 + u;
-                    // exact coordinates of this lane's reference: components live in lanes col, 16+col, 32+col
-                    float mref[3];
-#pragma unroll
-                    for (int d = 0; d < 3; ++d) mref[d] = __shfl(bq[g], d * 16 + col, GH_WAVE);
-                    const int jref = g * 16 + col;
-                    if (bits < 0 && jref < nvalid) {
-                        const float av[4] = {acc[u].x, acc[u].y, acc[u].z, acc[u].w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int ql = qg * 16 + kq * 4 + i;
-                            if (__float_as_int(av[i]) < 0 && ql < nq) {
-                                const int sg = s_lo + ql;
-                                float d2 = 0.0f;
-#pragma unroll
-                                for (int d = 0; d < D; ++d) {
-                                    const float df = qt[(int64_t)sg * QS + d] - mref[d];
-                                    d2 = fmaf(df, df, d2);
-                                }
-                                if (d2 <= qt[(int64_t)sg * QS + QT]) {
-                                    const int p = atomicAdd(hcount, 1);
-                                    const uint64_t key = gh_key(d2, id0 + (uint32_t)jref);
-                                    if (p < HITBUF) { hkey[p] = key; hq[p] = sg; }
-                                    else gh_append_candidate(cand, cnt, sg, key);
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-        }
+__device__ __forceinline__ void gh_split2(float x, _Float16 &h, _Float16 &l) {
+    h = (_Float16)x;
+    l = (_Float16)(x - (float)h);
+}
+__device__ __forceinline__ void gh_split3(float x, _Float16 &h, _Float16 &m, _Float16 &l) {
+    h = (_Float16)x;
+    const float r = x - (float)h;
+    m = (_Float16)r;
+    l = (_Float16)(r - (float)m);
+}
+
+// A-operand row of one query (16 halfs; lanes 0-31 of a wave read elements 0..7, lanes 32-63
+// elements 8..15).  q: D <= 3 coordinates (missing ones 0).  Returns false (and a never-pass row)
+// when the query is outside the f16 range: the caller must put it on the exact list.
+__device__ __forceinline__ bool gh_mf_query_row(const float *q, int D, float tau, _Float16 *row) {
+    bool ok = tau <= GH_MF_TAU_MAX;  // false for inf / NaN too
+    float qn = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        ok = ok && fabsf(q[d]) <= GH_MF_RANGE;
+        qn = fmaf(q[d], q[d], qn);
     }
+    for (int k = 0; k < 16; ++k) row[k] = (_Float16)0.0f;
+    if (!ok) {
+        row[12] = (_Float16)GH_MF_NEVER;
+        return false;
+    }
+    for (int d = 0; d < D; ++d) {
+        _Float16 h, l;
+        gh_split2(-2.0f * q[d], h, l);
+        row[3 * d] = h; row[3 * d + 1] = h; row[3 * d + 2] = l;
+    }
+    row[9] = row[10] = row[11] = (_Float16)1.0f;
+    const float T = (tau - qn) + (GH_MF_EPS * (qn + tau) + GH_MF_ABS);
+    gh_split3(-T, row[12], row[13], row[14]);
+    return true;
+}
+
+// B-operand column of one reference: the 8 halfs of lane half hsel (0: k = 0..7, 1: k = 8..15).
+// mv = (m_0, m_1, m_2, ...) with missing coordinates 0.  valid = false: padding slot (never
+// passes).  Returns false for a real reference outside the f16 range (never passes here; the
+// caller scans it exactly).
+__device__ __forceinline__ bool gh_mf_ref_col(const float *mv, bool valid, int hsel, gh_h8 &col) {
+    const bool ok = fabsf(mv[0]) <= GH_MF_RANGE && fabsf(mv[1]) <= GH_MF_RANGE && fabsf(mv[2]) <= GH_MF_RANGE;
+    const _Float16 z = (_Float16)0.0f;
+    if (!valid || !ok) {
+        // k = 9 (C0_h) = NEVER beats every in-range -T; k = 12..14 stay 1 so that a never-pass
+        // query row (NEVER in its -T_h slot) still yields NEVER, not 0
+        const _Float16 one = (_Float16)1.0f;
+        col = hsel ? (gh_h8){z, (_Float16)GH_MF_NEVER, z, z, one, one, one, z} : (gh_h8){z, z, z, z, z, z, z, z};
+        return !valid;
+    }
+    _Float16 h0, l0, h1, l1, h2, l2;
+    gh_split2(mv[0], h0, l0);
+    gh_split2(mv[1], h1, l1);
+    gh_split2(mv[2], h2, l2);
+    if (hsel == 0) {
+        col = (gh_h8){h0, l0, h0, h1, l1, h1, h2, l2};
+    } else {
+        float c0 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) c0 = fmaf(mv[d], mv[d], c0);
+        c0 = fmaf(-GH_MF_EPS, c0, c0);
+        _Float16 ch, cm, cl;
+        gh_split3(c0, ch, cm, cl);
+        const _Float16 one = (_Float16)1.0f;
+        col = (gh_h8){h2, ch, cm, cl, one, one, one, z};
+    }
+    return true;
 }

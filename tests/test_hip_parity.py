@@ -440,3 +440,56 @@ def test_full_size_rr_1m_bench_workload():
     assert np.isfinite(o64).all() and np.abs(o64.mean(0)).max() < 1e-5
     np.testing.assert_allclose(o64.std(0, ddof=1), 1.0, atol=1e-4)
     eng.close()
+
+
+def _fused_step_keys(n, D, edges, pos, sampled, k):
+    """Keys (dist2 bits << 32 | edge id) of the KNN phase as the fused spring+scan step computes them."""
+    from graphem_rapids_amd.distributed import HipShardEngine
+    sh = HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, len(sampled), 0, (0, n, 0, len(edges), 0), 0)
+    sh.set_positions(pos)
+    sh.step_begin(sampled)
+    sh.sync()
+    keys = sh.partial.cpu().numpy().copy()
+    sh.eng.close()
+    return keys
+
+
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+@pytest.mark.parametrize("n,D,deg,outliers", [
+    (50000, 3, 8, "none"),       # tiles of 512 edges
+    (400000, 3, 8, "none"),      # tiles of 1024 edges
+    (50000, 2, 8, "none"),
+    (50000, 3, 8, "some"),       # 1% of the vertices far outside the f16 range of the MFMA filter
+    (5000, 3, 8, "all"),         # every coordinate outside it: exact scans only
+    (50000, 3, 8, "tiny"),       # coordinates ~1e-4: distances near the absolute slack of the filter
+])
+def test_fused_scan_knn_is_exact(form, n, D, deg, outliers, monkeypatch):
+    """KNN of the fused spring+scan kernel (read back after gh_step_begin) against the oracle, for
+    both forms of its pre-filter: packed fp32 VALU (default) and split-f16 MFMA (GRAPHEM_HIP_MFMA=1).  The
+    filter is conservative and the decision exact, so ids AND distance bits must be identical."""
+    if form == "mfma":
+        monkeypatch.setenv("GRAPHEM_HIP_MFMA", "1")
+    else:
+        monkeypatch.delenv("GRAPHEM_HIP_MFMA", raising=False)
+    k, S = 10, 256
+    edges, pos, sampled = _random_case(n, D, deg, k, S, seed=101)
+    rng = np.random.default_rng(7)
+    if outliers == "some":
+        far = rng.permutation(n)[: n // 100]
+        pos[far] *= np.float32(300.0)
+        sampled[:8] = np.nonzero(np.isin(edges[:, 0], far))[0][:8]   # out-of-range queries too
+    elif outliers == "all":
+        pos *= np.float32(1000.0)
+    elif outliers == "tiny":
+        pos *= np.float32(1e-4)
+    keys = _fused_step_keys(n, D, edges, pos, sampled, k)
+    ids = (keys & 0xFFFFFFFF).astype(np.int32)
+    ref = oracle.knn_midpoints(pos, edges, sampled, k)
+    assert np.array_equal(ids[:, 1:], ref)
+    mid = oracle.midpoints(pos, edges)
+    d2 = (keys >> 32).astype(np.uint32).view(np.float32)
+    diff = mid[sampled][:, None, :] - mid[ids]
+    want = np.zeros(ids.shape, np.float32)
+    for d in range(D):   # fma chain in coordinate order; products of fp32 are exact in fp64
+        want = (diff[..., d].astype(np.float64) ** 2 + want.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(d2, want)
