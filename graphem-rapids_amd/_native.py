@@ -21,13 +21,18 @@ SYMBOLS = [
     "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
     "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts", "gh_set_stream",
     "gh_positions_rows_allocated", "gh_knn_points", "gh_stats_rows", "gh_spmv_symnorm",
-    "gh_spectral_last_error",
+    "gh_spectral_last_error", "gh_gather_layout", "gh_gather_buffer_device", "gh_gather_slot_bytes",
+    "gh_step_finish_gathered", "gh_vertex_order", "gh_positions_unpadded_device",
 ]
 
 
 class GhParams(ctypes.Structure):
     _fields_ = [("L_min", ctypes.c_float), ("k_attr", ctypes.c_float), ("k_inter", ctypes.c_float),
-                ("n_neighbors", ctypes.c_int32), ("sample_size", ctypes.c_int32), ("seed", ctypes.c_uint64)]
+                ("n_neighbors", ctypes.c_int32), ("sample_size", ctypes.c_int32), ("seed", ctypes.c_uint64),
+                ("reorder", ctypes.c_int32)]
+
+
+REORDER = {"auto": 0, "off": 1, "bfs": 2}  # gh_params.reorder (include/graphem_hip.h GH_REORDER_*)
 
 
 class GhPartition(ctypes.Structure):
@@ -68,7 +73,17 @@ def load():
     L.gh_row_stride.restype = i32
     L.gh_run.argtypes = [vp, i32, vp]
     L.gh_run.restype = ctypes.c_int
-    for name in ("gh_sync", "gh_step_finish", "gh_timing_reset"):
+    L.gh_vertex_order.argtypes = [vp, vp]
+    L.gh_vertex_order.restype = ctypes.c_int
+    L.gh_positions_unpadded_device.argtypes = [vp]
+    L.gh_positions_unpadded_device.restype = vp
+    L.gh_gather_layout.argtypes = [vp, i32, i32, i64]
+    L.gh_gather_layout.restype = ctypes.c_int
+    L.gh_gather_buffer_device.argtypes = [vp]
+    L.gh_gather_buffer_device.restype = vp
+    L.gh_gather_slot_bytes.argtypes = [vp]
+    L.gh_gather_slot_bytes.restype = i64
+    for name in ("gh_sync", "gh_step_finish", "gh_step_finish_gathered", "gh_timing_reset"):
         getattr(L, name).argtypes = [vp]
         getattr(L, name).restype = ctypes.c_int
     L.gh_knn_midpoints.argtypes = [vp, vp, vp]
@@ -133,14 +148,14 @@ class Engine:
     """Thin RAII wrapper over a gh_handle."""
 
     def __init__(self, n, D, edges, L_min, k_attr, k_inter, n_neighbors, sample_size, seed=0, device_id=0,
-                 partition=None):
+                 partition=None, reorder="auto"):
         self.lib = load()
         self.handle = ctypes.c_void_p()
         self.n, self.D = int(n), int(D)
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
         self.E = edges.shape[0]
         prm = GhParams(float(L_min), float(k_attr), float(k_inter), int(n_neighbors), int(sample_size),
-                       int(seed) & 0xFFFFFFFFFFFFFFFF)
+                       int(seed) & 0xFFFFFFFFFFFFFFFF, REORDER[reorder])
         part = None
         if partition is not None:
             vals = [int(x) for x in partition]  # (row_lo, row_hi, edge_lo, edge_hi[, edge_rule])
@@ -251,6 +266,30 @@ class Engine:
 
     def stats_rows(self):
         return int(self.lib.gh_stats_rows(self.handle))
+
+    def vertex_order(self):
+        """order[v] = row of vertex v in the device position array."""
+        out = np.empty(self.n, dtype=np.int32)
+        self._chk(self.lib.gh_vertex_order(self.handle, ptr(out)))
+        return out
+
+    def positions_unpadded_device_ptr(self):
+        p = self.lib.gh_positions_unpadded_device(self.handle)
+        if not p:
+            raise RuntimeError("gh_positions_unpadded_device failed")
+        return p
+
+    def gather_layout(self, world, rank, chunk):
+        self._chk(self.lib.gh_gather_layout(self.handle, int(world), int(rank), int(chunk)))
+
+    def gather_buffer_device_ptr(self):
+        return self.lib.gh_gather_buffer_device(self.handle)
+
+    def gather_slot_bytes(self):
+        return int(self.lib.gh_gather_slot_bytes(self.handle))
+
+    def step_finish_gathered(self):
+        self._chk(self.lib.gh_step_finish_gathered(self.handle))
 
     def positions_device_ptr(self):
         return self.lib.gh_positions_device(self.handle)

@@ -74,9 +74,9 @@ static gh_status check_handle(gh_engine *h) {
 }
 
 static void free_all(gh_engine *h) {
-    void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_new, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
-                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_stats, h->d_iscratch, h->d_stream_ids};
+    void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
+                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_cand, h->d_cnt,
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -129,6 +129,49 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     h->stream = h->own_stream;
     h->pos_rows = n + GH_POS_PAD_ROWS;
     h->force_unfused = getenv("GRAPHEM_HIP_UNFUSED") != nullptr;  // A/B switch for profiling and tests
+
+    // Internal vertex order (include/graphem_hip.h GH_REORDER_*): breadth-first numbers, components in
+    // order of their smallest vertex, children in pull-list (= edge id) order.
+    {
+        const bool l2_miss = (double)n * h->LD * sizeof(float) > 3.0 * 1024 * 1024;
+        const bool hashed_ok = !part || part->edge_rule == GH_EDGES_HASHED;
+        int mode = params->reorder;
+        if (const char *e = getenv("GRAPHEM_HIP_REORDER")) mode = atoi(e);  // tests / A-B runs: 1 off, 2 BFS
+        const bool reorder = hashed_ok && E > 0 && (mode == GH_REORDER_BFS || (mode == GH_REORDER_AUTO && l2_miss));
+        if (reorder) {
+            std::vector<int64_t> off((size_t)n + 1, 0);
+            for (int64_t e = 0; e < E; ++e) { off[(size_t)edges[2 * e] + 1]++; off[(size_t)edges[2 * e + 1] + 1]++; }
+            for (int64_t i = 0; i < n; ++i) off[(size_t)i + 1] += off[(size_t)i];
+            std::vector<int32_t> nb((size_t)off[(size_t)n]);
+            {
+                std::vector<int64_t> cur(off.begin(), off.end() - 1);
+                for (int64_t e = 0; e < E; ++e) {
+                    const int32_t u = edges[2 * e], v = edges[2 * e + 1];
+                    nb[(size_t)cur[(size_t)u]++] = v;
+                    nb[(size_t)cur[(size_t)v]++] = u;
+                }
+            }
+            h->order_host.assign((size_t)n, -1);
+            std::vector<int32_t> queue((size_t)n);
+            int64_t head = 0, tail = 0, next = 0;
+            for (int64_t root = 0; root < n; ++root) {
+                if (h->order_host[(size_t)root] >= 0) continue;
+                h->order_host[(size_t)root] = (int32_t)next++;
+                queue[(size_t)tail++] = (int32_t)root;
+                while (head < tail) {
+                    const int32_t x = queue[(size_t)head++];
+                    for (int64_t j = off[(size_t)x]; j < off[(size_t)x + 1]; ++j) {
+                        const int32_t y = nb[(size_t)j];
+                        if (h->order_host[(size_t)y] < 0) { h->order_host[(size_t)y] = (int32_t)next++; queue[(size_t)tail++] = y; }
+                    }
+                }
+            }
+            h->edges_internal.resize((size_t)E * 2);
+            for (int64_t i = 0; i < 2 * E; ++i) h->edges_internal[(size_t)i] = h->order_host[(size_t)edges[i]];
+            edges = h->edges_internal.data();  // everything below works on internal vertex numbers
+            if (!part) h->part = gh_partition{0, n, 0, 0, GH_EDGES_HASHED};
+        }
+    }
 
     // Pull lists of the own rows in the reference's summation order (pt.py:633-634):
     // first the edges where the vertex is endpoint 0, then those where it is endpoint 1,
@@ -290,6 +333,15 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         h->err = "upload of the graph failed";
         return bail(GH_ERR_HIP);
     }
+    if (!h->order_host.empty()) {
+        st = dev_alloc(h, &h->d_order, (size_t)n, false);
+        if (st != GH_OK) return bail(st);
+        if (hipMemcpy(h->d_order, h->order_host.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess) {
+            h->err = "upload of the vertex order failed";
+            return bail(GH_ERR_HIP);
+        }
+    }
+    std::vector<int32_t>().swap(h->edges_internal);
     *out = h;
     return GH_OK;
 }
@@ -329,6 +381,18 @@ extern "C" gh_status gh_get_positions(gh_handle h, float *pos) {
 }
 
 extern "C" float *gh_positions_device(gh_handle h) { return h ? h->d_pos : nullptr; }
+extern "C" gh_status gh_vertex_order(gh_handle h, int32_t *order) {
+    GH_TRY(check_handle(h));
+    if (!order) { h->err = "order is NULL"; return GH_ERR_INVALID; }
+    for (int64_t i = 0; i < h->n; ++i) order[i] = h->order_host.empty() ? (int32_t)i : h->order_host[(size_t)i];
+    return GH_OK;
+}
+extern "C" const float *gh_positions_unpadded_device(gh_handle h) {
+    if (!h || hipSetDevice(h->device) != hipSuccess) return nullptr;
+    if (gh_launch_unpad(h, h->d_pos, h->d_io) != GH_OK) return nullptr;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return nullptr;
+    return h->d_io;
+}
 extern "C" int32_t gh_row_stride(gh_handle h) { return h ? h->LD : 0; }
 
 // ---- the loop ----------------------------------------------------------------------
@@ -469,9 +533,39 @@ extern "C" gh_status gh_step_finish(gh_handle h) {
     return step_finish(h);
 }
 
+extern "C" gh_status gh_gather_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk) {
+    GH_TRY(check_handle(h));
+    if (world < 1 || rank < 0 || rank >= world || chunk < 1 || chunk * world < h->n ||
+        h->part.row_lo != std::min<int64_t>(h->n, rank * chunk) || h->part.row_hi != std::min<int64_t>(h->n, (rank + 1) * chunk)) {
+        h->err = "gather layout does not match the engine's row partition";
+        return GH_ERR_INVALID;
+    }
+    if (h->d_gbuf) { h->err = "gather layout already set"; return GH_ERR_INVALID; }
+    const int64_t stats_bytes = (int64_t)sizeof(double) * (2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
+    const int64_t slot = (chunk * h->LD * (int64_t)sizeof(float) + stats_bytes + 15) / 16 * 16;
+    GH_HIP(hipStreamSynchronize(h->stream));
+    GH_TRY(dev_alloc(h, &h->d_gbuf, (size_t)(slot * world), true));
+    h->d_new_own = h->d_new;
+    h->d_stats_own = h->d_stats;
+    h->d_new = reinterpret_cast<float *>(h->d_gbuf + rank * slot);
+    h->d_stats = reinterpret_cast<double *>(h->d_gbuf + rank * slot + chunk * h->LD * (int64_t)sizeof(float));
+    h->g_slot = slot; h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
+    return GH_OK;
+}
+extern "C" void *gh_gather_buffer_device(gh_handle h) { return h ? h->d_gbuf : nullptr; }
+extern "C" int64_t gh_gather_slot_bytes(gh_handle h) { return h ? h->g_slot : 0; }
+extern "C" gh_status gh_step_finish_gathered(gh_handle h) {
+    GH_TRY(check_handle(h));
+    if (!h->d_gbuf) { h->err = "gh_gather_layout has not been called"; return GH_ERR_INVALID; }
+    GH_TRY(gh_launch_normalise_gathered(h));
+    h->iter += 1;
+    return GH_OK;
+}
+
 // ---- per-phase entry points --------------------------------------------------------
 static bool whole_graph(gh_engine *h) {
-    return h->part.row_lo == 0 && h->part.row_hi == h->n && h->part.edge_lo == 0 && h->part.edge_hi == h->E;
+    return h->part.row_lo == 0 && h->part.row_hi == h->n &&
+           (h->part.edge_rule == GH_EDGES_HASHED || (h->part.edge_lo == 0 && h->part.edge_hi == h->E));
 }
 
 extern "C" gh_status gh_spring_forces(gh_handle h, float *F) {

@@ -89,6 +89,14 @@ struct gh_engine {
     float *d_q = nullptr;         // (S, QS) query records: midpoint coordinates + tau (knn.hip gh_qs)
     float *d_qscan = nullptr;     // (S, QS) pre-filter records (-2q, t) written by the threshold kernel
     uint16_t *d_qA = nullptr;     // (S, 16) f16 A-operand rows of the MFMA pre-filter (D <= 3), same kernel
+    int32_t *d_order = nullptr;       // internal row of every vertex (BFS reordering), or null: identity
+    std::vector<int32_t> order_host;  // the same on the host (empty: identity)
+    std::vector<int32_t> edges_internal;  // gh_create scratch: the edge list in internal vertex numbers
+    unsigned char *d_gbuf = nullptr;  // gather buffer of the one-collective finish (gh_gather_layout), or null
+    float *d_new_own = nullptr;       // allocations behind d_new / d_stats while they point into d_gbuf
+    double *d_stats_own = nullptr;
+    int64_t g_slot = 0, g_chunk = 0;  // slot bytes, rows per rank
+    int g_world = 0, g_rank = 0;
     int32_t *d_qexact = nullptr;  // [0] = count, [1..] = queries outside the f16 range (scanned exactly)
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
     int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line
@@ -139,7 +147,8 @@ gh_status gh_launch_integrate(gh_engine *h);               // d_Fs, d_acc -> d_n
 gh_status gh_launch_spring_only(gh_engine *h, float *d_F); // F (n, LD), own rows
 gh_status gh_launch_inter_to_dense(gh_engine *h, float *d_F);
 gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi);
-gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup);  // d_new, d_stats -> d_pos rows (+ zero d_acc)
+gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup);
+gh_status gh_launch_normalise_gathered(gh_engine *h);  // gathered slots of every rank -> all n rows of d_pos
 gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD);
 gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD);
 gh_status gh_launch_sample(gh_engine *h);                  // device sampler -> d_sampled

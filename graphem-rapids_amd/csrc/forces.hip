@@ -266,6 +266,65 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
     }
 }
 
+// The same normalisation for ALL n rows from the gathered slots of every rank (one-collective
+// finish, include/graphem_hip.h): slot r = [chunk rows of new positions | that rank's statistics].
+// The per-rank statistics are added in rank order, so every rank derives the same mean / std.
+__global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned char *__restrict__ gbuf, int64_t slot,
+                                                                int64_t chunk, int world, int D, int LD, int64_t n,
+                                                                int nfix, float *__restrict__ pos,
+                                                                double *__restrict__ acc, int32_t *__restrict__ tflag,
+                                                                const int32_t *__restrict__ touched,
+                                                                const int32_t *__restrict__ tcount) {
+    {
+        const int64_t nt = (int64_t)(*tcount) * LD;
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t x = touched[t / LD];
+            const int d = (int)(t % LD);
+            acc[x * LD + d] = 0.0;
+            if (d == 0) tflag[x] = 0;
+        }
+    }
+    extern __shared__ float ms[];  // mean[LD], std[LD], then world * 2 * LD doubles of per-rank totals
+    double *part = reinterpret_cast<double *>(ms + 2 * LD);
+    // per-rank totals (sum and sum of squares incl. the correction rows), one thread per (rank, entry) ...
+    for (int t = threadIdx.x; t < world * 2 * LD; t += blockDim.x) {
+        const int r = t / (2 * LD), c = t % (2 * LD), base = c / LD, col = c % LD;
+        const double *st = reinterpret_cast<const double *>(gbuf + r * slot + chunk * LD * sizeof(float));
+        double v = st[base * LD + col];
+        for (int b = 0; b < nfix; ++b) v += st[(2 + 2 * b + base) * LD + col];
+        part[t] = v;
+    }
+    __syncthreads();
+    // ... added in rank order
+    for (int d = threadIdx.x; d < LD; d += blockDim.x) {
+        float mean = 0.0f, sd = 1.0f;
+        if (d < D) {
+            double sum = 0.0, sq = 0.0;
+            for (int r = 0; r < world; ++r) {
+                sum += part[r * 2 * LD + d];
+                sq += part[r * 2 * LD + LD + d];
+            }
+            const double m = sum / (double)n;
+            double var = (sq - sum * m) / (double)(n - 1);
+            if (var < 0.0) var = 0.0;
+            mean = (float)m;
+            sd = (float)sqrt(var) + 1e-6f;
+        }
+        ms[d] = mean;
+        ms[LD + d] = sd;
+    }
+    __syncthreads();
+    const int64_t total = n * LD;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / LD;
+        const int d = (int)(t % LD);
+        const int64_t r = i / chunk;
+        const float *rowsrc = reinterpret_cast<const float *>(gbuf + r * slot);
+        const float c = rowsrc[(i - r * chunk) * LD + d] - ms[d];
+        pos[t] = d < D ? c / ms[LD + d] : 0.0f;
+    }
+}
+
 // pt.py:796-799 with given force arrays (per-phase entry point gh_integrate_normalise).
 __global__ __launch_bounds__(256) void integrate_given_kernel(const float *__restrict__ pos,
                                                              const float *__restrict__ Fs,
@@ -325,19 +384,25 @@ __global__ void reset_counter_kernel(int32_t *c) { *c = 0; }
 
 // ---------------------------------------------------------------------------------
 // (n, D) <-> (n, LD) copies for the host boundary.
-__global__ void pad_kernel(const float *__restrict__ src, int64_t n, int D, int LD, float *__restrict__ dst) {
+// Vertex arrays cross the API as (n, D) in the caller's vertex order; on the device they are
+// (n, LD) rows in the internal order (order[v] = row of vertex v; null = identity).
+__global__ void pad_kernel(const float *__restrict__ src, int64_t n, int D, int LD, const int32_t *__restrict__ order,
+                           float *__restrict__ dst) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= n * LD) return;
     const int64_t i = t / LD;
     const int d = (int)(t % LD);
-    dst[t] = d < D ? src[i * D + d] : 0.0f;
+    const int64_t row = order ? order[i] : i;
+    dst[row * LD + d] = d < D ? src[i * D + d] : 0.0f;
 }
-__global__ void unpad_kernel(const float *__restrict__ src, int64_t n, int D, int LD, float *__restrict__ dst) {
+__global__ void unpad_kernel(const float *__restrict__ src, int64_t n, int D, int LD, const int32_t *__restrict__ order,
+                             float *__restrict__ dst) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= n * D) return;
     const int64_t i = t / D;
     const int d = (int)(t % D);
-    dst[t] = src[i * LD + d];
+    const int64_t row = order ? order[i] : i;
+    dst[t] = src[row * LD + d];
 }
 
 // ---------------------------------------------------------------------------------
@@ -526,14 +591,26 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup) {
     return GH_OK;
 }
 
+gh_status gh_launch_normalise_gathered(gh_engine *h) {
+    gh_scope t(h, "normalise_gathered");
+    unsigned grid = grid_for(h->n * h->LD, 256);
+    if (grid > 2048) grid = 2048;
+    const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * h->LD * (size_t)h->g_world;
+    normalise_gathered_kernel<<<dim3(grid), dim3(256), smem, h->stream>>>(
+        h->d_gbuf, h->g_slot, h->g_chunk, h->g_world, h->D, h->LD, h->n, gh_fix_blocks(h->LD), h->d_pos, h->d_acc,
+        h->d_tflag, h->d_touched, h->d_tcount);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
 gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD) {
-    pad_kernel<<<dim3(grid_for(h->n * h->LD, 256)), dim3(256), 0, h->stream>>>(d_src_nD, h->n, h->D, h->LD, d_dst_nLD);
+    pad_kernel<<<dim3(grid_for(h->n * h->LD, 256)), dim3(256), 0, h->stream>>>(d_src_nD, h->n, h->D, h->LD, h->d_order, d_dst_nLD);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
 
 gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD) {
-    unpad_kernel<<<dim3(grid_for(h->n * h->D, 256)), dim3(256), 0, h->stream>>>(d_src_nLD, h->n, h->D, h->LD, d_dst_nD);
+    unpad_kernel<<<dim3(grid_for(h->n * h->D, 256)), dim3(256), 0, h->stream>>>(d_src_nLD, h->n, h->D, h->LD, h->d_order, d_dst_nD);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

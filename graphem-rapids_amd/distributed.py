@@ -13,11 +13,15 @@ most of the edges).  Every rank holds all n positions and the whole edge list.  
                       sampled midpoints among the OWN edges -> S x (k+1) keys
     gather  (RCCL)    all-gather of the keys                       S*(k+1)*8 B per rank
     part 2  (local)   merge keys -> global KNN; intersection forces (redundant on every rank,
-                      O(S*k)); integrate own rows; own column sums
-    reduce  (RCCL)    all-reduce of the column statistics (66 x ld doubles: sums, sums of
-                      squares and the correction rows of the touched vertices)
-    part 3  (local)   normalise own rows in the full position array
-    gather  (RCCL)    in-place all-gather of the position row blocks   chunk*ld*4 B per rank
+                      O(S*k)); integrate own rows; own column sums -- rows and sums land side
+                      by side in this rank's slot of the gather buffer
+    gather  (RCCL)    in-place all-gather of the slots    chunk*ld*4 B + 18*ld*8 B per rank
+    part 3  (local)   normalise ALL n rows from the gathered slots; the per-rank column sums are
+                      added in rank order, so every rank derives the same mean / std
+
+Two collectives per iteration: shipping the un-normalised rows together with the statistics
+spares the separate all-reduce (normalising n instead of n/world rows costs a few microseconds,
+a collective tens).
 
 The sample ids are the same on every rank: either passed in, or drawn by the engine's counter
 based sampler from (seed, iteration).  The compute engine is injectable so that the collective
@@ -79,6 +83,18 @@ class HipShardEngine:
         self.pos = device_view(e.positions_device_ptr(), (rows, e.ld), torch.float32, self.device, e)
         self.partial = device_view(e.knn_partial_device_ptr(), (e.S, k + 1), torch.int64, self.device, e)
         self.stats = device_view(e.stats_partial_device_ptr(), (e.stats_rows(), e.ld), torch.float64, self.device, e)
+        self.gbuf = None
+
+    def gather_layout(self, world, rank, chunk):
+        """Places the rank's new rows and statistics in slot `rank` of a (world, slot_bytes) buffer."""
+        from .embedder_hip import device_view
+        e = self.eng
+        e.gather_layout(world, rank, chunk)
+        self.gbuf = device_view(e.gather_buffer_device_ptr(), (world, e.gather_slot_bytes()), torch.uint8, self.device, e)
+        self.stats = device_view(e.stats_partial_device_ptr(), (e.stats_rows(), e.ld), torch.float64, self.device, e)
+
+    def step_finish_gathered(self):
+        self.eng.step_finish_gathered()
 
     def set_positions(self, pos):
         self.eng.set_positions(pos)
@@ -121,8 +137,7 @@ class PartitionedLayout:
         factory = engine_factory or HipShardEngine
         self.engine = factory(self.n, self.D, edges, L_min, k_attr, k_inter, n_neighbors, min(sample_size, len(edges)),
                               seed, part, device_id)
-        if self.chunk * self.world > self.engine.pos.shape[0]:
-            raise ValueError("world size too large for the engine's position padding")
+        self.engine.gather_layout(self.world, self.rank, self.chunk)
         self.K = n_neighbors + 1
         self.S = min(sample_size, len(edges))
         self.gathered = torch.empty((self.world, self.S, self.K), dtype=torch.int64, device=self.engine.pos.device)
@@ -139,12 +154,9 @@ class PartitionedLayout:
         # output in concatenated form (world*S, K): accepted by both the RCCL and the gloo backend
         dist.all_gather_into_tensor(self.gathered.view(self.world * self.S, self.K), e.partial, group=self.group)
         e.step_merge(self.gathered, self.world)
-        dist.all_reduce(e.stats, op=dist.ReduceOp.SUM, group=self.group)
-        e.step_finish()
-        # in-place all-gather: rank r's block sits at rows [r*chunk, (r+1)*chunk) of the output
-        full = e.pos[: self.chunk * self.world]
-        mine = e.pos[self.rank * self.chunk:(self.rank + 1) * self.chunk]
-        dist.all_gather_into_tensor(full, mine, group=self.group)
+        # in-place all-gather of the slots: rank r's new rows + statistics sit in row r of gbuf
+        dist.all_gather_into_tensor(e.gbuf.view(-1), e.gbuf[self.rank], group=self.group)
+        e.step_finish_gathered()
 
     def run(self, iters, sample_stream=None):
         for t in range(iters):

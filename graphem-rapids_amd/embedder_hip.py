@@ -200,10 +200,8 @@ class GraphEmbedderHIP:
     @property
     def _positions(self):
         """Device tensor of the positions (callers and tests read .device / .dtype / values)."""
-        self._engine.sync()
-        full = device_view(self._engine.positions_device_ptr(), (self.n, self._engine.ld), torch.float32,
-                           self.device, self._engine)
-        view = full[:, :self.n_components]
+        view = device_view(self._engine.positions_unpadded_device_ptr(), (self.n, self.n_components), torch.float32,
+                           self.device, self._engine).clone()  # the engine reuses that buffer
         return view if self.dtype == torch.float32 else view.to(self.dtype)
 
     def get_positions(self):

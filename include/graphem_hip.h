@@ -46,7 +46,19 @@ typedef struct {
     int32_t n_neighbors;  /* pt.py:60, k */
     int32_t sample_size;  /* pt.py:61, already min(sample_size, E) as pt.py:156 */
     uint64_t seed;        /* seed of the on-device sampler (used when no sample ids are passed) */
+    int32_t reorder;      /* internal vertex order: GH_REORDER_AUTO / _OFF / _BFS (no reference counterpart) */
 } gh_params;
+
+/* Internal vertex order.  The spring phase gathers the position row of every neighbour; with
+ * breadth-first vertex numbers a vertex sits next to its BFS siblings and close to its parent and
+ * children, so more of those gathers hit the L2.  Purely internal: vertex arrays cross the API in
+ * the caller's order, edge ids are unchanged and every summation keeps the reference's order, so
+ * results do not depend on it.  AUTO = BFS when the position array outgrows an L2 (n * row bytes >
+ * 3 MB) and the partition (if any) uses GH_EDGES_HASHED.  gh_positions_device() exposes the
+ * INTERNAL order; gh_vertex_order() returns the internal row of every vertex. */
+#define GH_REORDER_AUTO 0
+#define GH_REORDER_OFF 1
+#define GH_REORDER_BFS 2
 
 /* Row partition for multi-GPU runs (no reference counterpart).
  * A rank integrates vertices [row_lo, row_hi) and searches the edges it OWNS in the
@@ -84,6 +96,11 @@ gh_status gh_get_positions(gh_handle h, float *pos /* (n, D) host, blocking */);
 /* Device view for callers that keep data on the GPU (RCCL all-gather, torch tensors):
  * (n, ld) float32 rows, ld = gh_row_stride(h) >= D floats, columns >= D are zero. */
 float *gh_positions_device(gh_handle h);
+/* order[v] = row of vertex v in the device position array (identity without reordering). */
+gh_status gh_vertex_order(gh_handle h, int32_t *order);
+/* Device copy of the positions in the CALLER's vertex order, (n, n_components) floats without
+ * padding; valid until the next call on this handle. */
+const float *gh_positions_unpadded_device(gh_handle h);
 int32_t gh_row_stride(gh_handle h);
 
 /* ---- the loop: update_positions / run_layout (pt.py:776-806, 808-833) ------- */
@@ -134,9 +151,21 @@ uint64_t *gh_knn_partial_device(gh_handle h);      /* (S, k+1) uint64 keys, asce
 gh_status gh_step_merge(gh_handle h, const uint64_t *gathered, int32_t world);
 double *gh_stats_partial_device(gh_handle h);      /* (gh_stats_rows, ld) doubles, to be summed elementwise over ranks */
 int32_t gh_stats_rows(gh_handle h);
-/* Part 3: after the caller all-reduced (SUM) the whole statistics buffer: normalise own rows in place in the
- * full position array; the caller then all-gathers the row blocks. */
+/* Part 3, form A: after the caller all-reduced (SUM) the whole statistics buffer: normalise own rows in place in the
+ * full position array; the caller then all-gathers the row blocks (two collectives). */
 gh_status gh_step_finish(gh_handle h);
+
+/* Part 3, form B (ONE collective): the rank's un-normalised new rows and its statistics live side by side in
+ * one slot of a gather buffer; the caller all-gathers the slots in place and every rank then normalises ALL n
+ * rows from the gathered slots, summing the per-rank statistics in rank order (identical on every rank).
+ *   gh_gather_layout(h, world, rank, chunk)  once after gh_create: this rank is `rank` of `world`, rank r owns
+ *                                             rows [r*chunk, min(n, (r+1)*chunk)); allocates the buffer
+ *   gh_gather_buffer_device(h)               world * gh_gather_slot_bytes(h) bytes; slot r belongs to rank r
+ *   gh_step_finish_gathered(h)               after the all-gather: d_pos <- normalised rows of every rank */
+gh_status gh_gather_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk);
+void *gh_gather_buffer_device(gh_handle h);
+int64_t gh_gather_slot_bytes(gh_handle h);
+gh_status gh_step_finish_gathered(gh_handle h);
 
 /* ---- instrumentation --------------------------------------------------------- */
 

@@ -26,6 +26,19 @@ class CpuShardEngine:
         self.partial = torch.zeros((S, k + 1), dtype=torch.int64)
         self.stats = torch.zeros((2, self.ld), dtype=torch.float64)
         self.seed, self.iter = seed, 0
+        self.gbuf = None
+
+    def gather_layout(self, world, rank, chunk):
+        """Slot = [chunk rows of new positions (ld floats each) | (2, ld) float64 statistics], as the HIP engine."""
+        self.world, self.rank, self.chunk = world, rank, chunk
+        self.slot = (chunk * self.ld * 4 + 2 * self.ld * 8 + 15) // 16 * 16
+        self.gbuf = torch.zeros((world, self.slot), dtype=torch.uint8)
+
+    def _slot_views(self, r):
+        raw = self.gbuf[r].numpy()
+        rows = raw[: self.chunk * self.ld * 4].view(np.float32).reshape(self.chunk, self.ld)
+        stats = raw[self.chunk * self.ld * 4: self.chunk * self.ld * 4 + 2 * self.ld * 8].view(np.float64).reshape(2, self.ld)
+        return rows, stats
 
     def _p(self):
         return self.pos[: self.n, : self.D].numpy()
@@ -70,6 +83,10 @@ class CpuShardEngine:
         st[0, : self.D] = self.new.astype(np.float64).sum(0)
         st[1, : self.D] = (self.new.astype(np.float64) ** 2).sum(0)
         self.stats[:] = torch.from_numpy(st)
+        if self.gbuf is not None:
+            rows, stats = self._slot_views(self.rank)
+            rows[: self.row_hi - self.row_lo, : self.D] = self.new
+            stats[:] = st
 
     def step_finish(self):
         st = self.stats.numpy()
@@ -79,6 +96,21 @@ class CpuShardEngine:
         sd = np.sqrt(var).astype(np.float32) + np.float32(1e-6)
         out = (self.new - mean.astype(np.float32)) / sd
         self.pos[self.row_lo:self.row_hi, : self.D] = torch.from_numpy(out.astype(np.float32))
+        self.iter += 1
+
+    def step_finish_gathered(self):
+        """After the slots were all-gathered: normalise all n rows, statistics added in rank order."""
+        n = self.n
+        tot = np.zeros((2, self.ld))
+        for r in range(self.world):
+            tot += self._slot_views(r)[1]
+        mean = tot[0, : self.D] / n
+        var = np.maximum((tot[1, : self.D] - tot[0, : self.D] * mean) / (n - 1), 0.0)
+        sd = np.sqrt(var).astype(np.float32) + np.float32(1e-6)
+        for r in range(self.world):
+            lo, hi = min(n, r * self.chunk), min(n, (r + 1) * self.chunk)
+            new = self._slot_views(r)[0][: hi - lo, : self.D]
+            self.pos[lo:hi, : self.D] = torch.from_numpy(((new - mean.astype(np.float32)) / sd).astype(np.float32))
         self.iter += 1
 
     def sync(self):

@@ -288,6 +288,7 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D):
             owned += ehi - elo
         parts.append((lo, hi))
         shards.append(HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, part, 0))
+        shards[-1].gather_layout(world, r, chunk)
         shards[-1].set_positions(pos)
     assert owned == len(edges)  # every edge searched by exactly one rank
     for t in range(3):
@@ -296,14 +297,10 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D):
         gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()
         for sh in shards:
             sh.step_merge(gathered, world)
-        tot = sum(sh.stats.clone() for sh in shards)
+        slots = torch.stack([sh.gbuf[r].clone() for r, sh in enumerate(shards)])   # the all-gather of the slots
         for sh in shards:
-            sh.stats.copy_(tot)
-            sh.step_finish()
-        for r, (lo, hi) in enumerate(parts):
-            for o, other in enumerate(shards):
-                if o != r:
-                    other.pos[lo:hi].copy_(shards[r].pos[lo:hi])
+            sh.gbuf.copy_(slots)
+            sh.step_finish_gathered()
     torch.cuda.synchronize()
     for sh in shards:
         got = sh.get_positions()

@@ -12,6 +12,7 @@ for world, rule, rank in [(w, r, k_) for w in (1, 2, 4, 8) for r in rules for k_
     elo, ehi = partition_edges(edges, lo, hi)
     part = (lo, hi, elo, ehi, 0) if rule == "range" else (lo, hi, 0, 0, 1)
     sh = HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, part, 0)
+    sh.gather_layout(world, rank, chunk)
     sh.set_positions(pos)
     gathered = torch.empty((world, S, k + 1), dtype=torch.int64, device="cuda")
     def it():
@@ -19,7 +20,8 @@ for world, rule, rank in [(w, r, k_) for w in (1, 2, 4, 8) for r in rules for k_
         for w in range(world):
             gathered[w].copy_(sh.partial)
         sh.step_merge(gathered, world)
-        sh.step_finish()
+        sh.gbuf.copy_(sh.gbuf[rank].expand_as(sh.gbuf).clone())  # stand-in for the all-gather of the slots
+        sh.step_finish_gathered()
     for _ in range(5): it()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(30): it()
