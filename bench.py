@@ -164,32 +164,43 @@ def main():
         kern = {name: {"avg_us": 1e3 * tot / cnt, "launches_per_step": cnt / args.steps}
                 for name, (tot, cnt) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
         E_rank = E // world
-        # dominant kernel: the fused spring+scan kernel (or the stand-alone scan when unfused)
+        n_rank = n // world
+        # Dominant kernel: the fused spring+scan kernel (the stand-alone scan when unfused).  It is bound by the
+        # memory system: the spring phase gathers one position row per pull-list entry (2E random 16-byte rows),
+        # and with no locality in the graph most of them miss the L2 (PMC traffic below).
         dom = "spring_scan" if "spring_scan" in kern else "knn_scan"
         scan_us = kern.get(dom, {}).get("avg_us")
-        flops_scan = 3.0 * D * S * E_rank                      # F_knn = 3*D*S*E per launch (per rank)
         roofline = None
+        knn_fp32 = None
         if scan_us:
-            ach = flops_scan / (scan_us * 1e-6)
-            roofline = {"kernel": dom, "bound": "mfma",
-                        "pipe": "fp32 VALU, packed v_pk_*_f32 (vector fp32 peak = dense fp32 MFMA peak)",
-                        "achieved": ach / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_PEAK,
-                        "traffic": None, "avg_launch_us": scan_us, "algorithmic_flops_per_launch": flops_scan}
+            # SURVEY 8d, the parts of B_iter this kernel performs: spring (edge list, read pos, zero F, write F),
+            # KNN midpoints (edge list, read pos) and the un-normalised update (read pos, read F, write new):
+            # 16 E + 7 * (n D 4) bytes, per rank
+            b_alg = 16.0 * E_rank + 28.0 * n_rank * D if dom == "spring_scan" else 8.0 * E_rank + 4.0 * n_rank * D
+            ach = b_alg / (scan_us * 1e-6)
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK, "traffic": None, "avg_launch_us": scan_us,
+                        "algorithmic_bytes_per_launch": b_alg,
+                        "random_row_fetches_per_launch": 2.0 * E_rank,
+                        "row_fetch_rate_G_per_s": 2.0 * E_rank / (scan_us * 1e-6) / 1e9,
+                        "row_fetch_ceiling_G_per_s": 73.9,  # tools/micro/gather_bench.hip: 8M random 16-B rows of a 16 MB table in 108 us
+                        }
             if world == 1:
                 tb, src = pmc_traffic(args.workload, dom)
                 roofline["traffic"] = tb
                 roofline["traffic_source"] = src
+                if tb:
+                    roofline["traffic_rate_GBps"] = tb / (scan_us * 1e-6) / 1e9
+                    roofline["traffic_frac_of_peak"] = tb / (scan_us * 1e-6) / HBM_PEAK
+            # the same kernel's arithmetic side (F_knn = 3 D S E per launch) against the fp32 vector
+            # peak (= dense fp32 MFMA peak); the pre-filter spends fewer instructions per pair than this count
+            flops_scan = 3.0 * D * S * E_rank
+            knn_fp32 = {"kernel": dom, "bound": "mfma", "pipe": "fp32 VALU, packed v_pk_*_f32",
+                        "achieved": flops_scan / (scan_us * 1e-6) / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
+                        "frac": flops_scan / (scan_us * 1e-6) / FP32_PEAK, "algorithmic_flops_per_launch": flops_scan}
         b_iter = 16.0 * E + 36.0 * n * D                       # B_iter = 16E + 36nD
         hbm = {"bound": "hbm", "achieved": b_iter / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                "frac": b_iter / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_iter": b_iter, "traffic": None}
-        if scan_us and dom == "spring_scan":
-            # the same kernel's memory side: pull lists + row pointers + positions read + forces written
-            b_sp = (8.0 * E + (8.0 + 4.0 * D * 2) * n) / world
-            hbm["spring_scan"] = {"avg_launch_us": scan_us, "algorithmic_bytes": b_sp,
-                                  "achieved_GBps": b_sp / (scan_us * 1e-6) / 1e9,
-                                  "frac": b_sp / (scan_us * 1e-6) / HBM_PEAK,
-                                  "random_row_fetches": 2.0 * E / world,
-                                  "row_fetch_rate_G_per_s": 2.0 * E / world / (scan_us * 1e-6) / 1e9}
         out = {
             "metric": "layout iterations/s", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
@@ -198,7 +209,7 @@ def main():
             "config": {"workload": args.workload, "graph": WORKLOADS[args.workload][0], "n_vertices": n,
                        "n_edges": E, "n_components": D, "n_neighbors": k, "sample_size": S,
                        "sampler": args.sampler, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else "")},
-            "roofline": roofline, "roofline_iter_hbm": hbm, "kernels": kern,
+            "roofline": roofline, "roofline_knn_fp32": knn_fp32, "roofline_iter_hbm": hbm, "kernels": kern,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, D, k, S, edges, pos)

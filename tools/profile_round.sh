@@ -19,4 +19,5 @@ timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCC_E
     --output-format csv -d "$ROOT/$OUT/pmc_tcc" -- python3 "$ROOT/tools/run_knn_only.py" "$WL" 5 step > /dev/null 2>&1
 find "$ROOT/$OUT" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$ROOT/$OUT/kernel_stats.csv"
 python3 "$ROOT/tools/pmc_summary.py" "$ROOT/$OUT/pmc_FETCH_SIZE" "$ROOT/$OUT/pmc_WRITE_SIZE" "$ROOT/$OUT/pmc_sq" "$ROOT/$OUT/pmc_tcc" > "$ROOT/$OUT/pmc_summary.txt"
+python3 "$ROOT/tools/make_traffic_json.py" "$ROOT/$OUT" "$WL" > /dev/null
 echo "profile written to $OUT"
