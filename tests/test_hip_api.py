@@ -201,3 +201,56 @@ def test_two_hexagons_separate():
     pos = gra.create_graphem(adj, n_components=2, backend="hip", verbose=False).run_layout(num_iterations=8)
     assert pos.shape == (12, 2) and np.isfinite(pos).all()
     assert np.linalg.norm(pos[:6].mean(0) - pos[6:].mean(0)) > 1e-2
+
+
+def test_internal_vertex_order_is_invisible_to_the_caller():
+    """gh_params.reorder: the breadth-first internal vertex order changes where rows sit on the device
+    (gh_vertex_order, gh_positions_device) and nothing the caller sees: same forces, same KNN, same
+    positions, in the caller's vertex order."""
+    import torch
+    from graphem_rapids_amd import _native
+    from graphem_rapids_amd.embedder_hip import device_view
+    import graphem_rapids_amd as gra
+    n, D, k, S = 30000, 3, 10, 256
+    edges = gra.random_regular_edges(n, 8, seed=5).astype(np.int32)
+    rng = np.random.default_rng(5)
+    pos = rng.standard_normal((n, D)).astype(np.float32)
+    stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(3)]).astype(np.int32)
+    out = {}
+    for mode in ("off", "bfs"):
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, reorder=mode)
+        eng.set_positions(pos)
+        order = eng.vertex_order()
+        assert np.array_equal(np.sort(order), np.arange(n))
+        assert (mode == "off") == np.array_equal(order, np.arange(n))
+        dev = device_view(eng.positions_device_ptr(), (n, eng.ld), torch.float32, torch.device("cuda", 0), eng)
+        assert np.array_equal(dev.cpu().numpy()[order, :D], pos)            # row of vertex v = order[v]
+        flat = device_view(eng.positions_unpadded_device_ptr(), (n, D), torch.float32, torch.device("cuda", 0), eng)
+        assert np.array_equal(flat.cpu().numpy(), pos)                       # caller's order, no padding
+        F = eng.spring_forces()
+        knn = eng.knn_midpoints(stream[0])
+        eng.run(3, stream)
+        out[mode] = (F, knn, eng.get_positions())
+        eng.close()
+    assert np.array_equal(out["off"][0], out["bfs"][0])
+    assert np.array_equal(out["off"][1], out["bfs"][1])
+    assert np.abs(out["off"][2] - out["bfs"][2]).max() <= 2e-6   # column sums are taken in row order
+
+
+def test_gather_layout_argument_checks():
+    from graphem_rapids_amd import _native
+    import graphem_rapids_amd as gra
+    n = 5000
+    edges = gra.random_regular_edges(n, 6, seed=1).astype(np.int32)
+    eng = _native.Engine(n, 3, edges, 1.0, 0.2, 0.5, 5, 64, partition=(0, 2500, 0, 0, _native.EDGES_HASHED))
+    with pytest.raises(ValueError):
+        eng.step_finish_gathered()            # no layout yet
+    with pytest.raises(ValueError):
+        eng.gather_layout(2, 1, 2500)         # this engine holds the rows of rank 0
+    with pytest.raises(ValueError):
+        eng.gather_layout(2, 0, 2000)         # chunks do not cover n
+    eng.gather_layout(2, 0, 2500)
+    assert eng.gather_slot_bytes() >= 2500 * 4 * 4 + eng.stats_rows() * 4 * 8
+    with pytest.raises(ValueError):
+        eng.gather_layout(2, 0, 2500)         # only once
+    eng.close()
