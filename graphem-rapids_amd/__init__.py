@@ -40,6 +40,10 @@ def graphem_seed_selection(embedder, k, num_iterations=20):
     run the layout, pick the k vertices farthest from the origin."""
     import numpy as np
     embedder.run_layout(num_iterations=num_iterations)
+    engine = getattr(embedder, "_engine", None)
+    if engine is not None and 1 <= k <= min(64, embedder.n):
+        # SURVEY 8f F4: radial norm + top-k on the device, k ids come back instead of (n, D) positions
+        return engine.radial_topk(k).tolist()
     radial = np.linalg.norm(np.array(embedder.positions), axis=1)
     return np.argsort(-radial)[:k].tolist()
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts", "gh_set_stream",
     "gh_positions_rows_allocated", "gh_knn_points", "gh_stats_rows", "gh_spmv_symnorm",
     "gh_spectral_last_error", "gh_gather_layout", "gh_gather_buffer_device", "gh_gather_slot_bytes",
-    "gh_step_finish_gathered", "gh_vertex_order", "gh_positions_unpadded_device",
+    "gh_step_finish_gathered", "gh_vertex_order", "gh_positions_unpadded_device", "gh_radial_topk",
 ]
 
 
@@ -73,6 +73,8 @@ def load():
     L.gh_row_stride.restype = i32
     L.gh_run.argtypes = [vp, i32, vp]
     L.gh_run.restype = ctypes.c_int
+    L.gh_radial_topk.argtypes = [vp, i32, vp]
+    L.gh_radial_topk.restype = ctypes.c_int
     L.gh_vertex_order.argtypes = [vp, vp]
     L.gh_vertex_order.restype = ctypes.c_int
     L.gh_positions_unpadded_device.argtypes = [vp]
@@ -266,6 +268,12 @@ class Engine:
 
     def stats_rows(self):
         return int(self.lib.gh_stats_rows(self.handle))
+
+    def radial_topk(self, k):
+        """The k vertices farthest from the origin, farthest first (include/graphem_hip.h gh_radial_topk)."""
+        out = np.empty(int(k), dtype=np.int32)
+        self._chk(self.lib.gh_radial_topk(self.handle, int(k), ptr(out)))
+        return out
 
     def vertex_order(self):
         """order[v] = row of vertex v in the device position array."""

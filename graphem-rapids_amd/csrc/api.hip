@@ -562,6 +562,27 @@ extern "C" gh_status gh_step_finish_gathered(gh_handle h) {
     return GH_OK;
 }
 
+extern "C" gh_status gh_radial_topk(gh_handle h, int32_t k, int32_t *ids) {
+    GH_TRY(check_handle(h));
+    if (!ids) { h->err = "ids is NULL"; return GH_ERR_INVALID; }
+    if (k < 1 || k > 64 || k > h->n) { h->err = "gh_radial_topk: k must be in [1, min(n, 64)]"; return GH_ERR_INVALID; }
+    int nparts = (int)((h->n + 2047) / 2048);
+    if (nparts > 256) nparts = 256;
+    uint64_t *d_part = nullptr;
+    int32_t *d_ids = nullptr;
+    GH_TRY(dev_alloc(h, &d_part, (size_t)nparts * k, false));
+    gh_status st = dev_alloc(h, &d_ids, (size_t)k, false);
+    if (st == GH_OK) st = gh_radial_topk_device(h, k, d_part, nparts, d_ids);
+    if (st == GH_OK && hipMemcpyAsync(ids, d_ids, sizeof(int32_t) * k, hipMemcpyDeviceToHost, h->stream) != hipSuccess) {
+        h->err = "gh_radial_topk: copy failed";
+        st = GH_ERR_HIP;
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess && st == GH_OK) { h->err = "gh_radial_topk: sync failed"; st = GH_ERR_HIP; }
+    (void)hipFree(d_part);
+    (void)hipFree(d_ids);
+    return st;
+}
+
 // ---- per-phase entry points --------------------------------------------------------
 static bool whole_graph(gh_engine *h) {
     return h->part.row_lo == 0 && h->part.row_hi == h->n &&

@@ -135,6 +135,7 @@ gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
 gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq, const float *d_ref, int64_t nref,
                                int D, int K, uint64_t *d_keys, std::string *err);
 // fused.hip
+gh_status gh_radial_topk_device(gh_engine *h, int K, uint64_t *d_part, int nparts, int32_t *d_ids);
 int gh_fused_tile(const gh_engine *h);              // edges per fused workgroup
 gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -> d_keys_cur

@@ -771,6 +771,75 @@ gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {
     return GH_OK;
 }
 
+// F4 (influence.py:28-37): the K vertices with the largest radial distance.  Key = (~bits(radial) <<
+// 32) | vertex: non-negative floats order like their bit patterns, so the K smallest keys are the K
+// largest distances, ties on the smaller vertex id.  Level 0: workgroup b takes vertices b*256+t,
+// stride gridDim*256, keeps its K best as it goes (chunks of 8 keys per thread) -> part[b][K];
+// level 1 (one workgroup): K best of all parts.
+__global__ __launch_bounds__(256) void radial_topk_kernel(const float *__restrict__ pos, const int32_t *__restrict__ order,
+                                                         int64_t n, int D, int LD, int K, uint64_t *__restrict__ part) {
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
+    constexpr int NPT = 8;
+    for (int i = threadIdx.x; i < K; i += 256) best[i] = GH_KEY_INF;
+    __syncthreads();
+    const int64_t step = (int64_t)gridDim.x * 256 * NPT;
+    for (int64_t base = (int64_t)blockIdx.x * 256 * NPT; base < n; base += step) {
+        const uint64_t tk = best[K - 1];
+        uint64_t keys[NPT + 1];
+        int any = 0;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int64_t v = base + j * 256 + threadIdx.x;
+            uint64_t key = GH_KEY_INF;
+            if (v < n) {
+                const float *row = pos + (order ? (int64_t)order[v] : v) * LD;
+                float s = 0.0f;
+                for (int d = 0; d < D; ++d) s = s + row[d] * row[d];  // numpy: multiply, then add, in order
+                const float r = sqrtf(s);
+                key = ((uint64_t)(~__float_as_uint(r)) << 32) | (uint32_t)v;
+                if (key < tk) any = 1; else key = GH_KEY_INF;
+            }
+            keys[j] = key;
+        }
+        if (__syncthreads_or(any)) {
+            keys[NPT] = threadIdx.x < K ? best[threadIdx.x] : GH_KEY_INF;
+            __syncthreads();
+            block_extract_smallest<NPT + 1>(keys, K, best, red);
+        }
+    }
+    for (int i = threadIdx.x; i < K; i += 256) part[(int64_t)blockIdx.x * K + i] = best[i];
+}
+
+__global__ __launch_bounds__(256) void radial_topk_merge_kernel(const uint64_t *__restrict__ part, int nparts, int K,
+                                                               int32_t *__restrict__ ids) {
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
+    constexpr int NPT = 8;
+    for (int i = threadIdx.x; i < K; i += 256) best[i] = GH_KEY_INF;
+    __syncthreads();
+    const int total = nparts * K;
+    for (int base = 0; base < total; base += 256 * NPT) {
+        uint64_t keys[NPT + 1];
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = base + j * 256 + threadIdx.x;
+            keys[j] = i < total ? part[i] : GH_KEY_INF;
+        }
+        keys[NPT] = threadIdx.x < K ? best[threadIdx.x] : GH_KEY_INF;
+        __syncthreads();
+        block_extract_smallest<NPT + 1>(keys, K, best, red);
+    }
+    for (int i = threadIdx.x; i < K; i += 256) ids[i] = (int32_t)(uint32_t)best[i];
+}
+
+gh_status gh_radial_topk_device(gh_engine *h, int K, uint64_t *d_part, int nparts, int32_t *d_ids) {
+    radial_topk_kernel<<<dim3((unsigned)nparts), dim3(256), 0, h->stream>>>(h->d_pos, h->d_order, h->n, h->D, h->LD, K, d_part);
+    radial_topk_merge_kernel<<<dim3(1), dim3(256), 0, h->stream>>>(d_part, nparts, K, d_ids);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
 // Plain point-set KNN (the reference's _compute_knn_chunked / _compute_knn_torch, pt.py:426-483,
 // 543-593, as a library call): K smallest (dist2, id) keys of every query row among the
 // reference rows, by the per-query kernels above with the point arrays standing in for the

@@ -189,6 +189,16 @@ gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final
 gh_status gh_knn_points(int device_id, const float *q, int64_t nq, const float *ref, int64_t nref,
                         int32_t n_components, int32_t k, int64_t *out);
 
+/* ---- caller-side reduction on the device (influence.py:28-37) ----
+ * The k vertices farthest from the origin, farthest first: np.argsort(-np.linalg.norm(positions,
+ * axis=1))[:k] of the reference's graphem_seed_selection without the (n, D) device-to-host copy.
+ * Radial distance = sqrtf of the sum of squares accumulated in coordinate order with separate
+ * multiply and add: numpy's own order for rows shorter than 8 (longer rows it sums pairwise, so the
+ * last bit -- and with it only the order of near-ties -- may differ); equal distances -> smaller
+ * vertex id first (numpy's unstable sort leaves that order open).  ids: k host int32.  1 <= k <= min(n, 64).
+ * Blocking. */
+gh_status gh_radial_topk(gh_handle h, int32_t k, int32_t *ids);
+
 /* ---- spectral initialisation (_compute_laplacian_embedding, pt.py:337-379) ----
  * y = (2I - L) x for the normalised Laplacian L of a symmetric, unweighted graph in CSR form:
  * y_i = x_i + s_i * sum_j s_j x_j over the neighbours j of i (s = degree^-1/2), y_i = 2 x_i for an

@@ -254,3 +254,27 @@ def test_gather_layout_argument_checks():
     with pytest.raises(ValueError):
         eng.gather_layout(2, 0, 2500)         # only once
     eng.close()
+
+
+@pytest.mark.parametrize("n,D,k", [(1000, 3, 10), (200000, 3, 50), (5000, 16, 64), (300, 2, 1), (40, 5, 40)])
+def test_radial_topk_on_device_equals_numpy(n, D, k):
+    """gh_radial_topk == np.argsort(-np.linalg.norm(positions, axis=1))[:k] (influence.py:31-35),
+    with and without the internal vertex order, ties resolved on the smaller id."""
+    from graphem_rapids_amd import _native
+    import graphem_rapids_amd as gra
+    edges = gra.random_regular_edges(n, 4, seed=3).astype(np.int32)
+    rng = np.random.default_rng(n)
+    pos = rng.standard_normal((n, D)).astype(np.float32)
+    pos[rng.permutation(n)[:5]] *= np.float32(3.0)
+    pos[7] = pos[3]                                   # an exact tie
+    radial = np.linalg.norm(pos, axis=1)
+    want = np.lexsort((np.arange(n), -radial))[:k]    # farthest first, smaller id on ties
+    for mode in ("off", "bfs"):
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, 3, 16, reorder=mode)
+        eng.set_positions(pos)
+        got = eng.radial_topk(k)
+        eng.close()
+        assert np.array_equal(got, want), mode
+    with pytest.raises(ValueError):
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, 3, 16)
+        eng.radial_topk(65)
