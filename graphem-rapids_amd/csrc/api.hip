@@ -361,6 +361,7 @@ extern "C" const char *gh_last_error(gh_handle h) { return h ? h->err.c_str() : 
 extern "C" gh_status gh_set_positions(gh_handle h, const float *pos) {
     GH_TRY(check_handle(h));
     if (!pos) { h->err = "positions is NULL"; return GH_ERR_INVALID; }
+    h->presetup_valid = false;
     GH_HIP(hipMemcpyAsync(h->d_io, pos, sizeof(float) * (size_t)h->n * h->D, hipMemcpyHostToDevice, h->stream));
     GH_TRY(gh_launch_pad(h, h->d_io, h->d_pos));
     GH_HIP(hipStreamSynchronize(h->stream));  // the host buffer may be released by the caller
@@ -455,8 +456,13 @@ static gh_status step_merge(gh_engine *h, const uint64_t *gathered, int world) {
     return GH_OK;
 }
 
-static gh_status step_finish(gh_engine *h) {
-    GH_TRY(gh_launch_normalise(h, true));  // also zeroes what the intersection phase touched
+// next_mode < 0: plain finish.  Otherwise the normalise launch of a single-rank step on the fused path
+// also runs the next iteration's KNN set-up, for the sample source expected then (gh_launch_normalise);
+// gh_knn_prepare falls back to its own kernel when the next step turns out different.
+static gh_status step_finish(gh_engine *h, int next_mode = -1, int32_t *next_ids = nullptr) {
+    const bool presetup = next_mode >= 0 && h->rows == h->n && !h->d_gbuf && h->fused_scan && gh_knn_scan_path(h) &&
+                          !h->force_unfused && h->S > 0 && h->k > 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
+    GH_TRY(gh_launch_normalise(h, true, presetup, next_mode, next_ids));  // also zeroes what the intersection phase touched
     h->iter += 1;
     return GH_OK;
 }
@@ -467,7 +473,8 @@ extern "C" gh_status gh_step(gh_handle h, const int32_t *sampled) {
     GH_TRY(set_sample(h, sampled, nullptr));
     GH_TRY(step_begin(h, true));
     GH_TRY(step_merge(h, h->d_partial, 1));
-    return step_finish(h);
+    // a caller that drew this step's ids itself will do so again; otherwise prepare the next step's own draw
+    return step_finish(h, sampled ? -1 : (h->S >= h->E ? 2 : 1));
 }
 
 extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_stream) {
@@ -492,7 +499,10 @@ extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_st
         GH_TRY(set_sample(h, nullptr, use_stream ? h->d_stream_ids + (size_t)t * h->S : nullptr));
         GH_TRY(step_begin(h, true));
         GH_TRY(step_merge(h, h->d_partial, 1));
-        GH_TRY(step_finish(h));
+        const bool more = t + 1 < iters;
+        if (h->S >= h->E) GH_TRY(step_finish(h, 2));
+        else if (use_stream && more) GH_TRY(step_finish(h, 0, h->d_stream_ids + (size_t)(t + 1) * h->S));
+        else GH_TRY(step_finish(h, use_stream ? -1 : 1));  // after the last id row: nothing to prepare
     }
     h->d_sampled_cur = h->d_sampled;
     return GH_OK;

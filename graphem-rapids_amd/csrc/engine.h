@@ -83,6 +83,11 @@ struct gh_engine {
     size_t stream_ids_cap = 0;
     bool new0_ready = false;      // the fused kernel of this step wrote d_new = pos + Fs and its block sums
     bool intersect_done = false;  // the KNN kernels of this step already ran the intersection phase
+    bool presetup_valid = false;  // the last normalise launch also ran the KNN set-up of iteration presetup_iter
+    int presetup_mode = 0;        //   with this sample mode / id pointer (gh_knn_prepare then skips its kernel)
+    const int32_t *presetup_ids = nullptr;
+    uint64_t presetup_iter = 0;
+    bool tcount_reset_pending = false;  // this step's threshold kernel must reset d_tcount
     bool sample_pending = false;  // ids of this iteration still to be produced (inside knn_setup_kernel)
     int sample_mode = 0;          // 1 device sampler, 2 arange
     float *d_iscratch = nullptr;  // (S * k, LD) per-pair scratch of the intersection kernel
@@ -129,6 +134,8 @@ struct gh_scope {
 // knn.hip
 gh_status gh_knn_local(gh_engine *h, bool fuse_intersect);  // d_sampled, d_mid -> d_partial (unfused)
 bool gh_knn_scan_path(const gh_engine *h);
+struct gh_setup_args;
+gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint64_t iter);  // setup_core.h
 gh_status gh_knn_prepare(gh_engine *h);
 gh_status gh_knn_thresholds(gh_engine *h);
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
@@ -148,7 +155,8 @@ gh_status gh_launch_integrate(gh_engine *h);               // d_Fs, d_acc -> d_n
 gh_status gh_launch_spring_only(gh_engine *h, float *d_F); // F (n, LD), own rows
 gh_status gh_launch_inter_to_dense(gh_engine *h, float *d_F);
 gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi);
-gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup);
+gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup = false, int next_mode = 0,
+                              int32_t *next_ids = nullptr);
 gh_status gh_launch_normalise_gathered(gh_engine *h);  // gathered slots of every rank -> all n rows of d_pos
 gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD);
 gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD);

@@ -5,6 +5,7 @@
 #include "common.h"
 #include "engine.h"
 #include "intersect_core.h"
+#include "setup_core.h"
 
 namespace {
 
@@ -222,17 +223,21 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
 // pt.py:802-804: centre by the column mean, divide by (unbiased std + 1e-6).
 // stats = global (sum, sum of squares) over all n rows; every thread derives the same
 // mean / std from them.  Writes rows [row_lo, row_lo+rows) of pos.
+// The workgroups past g_norm (single-rank steps only, rows == n) run the NEXT iteration's KNN set-up
+// (setup_core.h) from the un-normalised rows: one launch and its dependent loads off the iteration.
 __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict__ nw, int64_t rows, int64_t row_lo,
                                                        int D, int LD, int64_t n, const double *__restrict__ stats,
                                                        float *__restrict__ pos, double *__restrict__ acc,
                                                        int32_t *__restrict__ tflag,
                                                        const int32_t *__restrict__ touched,
-                                                       const int32_t *__restrict__ tcount, int nfix) {
+                                                       const int32_t *__restrict__ tcount, int nfix, int g_norm,
+                                                       gh_setup_args sa, int32_t *__restrict__ qexact) {
+    const bool setup_block = (int)blockIdx.x >= g_norm;
     // also zero what the intersection phase touched (acc != nullptr): the integrate kernel that
     // read those accumulators has finished; tcount itself is reset by the next KNN setup
-    if (acc) {
+    if (acc && !setup_block) {
         const int64_t nt = (int64_t)(*tcount) * LD;
-        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)g_norm * blockDim.x) {
             const int64_t x = touched[t / LD];
             const int d = (int)(t % LD);
             acc[x * LD + d] = 0.0;
@@ -258,8 +263,15 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
         ms[LD + d] = sd;
     }
     __syncthreads();
+    if (setup_block) {
+        const int64_t t = ((int64_t)blockIdx.x - g_norm) * blockDim.x + threadIdx.x;
+        if (t == 0) qexact[0] = 0;
+        // position of vertex v, component d < D, exactly as the normalising threads below compute it
+        gh_setup_item(sa, t, [=](int64_t v, int d) { return (nw[v * LD + d] - ms[d]) / ms[LD + d]; });
+        return;
+    }
     const int64_t total = rows * LD;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)g_norm * blockDim.x) {
         const int d = (int)(t % LD);
         const float c = nw[t] - ms[d];
         pos[row_lo * LD + t] = d < D ? c / ms[LD + d] : 0.0f;
@@ -578,16 +590,32 @@ gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float
     return GH_OK;
 }
 
-gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup) {
+// presetup: also run the next iteration's KNN set-up in this launch (single-rank fused steps), for the
+// sample source the caller expects then: mode 0 = the ids at next_ids, 1 = device sampler, 2 = arange.
+gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, int next_mode, int32_t *next_ids) {
+    h->presetup_valid = false;  // positions change: whatever set-up was done ahead is stale
     if (h->rows == 0) return with_cleanup ? gh_launch_inter_cleanup(h) : GH_OK;
     gh_scope t(h, "normalise");
     const int64_t total = h->rows * h->LD;
     unsigned grid = grid_for(total, 256);
     if (grid > 2048) grid = 2048;
-    normalise_kernel<<<dim3(grid), dim3(256), sizeof(float) * 2 * h->LD, h->stream>>>(
+    gh_setup_args sa{};
+    unsigned extra = 0;
+    if (presetup) {
+        sa = gh_make_setup_args(h, next_mode, next_mode == 0 ? next_ids : h->d_sampled, h->iter + 1);
+        extra = grid_for(h->S + sa.M1 * h->LD, 256);
+    }
+    normalise_kernel<<<dim3(grid + extra), dim3(256), sizeof(float) * 2 * h->LD, h->stream>>>(
         h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos,
-        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount, gh_fix_blocks(h->LD));
+        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount, gh_fix_blocks(h->LD), (int)grid, sa,
+        h->d_qexact);
     GH_LAUNCH_CHECK();
+    if (presetup) {
+        h->presetup_valid = true;
+        h->presetup_mode = next_mode;
+        h->presetup_ids = next_mode == 0 ? next_ids : h->d_sampled;
+        h->presetup_iter = h->iter + 1;
+    }
     return GH_OK;
 }
 

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "engine.h"
 #include "scan_core.h"
+#include "setup_core.h"
 #include "intersect_core.h"
 
 #include <math.h>
@@ -55,35 +56,12 @@ __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi
 // copy of the midpoints of every `stride`-th own edge that the threshold kernel works on
 // (M1 ~ E/64 rows gathered from positions: the full midpoint array is never needed for it).
 // mode: 0 ids already in `sampled`, 1 device sampler, 2 arange.
-__global__ __launch_bounds__(256) void knn_setup_kernel(
-    const float *__restrict__ pos, const int32_t *__restrict__ edges, int32_t *__restrict__ sampled, int mode,
-    int64_t E, uint64_t seed, uint64_t iter, int64_t S, int D, int LD, float *__restrict__ qt,
-    int32_t *__restrict__ cnt, int32_t *__restrict__ ovf, int64_t e_lo, const int32_t *__restrict__ own_eids,
-    int64_t M1, int64_t stride, float *__restrict__ midsub, int32_t *__restrict__ tcount,
-    int32_t *__restrict__ qexact) {
+__global__ __launch_bounds__(256) void knn_setup_kernel(const float *__restrict__ pos, gh_setup_args a,
+                                                       int32_t *__restrict__ tcount, int32_t *__restrict__ qexact) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t == 0) { *tcount = 0; qexact[0] = 0; }  // the previous iteration's normalise kernel has consumed it
-    if (t < S) {
-        int32_t e32;
-        if (mode == 1) { e32 = gh_sample_id(E, seed, iter, t); sampled[t] = e32; }
-        else if (mode == 2) { e32 = (int32_t)t; sampled[t] = e32; }
-        else e32 = sampled[t];
-        const int QS = gh_qs(D, LD);
-        const int64_t e = e32;
-        const int64_t u = edges[2 * e], v = edges[2 * e + 1];
-        for (int d = 0; d < QS; ++d) qt[t * QS + d] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
-        qt[t * QS + gh_qtau(D, LD)] = INFINITY;
-        cnt[t * GH_CNT_STRIDE] = 0;
-        ovf[t] = 0;
-        return;
-    }
-    const int64_t g = t - S;
-    if (g >= M1 * LD) return;
-    const int64_t j = g / LD;
-    const int d = (int)(g % LD);
-    const int64_t e = own_eids ? (int64_t)own_eids[j * stride] : e_lo + j * stride;
-    const int64_t u = edges[2 * e], v = edges[2 * e + 1];
-    midsub[g] = d < D ? (pos[u * LD + d] + pos[v * LD + d]) / 2.0f : 0.0f;
+    const int LD = a.LD;
+    gh_setup_item(a, t, [=](int64_t v, int d) { return pos[v * LD + d]; });
 }
 
 // Bitonic sort of n2 (power of two) keys in LDS by one 256-thread workgroup, ascending.
@@ -409,8 +387,11 @@ template <int LD, int NT, int RPT /* rows per thread per pass */>
 __global__ __launch_bounds__(NT) void knn_threshold_kernel(const float *__restrict__ midsub, int64_t M1, int D,
                                                            float *__restrict__ qt, float *__restrict__ qscan,
                                                            int QS, int QT, int K, _Float16 *__restrict__ qA,
-                                                           int32_t *__restrict__ qexact) {
+                                                           int32_t *__restrict__ qexact,
+                                                           int32_t *__restrict__ tcount_reset) {
     constexpr int BUF = 4096, NPT = BUF / NT;
+    // set-up done inside the previous normalise launch: the touched-list counter is reset here instead
+    if (tcount_reset && blockIdx.x == 0 && threadIdx.x == 0) *tcount_reset = 0;
     __shared__ uint64_t buf[BUF];
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[(NT / 64) * GH_EXTRACT_MAX_K];
@@ -668,18 +649,29 @@ bool gh_knn_scan_path(const gh_engine *h) {
 
 // Sample ids (if still pending), query records, list reset and -- on the scan path -- the compact
 // threshold subset: one launch.
-gh_status gh_knn_prepare(gh_engine *h) {
+gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint64_t iter) {
     const int64_t Mtot = own_edges(h);
     const bool scan = gh_knn_scan_path(h);
     const int64_t st = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h)) : 1;
     const int64_t M1 = scan ? (Mtot + st - 1) / st : 0;
+    return gh_setup_args{h->d_edges, sampled, mode, h->E, h->prm.seed, iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
+                         h->d_ovf, h->part.edge_lo, h->d_own_eids, M1, st, h->d_midsub};
+}
+
+gh_status gh_knn_prepare(gh_engine *h) {
     const int mode = h->sample_pending ? h->sample_mode : 0;
     h->sample_pending = false;
+    // the previous normalise launch may already have done this iteration's set-up (forces.hip)
+    const bool done = h->presetup_valid && h->presetup_mode == mode && h->presetup_iter == h->iter &&
+                      (mode != 0 || h->presetup_ids == h->d_sampled_cur);
+    h->presetup_valid = false;
+    h->tcount_reset_pending = done;  // the stand-alone kernel resets d_tcount; else the threshold kernel does
+    if (done) return GH_OK;
+    const gh_setup_args a = gh_make_setup_args(h, mode, h->d_sampled_cur, h->iter);
     gh_scope t(h, "knn_setup");
-    const int64_t threads = h->S + M1 * h->LD;
-    knn_setup_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream>>>(
-        h->d_pos, h->d_edges, h->d_sampled_cur, mode, h->E, h->prm.seed, h->iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
-        h->d_ovf, h->part.edge_lo, h->d_own_eids, M1, st, h->d_midsub, h->d_tcount, h->d_qexact);
+    const int64_t threads = h->S + a.M1 * h->LD;
+    knn_setup_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_pos, a, h->d_tcount,
+                                                                                          h->d_qexact);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
@@ -701,7 +693,7 @@ gh_status gh_knn_thresholds(gh_engine *h) {
 #define GH_THR(LDv, NTv, RPTv)                                                                                       \
     knn_threshold_kernel<LDv, NTv, RPTv><<<dim3((unsigned)h->S), dim3(NTv), 0, h->stream>>>(h->d_midsub, M1, h->D,    \
                                                                                            h->d_q, h->d_qscan, QS, QT, h->K,           \
-        reinterpret_cast<_Float16 *>(h->d_qA), h->d_qexact)
+        reinterpret_cast<_Float16 *>(h->d_qA), h->d_qexact, h->tcount_reset_pending ? h->d_tcount : nullptr)
 #define GH_THR_LD(LDv, R0)                                                                                           \
     const bool half = rpt == -1 || rpt == R0 / 2;                                                                    \
     if (nt == 256) { if (half) GH_THR(LDv, 256, R0 / 2); else GH_THR(LDv, 256, R0); }                                \
