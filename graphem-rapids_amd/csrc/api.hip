@@ -519,6 +519,7 @@ extern "C" gh_status gh_sync(gh_handle h) {
 extern "C" gh_status gh_step_begin(gh_handle h, const int32_t *sampled) {
     GH_TRY(check_handle(h));
     GH_TRY(check_k(h));
+    h->last_step_own_ids = sampled == nullptr;
     GH_TRY(set_sample(h, sampled, nullptr));
     return step_begin(h, false);
 }
@@ -567,7 +568,8 @@ extern "C" int64_t gh_gather_slot_bytes(gh_handle h) { return h ? h->g_slot : 0;
 extern "C" gh_status gh_step_finish_gathered(gh_handle h) {
     GH_TRY(check_handle(h));
     if (!h->d_gbuf) { h->err = "gh_gather_layout has not been called"; return GH_ERR_INVALID; }
-    GH_TRY(gh_launch_normalise_gathered(h));
+    // a rank that drew this step's ids on the device will do so again: prepare them in the same launch
+    GH_TRY(gh_launch_normalise_gathered(h, h->last_step_own_ids ? (h->S >= h->E ? 2 : 1) : -1));
     h->iter += 1;
     return GH_OK;
 }

@@ -87,6 +87,7 @@ struct gh_engine {
     int presetup_mode = 0;        //   with this sample mode / id pointer (gh_knn_prepare then skips its kernel)
     const int32_t *presetup_ids = nullptr;
     uint64_t presetup_iter = 0;
+    bool last_step_own_ids = false;     // gh_step_begin was called without ids (device sampler / arange)
     bool tcount_reset_pending = false;  // this step's threshold kernel must reset d_tcount
     bool sample_pending = false;  // ids of this iteration still to be produced (inside knn_setup_kernel)
     int sample_mode = 0;          // 1 device sampler, 2 arange
@@ -157,7 +158,7 @@ gh_status gh_launch_inter_to_dense(gh_engine *h, float *d_F);
 gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi);
 gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup = false, int next_mode = 0,
                               int32_t *next_ids = nullptr);
-gh_status gh_launch_normalise_gathered(gh_engine *h);  // gathered slots of every rank -> all n rows of d_pos
+gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode = -1);  // gathered slots of every rank -> all n rows of d_pos
 gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD);
 gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD);
 gh_status gh_launch_sample(gh_engine *h);                  // device sampler -> d_sampled

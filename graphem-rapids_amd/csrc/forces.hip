@@ -286,10 +286,12 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
                                                                 int nfix, float *__restrict__ pos,
                                                                 double *__restrict__ acc, int32_t *__restrict__ tflag,
                                                                 const int32_t *__restrict__ touched,
-                                                                const int32_t *__restrict__ tcount) {
-    {
+                                                                const int32_t *__restrict__ tcount, int g_norm,
+                                                                gh_setup_args sa, int32_t *__restrict__ qexact) {
+    const bool setup_block = (int)blockIdx.x >= g_norm;  // the next iteration's KNN set-up, as in normalise_kernel
+    if (!setup_block) {
         const int64_t nt = (int64_t)(*tcount) * LD;
-        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
+        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)g_norm * blockDim.x) {
             const int64_t x = touched[t / LD];
             const int d = (int)(t % LD);
             acc[x * LD + d] = 0.0;
@@ -326,8 +328,18 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
         ms[LD + d] = sd;
     }
     __syncthreads();
+    if (setup_block) {
+        const int64_t t = ((int64_t)blockIdx.x - g_norm) * blockDim.x + threadIdx.x;
+        if (t == 0) qexact[0] = 0;
+        gh_setup_item(sa, t, [=](int64_t v, int d) {
+            const int64_t r = v / chunk;
+            const float *rowsrc = reinterpret_cast<const float *>(gbuf + r * slot);
+            return (rowsrc[(v - r * chunk) * LD + d] - ms[d]) / ms[LD + d];
+        });
+        return;
+    }
     const int64_t total = n * LD;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)g_norm * blockDim.x) {
         const int64_t i = t / LD;
         const int d = (int)(t % LD);
         const int64_t r = i / chunk;
@@ -619,15 +631,31 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
     return GH_OK;
 }
 
-gh_status gh_launch_normalise_gathered(gh_engine *h) {
+// next_mode >= 0: also the next iteration's KNN set-up (as gh_launch_normalise).
+gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
+    h->presetup_valid = false;
     gh_scope t(h, "normalise_gathered");
     unsigned grid = grid_for(h->n * h->LD, 256);
     if (grid > 2048) grid = 2048;
+    const bool presetup = next_mode >= 0 && h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused && h->S > 0 &&
+                          h->k > 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
+    gh_setup_args sa{};
+    unsigned extra = 0;
+    if (presetup) {
+        sa = gh_make_setup_args(h, next_mode, h->d_sampled, h->iter + 1);
+        extra = grid_for(h->S + sa.M1 * h->LD, 256);
+    }
     const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * h->LD * (size_t)h->g_world;
-    normalise_gathered_kernel<<<dim3(grid), dim3(256), smem, h->stream>>>(
+    normalise_gathered_kernel<<<dim3(grid + extra), dim3(256), smem, h->stream>>>(
         h->d_gbuf, h->g_slot, h->g_chunk, h->g_world, h->D, h->LD, h->n, gh_fix_blocks(h->LD), h->d_pos, h->d_acc,
-        h->d_tflag, h->d_touched, h->d_tcount);
+        h->d_tflag, h->d_touched, h->d_tcount, (int)grid, sa, h->d_qexact);
     GH_LAUNCH_CHECK();
+    if (presetup) {
+        h->presetup_valid = true;
+        h->presetup_mode = next_mode;
+        h->presetup_ids = h->d_sampled;
+        h->presetup_iter = h->iter + 1;
+    }
     return GH_OK;
 }
 

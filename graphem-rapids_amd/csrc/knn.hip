@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
 // Only launched for world > 1; the intersection phase reads keys and drops column 0 itself
 // (pt.py:421: knn_indices[:, 1:]).
 __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restrict__ gathered, int world, int64_t S,
-                                                        int K, uint64_t *__restrict__ merged) {
+                                                        int K, uint64_t *__restrict__ merged, inter_args ia) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t *buf = reinterpret_cast<uint64_t *>(smem_raw);
     const int64_t qi = blockIdx.x;
@@ -541,6 +541,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restri
     __syncthreads();
     block_sort(buf, n2);
     for (int c = threadIdx.x; c < K; c += blockDim.x) merged[qi * K + c] = buf[c];
+    if (ia.pos) intersect_query(ia, qi, buf);  // the k candidate pairs of this query, same launch (pt.py:638-774)
 }
 
 template <int D, int R>
@@ -755,11 +756,12 @@ gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {
         h->err = "world * (n_neighbors + 1) too large for the merge kernel";
         return GH_ERR_INVALID;
     }
-    gh_scope t(h, "knn_merge");
+    gh_scope t(h, "knn_merge_intersect");
     knn_merge_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(uint64_t) * (size_t)n2, h->stream>>>(
-        gathered, world, h->S, h->K, h->d_merged);
+        gathered, world, h->S, h->K, h->d_merged, make_inter_args(h, !h->intersect_done));
     GH_LAUNCH_CHECK();
     h->d_keys_cur = h->d_merged;
+    h->intersect_done = true;
     return GH_OK;
 }
 

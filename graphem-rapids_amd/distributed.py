@@ -124,8 +124,8 @@ class PartitionedLayout:
         self.n, self.D = int(n), int(D)
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
         self.chunk, self.row_lo, self.row_hi = partition_rows(self.n, self.world, self.rank)
-        if edge_ownership == "auto":  # one rank owns everything either way: keep the cheaper contiguous ids
-            edge_ownership = "hashed" if self.world > 1 else "range"
+        if edge_ownership == "auto":  # balanced shares, and the rule the engine's internal BFS vertex order needs
+            edge_ownership = "hashed"
         if edge_ownership not in ("hashed", "range"):
             raise ValueError(f"edge_ownership must be 'auto', 'hashed' or 'range', got {edge_ownership!r}")
         self.edge_ownership = edge_ownership
