@@ -281,3 +281,29 @@ def test_radial_topk_on_device_equals_numpy(n, D, k):
     with pytest.raises(ValueError):
         eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, 3, 16)
         eng.radial_topk(65)
+
+
+def test_integration_md_binding_stub_runs():
+    """The ctypes stub INTEGRATION.md shows a maintainer of the reference (section B) is executed as written
+    (only the library path is made absolute) and must lay a graph out through the bare C ABI."""
+    import re
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    section = text[text.index("## B."):]
+    code = re.search(r"```python\n(.*?)```", section, re.S).group(1)
+    assert 'ctypes.CDLL("libgraphem_hip.so")' in code
+    code = code.replace('ctypes.CDLL("libgraphem_hip.so")', f'ctypes.CDLL({_native.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    adj = gra.generate_random_regular(n=3000, d=6, seed=1)
+    emb = ns["GraphEmbedderHIP"](adj, n_components=3, seed=4)
+    p0 = np.random.default_rng(0).standard_normal((3000, 3)).astype(np.float32)
+    emb.positions = p0
+    assert np.array_equal(emb.positions, p0)
+    out = emb.run_layout(5)
+    assert out.shape == (3000, 3) and np.isfinite(out).all()
+    assert np.abs(out.std(axis=0, ddof=1) - 1).max() < 1e-3
+    emb.update_positions()
+    assert not np.array_equal(emb.get_positions(), out)
