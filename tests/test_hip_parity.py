@@ -490,3 +490,34 @@ def test_fused_scan_knn_is_exact(form, n, D, deg, outliers, monkeypatch):
     for d in range(D):   # fma chain in coordinate order; products of fp32 are exact in fp64
         want = (diff[..., d].astype(np.float64) ** 2 + want.astype(np.float64)).astype(np.float32)
     assert np.array_equal(d2, want)
+
+
+@pytest.mark.parametrize("reorder", ["off", "bfs"])
+def test_skewed_degrees_hubs(reorder):
+    """A graph with hubs (degrees 20000, 2000, 600 on top of a sparse random graph): one row owns more
+    edges than a fused workgroup holds, so the engine must take its unfused kernels; one thread
+    walks a 20000-long pull list in the reference's order.  Every phase against the oracle."""
+    from graphem_rapids_amd import _native
+    import graphem_rapids_amd as gra
+    n, D, k, S = 50000, 3, 10, 256
+    rng = np.random.default_rng(11)
+    base = gra.random_regular_edges(n, 4, seed=9).astype(np.int64)
+    extra = []
+    for hub, deg in ((17, 20000), (4021, 2000), (49999, 600)):
+        nb = rng.choice(n, size=deg, replace=False)
+        nb = nb[nb != hub]
+        extra.append(np.stack([np.minimum(hub, nb), np.maximum(hub, nb)], axis=1))
+    e = np.unique(np.concatenate([np.sort(base, axis=1)] + extra), axis=0)   # u < v, sorted, no duplicates
+    edges = np.ascontiguousarray(e, dtype=np.int32)
+    pos = rng.standard_normal((n, D)).astype(np.float32)
+    sampled = rng.permutation(len(edges))[:S].astype(np.int32)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, reorder=reorder)
+    eng.set_positions(pos)
+    assert np.array_equal(eng.spring_forces(), oracle.spring_forces(pos, edges, 1.0, 0.2))
+    assert np.array_equal(eng.knn_midpoints(sampled), oracle.knn_midpoints(pos, edges, sampled, k))
+    eng.step(sampled)
+    ref = oracle.step(pos, edges, sampled, k, 1.0, 0.2, 0.5)
+    assert np.abs(eng.get_positions() - ref).max() <= 1e-4
+    eng.run(3)                      # device sampler on the same paths
+    assert np.isfinite(eng.get_positions()).all()
+    eng.close()
