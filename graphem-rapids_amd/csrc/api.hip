@@ -75,7 +75,7 @@ static gh_status check_handle(gh_engine *h) {
 
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
-                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_cand, h->d_cnt,
+                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_terms, h->d_cand, h->d_cnt,
                     h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -173,6 +173,16 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         }
     }
 
+    // Hubs (common.h GH_LONG_DEG): degrees over the WHOLE graph, so that every rank sees the same set.
+    // A graph that has any takes the flagged ownership rule (it lets the short endpoint of a hub's
+    // edge own it, so that no row owns more than a workgroup's tile).
+    std::vector<int32_t> deg((size_t)n, 0);
+    for (int64_t i = 0; i < 2 * E; ++i) deg[(size_t)edges[i]]++;
+    bool has_long = false;
+    for (int64_t i = 0; i < n && !has_long; ++i) has_long = deg[(size_t)i] > GH_LONG_DEG;
+    if (has_long && part && part->edge_rule != GH_EDGES_HASHED) has_long = false;  // range partitions: as before
+    if (has_long && !part) h->part = gh_partition{0, n, 0, 0, GH_EDGES_HASHED};
+
     // Pull lists of the own rows in the reference's summation order (pt.py:633-634):
     // first the edges where the vertex is endpoint 0, then those where it is endpoint 1,
     // each in edge-list order.  Bit 31 of an entry marks the edges this row OWNS (emits the
@@ -180,9 +190,14 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     // [edge_lo, edge_hi), each owned by its endpoint 0.  GH_EDGES_HASHED (partitioned engines):
     // a hash of the edge id picks the owning endpoint, so every rank owns ~E/world edges
     // whatever the vertex numbering (with endpoint-0 ownership the low-numbered ranks of a
-    // u<v edge list hold most of the edges).
+    // u<v edge list hold most of the edges); an edge between a hub and a short row always belongs to
+    // the short row.
     const bool hashed = h->part.edge_rule == GH_EDGES_HASHED;
-    auto owner_is_v = [](int64_t e) {
+    auto owner_is_v = [&](int64_t e) {
+        if (has_long) {
+            const bool lu = deg[(size_t)edges[2 * e]] > GH_LONG_DEG, lv = deg[(size_t)edges[2 * e + 1]] > GH_LONG_DEG;
+            if (lu != lv) return lu;
+        }
         uint32_t x = (uint32_t)e * 0x9E3779B1u;
         x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13;
         return (x >> 31) != 0;
@@ -225,7 +240,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     // row are consecutive ids and the offset is the first of them.  Hashed rule: a prefix count
     // into the list own_eids of owned edge ids in (row, pull list) order.
     std::vector<int32_t> first_edge((size_t)h->rows + 1, 0);
-    std::vector<int32_t> own_eids;
+    std::vector<int32_t> own_eids, long_rows, long_ownptr, long_ownadj, long_eptr;
     if (hashed) {
         own_eids.reserve((size_t)(E / std::max<int64_t>(1, n / std::max<int64_t>(h->rows, 1)) + 16));
         for (int64_t i = 0; i < h->rows; ++i) {
@@ -235,6 +250,20 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         }
         first_edge[(size_t)h->rows] = (int32_t)own_eids.size();
         h->own_count = (int64_t)own_eids.size();
+        if (has_long) {  // the own hub rows and the (hub-hub) edges they own, for spring_long_kernel / spring_row
+            long_ownptr.push_back(0);
+            long_eptr.push_back(0);
+            for (int64_t i = 0; i < h->rows; ++i) {
+                if (rowptr[(size_t)i + 1] - rowptr[(size_t)i] <= GH_LONG_DEG) continue;
+                long_rows.push_back((int32_t)i);
+                long_eptr.push_back(long_eptr.back() + (rowptr[(size_t)i + 1] - rowptr[(size_t)i]));
+                for (int32_t j = rowptr[(size_t)i]; j < rowptr[(size_t)i + 1]; ++j)
+                    if ((uint32_t)adj[(size_t)j] >> 31) long_ownadj.push_back((int32_t)((uint32_t)adj[(size_t)j] & 0x7FFFFFFFu));
+                long_ownptr.push_back((int32_t)long_ownadj.size());
+            }
+            h->nlong = (int)long_rows.size();
+            h->long_entries = long_eptr.back();
+        }
         h->mid_base = 0;
         h->fused_mid = true;
         std::vector<int32_t>().swap(adj_eid);
@@ -293,6 +322,13 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_Fs, (size_t)h->rows * h->LD, true);
     GH_A(d_midsub, (size_t)(h->own_count / 2 + 2) * h->LD, true);
     if (hashed) GH_A(d_own_eids, own_eids.size() + 1, true);
+    if (h->nlong) {
+        GH_A(d_long_rows, long_rows.size(), false);
+        GH_A(d_long_ownptr, long_ownptr.size(), false);
+        GH_A(d_long_ownadj, long_ownadj.size() + 1, true);
+        GH_A(d_long_eptr, long_eptr.size(), false);
+        GH_A(d_long_terms, (size_t)h->long_entries * D, false);
+    }
     GH_A(d_vblock, vblock.size(), false);
     GH_A(d_pos, (size_t)h->pos_rows * h->LD, true);
     GH_A(d_new, (size_t)h->rows * h->LD, true);
@@ -329,6 +365,10 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         !up(h->d_first_edge, first_edge.data(), sizeof(int32_t) * first_edge.size()) ||
         !up(h->d_vblock, vblock.data(), sizeof(int32_t) * vblock.size()) ||
         (hashed && !up(h->d_own_eids, own_eids.data(), sizeof(int32_t) * own_eids.size())) ||
+        (h->nlong && (!up(h->d_long_rows, long_rows.data(), sizeof(int32_t) * long_rows.size()) ||
+                      !up(h->d_long_ownptr, long_ownptr.data(), sizeof(int32_t) * long_ownptr.size()) ||
+                      !up(h->d_long_eptr, long_eptr.data(), sizeof(int32_t) * long_eptr.size()) ||
+                      !up(h->d_long_ownadj, long_ownadj.data(), sizeof(int32_t) * long_ownadj.size()))) ||
         hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "upload of the graph failed";
         return bail(GH_ERR_HIP);

@@ -150,6 +150,50 @@ __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const
 
 
 // ---------------------------------------------------------------------------------
+// Long rows (hubs).  A thread walking a pull list of thousands of entries eight gathers at a time
+// holds its whole workgroup up for milliseconds, so rows with more than GH_LONG_DEG neighbours get
+// their spring force from spring_long_kernel (forces.hip) beforehand: one wave per row, 64
+// neighbours gathered and their force terms computed in parallel, then ADDED IN LIST ORDER through
+// v_readlane -- the reference's summation order, bit for bit.  Such rows own no edge whose other
+// endpoint is short (api.hip: the short endpoint owns it); the few they do own (hub-hub edges) are
+// listed apart so that their midpoints can still be emitted by the row's thread.
+#define GH_LONG_DEG 128
+struct gh_long_args {
+    const int32_t *rows;    // local ids of the long own rows, ascending
+    const int32_t *ownptr;  // (n + 1) offsets into ownadj
+    const int32_t *ownadj;  // neighbours across the edges the long rows own, pull-list order
+    int n;                  // number of long own rows (0: the graph has none)
+};
+
+// One row of the spring phase: short rows pull, long rows take the force spring_long_kernel left
+// in Fpre and only emit the midpoints of the edges they own.
+template <int D, int LD, bool WRITE_MID>
+__device__ __forceinline__ void spring_row(const float *__restrict__ pos, const int32_t *__restrict__ adj, int beg,
+                                           int end, int64_t self, const float *px, float L_min, float neg_k, float *F,
+                                           float *__restrict__ mid, int64_t mid_row0, const gh_long_args &la,
+                                           int i_local, const float *__restrict__ Fpre) {
+    if (la.n > 0 && end - beg > GH_LONG_DEG) {
+        gh_load_row<LD>(Fpre, 0, F);
+        if (WRITE_MID) {
+            int lo = 0, hi = la.n - 1;
+            while (lo < hi) {  // la.rows holds i_local
+                const int m = (lo + hi) >> 1;
+                if (la.rows[m] < i_local) lo = m + 1; else hi = m;
+            }
+            for (int j = la.ownptr[lo]; j < la.ownptr[lo + 1]; ++j) {
+                float py[LD], mrow[LD];
+                gh_load_row<LD>(pos, la.ownadj[j], py);
+#pragma unroll
+                for (int d = 0; d < LD; ++d) mrow[d] = d < D ? (px[d] + py[d]) / 2.0f : 0.0f;
+                gh_store_row<LD>(mid, mid_row0++, mrow);
+            }
+        }
+        return;
+    }
+    spring_pull<D, LD, WRITE_MID>(pos, adj, beg, end, self, px, L_min, neg_k, F, mid, mid_row0);
+}
+
+// ---------------------------------------------------------------------------------
 // Device sampler: the t-th value of a keyed pseudo-random permutation of [0, E) (stands in for
 // torch.randperm(E)[t], pt.py:409).  A 4-round Feistel network on ceil(log2 E) bits with cycle
 // walking: every thread computes its own id, ids are distinct by construction, and every rank

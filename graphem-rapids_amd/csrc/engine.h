@@ -55,6 +55,13 @@ struct gh_engine {
     int64_t own_count = 0;           // edges this rank owns (midpoints in d_mid, searched by its KNN kernels)
     int64_t mid_base = 0;            // d_mid row of an owned edge = d_first_edge offset - mid_base
     bool fused_mid = false;       // own edge range == edges owned by own rows: spring kernel writes midpoints
+    int32_t *d_long_rows = nullptr;   // local ids of the own rows with more than GH_LONG_DEG neighbours (common.h)
+    int32_t *d_long_ownptr = nullptr; // their owned (hub-hub) edges: offsets ...
+    int32_t *d_long_ownadj = nullptr; // ... and neighbours
+    int32_t *d_long_eptr = nullptr;   // (nlong + 1) prefix of their degrees
+    float *d_long_terms = nullptr;    // (long_entries * D) force terms of their neighbours, component-major per row
+    int nlong = 0;
+    int64_t long_entries = 0;
     float *d_mid = nullptr;       // (own_count, LD) midpoints of the own edges, current iteration
     float *d_Fs = nullptr;        // (rows, LD) spring forces of the own rows
     float *d_midsub = nullptr;    // (ceil(own edges / 2), LD) compact midpoints of the threshold subsets
@@ -158,7 +165,10 @@ gh_status gh_launch_inter_to_dense(gh_engine *h, float *d_F);
 gh_status gh_launch_integrate_given(gh_engine *h, const float *d_Fs, const float *d_Fi);
 gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup = false, int next_mode = 0,
                               int32_t *next_ids = nullptr);
-gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode = -1);  // gathered slots of every rank -> all n rows of d_pos
+gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode = -1);
+struct gh_long_args;
+gh_long_args gh_make_long_args(const gh_engine *h);                 // common.h
+gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0);  // spring forces of the hub rows  // gathered slots of every rank -> all n rows of d_pos
 gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD);
 gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD);
 gh_status gh_launch_sample(gh_engine *h);                  // device sampler -> d_sampled

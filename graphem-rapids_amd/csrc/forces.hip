@@ -21,11 +21,11 @@ namespace {
 // Spring forces of the rows [row_lo, row_lo + rows) (pt.py:595-636) and, when WRITE_MID, the
 // midpoints of the edges those rows own (edges are sorted by first endpoint, so the edges of
 // row i are first_edge[i] .. first_edge[i+1]).  F goes to outF[(i + f_row0) * LD].
-template <int D, int LD, bool WRITE_MID>
+template <int D, int LD, bool WRITE_MID, bool LONG>
 __global__ __launch_bounds__(256) void spring_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
     const int32_t *__restrict__ first_edge, int64_t edge_lo, int64_t row_lo, int64_t rows, float L_min,
-    float neg_k, float *__restrict__ outF, int64_t f_row0, float *__restrict__ mid) {
+    float neg_k, float *__restrict__ outF, int64_t f_row0, float *__restrict__ mid, gh_long_args la) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= rows) return;
     const int64_t x = row_lo + i;
@@ -33,8 +33,98 @@ __global__ __launch_bounds__(256) void spring_kernel(
     gh_load_row<LD>(pos, x, px);
     int64_t mid_row0 = 0;
     if (WRITE_MID) mid_row0 = first_edge[i] - edge_lo;  // d_mid row of the first edge this row owns
-    spring_pull<D, LD, WRITE_MID>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mid, mid_row0);
+    if constexpr (LONG)
+        spring_row<D, LD, WRITE_MID>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mid, mid_row0, la, (int)i,
+                                     outF + (i + f_row0) * LD);
+    else
+        spring_pull<D, LD, WRITE_MID>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mid, mid_row0);
     gh_store_row<LD>(outF, i + f_row0, F);
+}
+
+// Spring force of the long rows (common.h GH_LONG_DEG) in two launches.
+// (1) long_terms_kernel: one thread per pull-list entry of a long row computes that neighbour's force
+//     term with the arithmetic of spring_pull -- all gathers of all hubs in flight at once -- and
+//     stores it component-major per row: terms[eptr[r]*D + d*deg_r + idx].
+// (2) long_sum_kernel: one wave per long row ADDS THE TERMS IN LIST ORDER, the reference's order
+//     (pt.py:633-634): 64 terms per step, lane 0 starts from the running sum, then 63 dependent adds
+//     x_l = x_(l-1) + term_l with the neighbour lane read through DPP wave_shr:1, so that lane k
+//     holds ((F + t_0) + t_1) + ... + t_k.  The reads are contiguous and fetched two steps ahead.
+template <int D, int LD>
+__global__ __launch_bounds__(256) void long_terms_kernel(const float *__restrict__ pos, const int32_t *__restrict__ rowptr,
+                                                        const int32_t *__restrict__ adj,
+                                                        const int32_t *__restrict__ long_rows,
+                                                        const int32_t *__restrict__ eptr, int nlong, int64_t row_lo,
+                                                        float L_min, float neg_k, float *__restrict__ terms) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= eptr[nlong]) return;
+    int lo = 0, hi = nlong - 1;
+    while (lo < hi) {  // last r with eptr[r] <= t
+        const int m = (lo + hi + 1) >> 1;
+        if (eptr[m] <= t) lo = m; else hi = m - 1;
+    }
+    const int i = long_rows[lo];
+    const int idx = t - eptr[lo], deg = eptr[lo + 1] - eptr[lo];
+    const int64_t y = (uint32_t)adj[rowptr[i] + idx] & 0x7FFFFFFFu;
+    float px[LD], py[LD], diff[D];
+    gh_load_row<LD>(pos, row_lo + i, px);
+    gh_load_row<LD>(pos, y, py);
+#pragma unroll
+    for (int d = 0; d < D; ++d) diff[d] = py[d] - px[d];
+    const float dist = sqrtf(gh_sumsq<D>(diff)) + 1e-6f;
+    const float fm = neg_k * (dist - L_min);
+#pragma unroll
+    for (int d = 0; d < D; ++d) terms[(int64_t)eptr[lo] * D + (int64_t)d * deg + idx] = fm * (diff[d] / dist);
+}
+
+template <int D, int LD>
+__global__ __launch_bounds__(256) void long_sum_kernel(const float *__restrict__ terms, const int32_t *__restrict__ long_rows,
+                                                      const int32_t *__restrict__ eptr, int nlong,
+                                                      float *__restrict__ outF, int64_t f_row0) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nlong) return;
+    const int deg = eptr[r + 1] - eptr[r];
+    const float *tr = terms + (int64_t)eptr[r] * D;
+    float F[D], nxt[2][D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        F[d] = 0.0f;
+        nxt[0][d] = lane < deg ? tr[(int64_t)d * deg + lane] : 0.0f;
+        nxt[1][d] = 64 + lane < deg ? tr[(int64_t)d * deg + 64 + lane] : 0.0f;
+    }
+    for (int base = 0; base < deg; base += 64) {
+        float x[D], t[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float term = nxt[0][d];
+            nxt[0][d] = nxt[1][d];
+            nxt[1][d] = base + 128 + lane < deg ? tr[(int64_t)d * deg + base + 128 + lane] : 0.0f;
+            x[d] = lane == 0 ? F[d] + term : term;
+            t[d] = term;
+        }
+        const int cnt = deg - base < 64 ? deg - base : 64;
+        // 63 steps of ONE instruction per coordinate: v_add_f32 with its first operand taken from the
+        // left neighbour lane (DPP wave_shr:1); lane 0 has none and, bound_ctrl being off, keeps its
+        // value.  Values only travel upwards, so a lane is final after as many steps as its index and
+        // the steps past cnt-1 of a short last batch change nothing below lane cnt.  The s_nop keeps the
+        // two wait states a DPP read needs after the VALU write of the same register (D < 3).
+#pragma unroll
+        for (int step = 1; step < 64; ++step) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                asm volatile("v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x[d]) : "v"(t[d]));
+            asm volatile("s_nop 1");
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            F[d] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x[d]), cnt - 1));
+    }
+    if (lane == 0) {
+        float out[LD];
+#pragma unroll
+        for (int d = 0; d < LD; ++d) out[d] = d < D ? F[d] : 0.0f;
+        gh_store_row<LD>(outF, long_rows[r] + f_row0, out);
+    }
 }
 
 // Combine (pt.py:796-799): new = pos + (F_spring + F_inter) for the own rows, plus the
@@ -449,10 +539,13 @@ template <bool WRITE_MID>
 gh_status launch_spring(gh_engine *h, float *outF, int64_t f_row0) {
     const unsigned grid = grid_for(h->rows, 256);
     const float neg_k = -h->prm.k_attr;
+    const gh_long_args la = gh_make_long_args(h);
+#define GH_SPRING_ARGS h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->mid_base, h->part.row_lo, h->rows, \
+                       h->prm.L_min, neg_k, outF, f_row0, h->d_mid, la
 #define GH_SPRING_CASE(DD, LL)                                                                              \
-    spring_kernel<DD, LL, WRITE_MID><<<dim3(grid), dim3(256), 0, h->stream>>>(                              \
-        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->mid_base, h->part.row_lo, h->rows,         \
-        h->prm.L_min, neg_k, outF, f_row0, h->d_mid)
+    if (la.n > 0) spring_kernel<DD, LL, WRITE_MID, true><<<dim3(grid), dim3(256), 0, h->stream>>>(GH_SPRING_ARGS); \
+    else spring_kernel<DD, LL, WRITE_MID, false><<<dim3(grid), dim3(256), 0, h->stream>>>(GH_SPRING_ARGS)
+    GH_TRY_ST(gh_launch_spring_long(h, outF, f_row0));  // hubs first: spring_row reads their forces back
     switch (h->D) {
         case 2: GH_SPRING_CASE(2, 4); break;
         case 3: GH_SPRING_CASE(3, 4); break;
@@ -465,9 +558,44 @@ gh_status launch_spring(gh_engine *h, float *outF, int64_t f_row0) {
                 f_row0, h->d_tmpF2);
     }
 #undef GH_SPRING_CASE
+#undef GH_SPRING_ARGS
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
+
+}  // namespace
+
+static bool spring_is_templated_d(int D) { return D == 2 || D == 3 || D == 4 || D == 8 || D == 16; }
+
+gh_long_args gh_make_long_args(const gh_engine *h) {
+    if (h->nlong == 0 || !spring_is_templated_d(h->D)) return gh_long_args{nullptr, nullptr, nullptr, 0};
+    return gh_long_args{h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->nlong};
+}
+
+// Spring forces of the long own rows -> outF rows (i + f_row0); no-op for graphs without hubs.
+gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0) {
+    const gh_long_args la = gh_make_long_args(h);
+    if (la.n == 0) return GH_OK;
+    gh_scope t(h, "spring_long");
+    const float neg_k = -h->prm.k_attr;
+#define GH_LONG_CASE(DD, LL)                                                                                          \
+    long_terms_kernel<DD, LL><<<dim3(grid_for(h->long_entries, 256)), dim3(256), 0, h->stream>>>(                       \
+        h->d_pos, h->d_rowptr, h->d_adj, la.rows, h->d_long_eptr, la.n, h->part.row_lo, h->prm.L_min, neg_k, h->d_long_terms); \
+    long_sum_kernel<DD, LL><<<dim3((unsigned)((la.n + 3) / 4)), dim3(256), 0, h->stream>>>(h->d_long_terms, la.rows,   \
+                                                                                          h->d_long_eptr, la.n, outF, f_row0)
+    switch (h->D) {
+        case 2: GH_LONG_CASE(2, 4); break;
+        case 3: GH_LONG_CASE(3, 4); break;
+        case 4: GH_LONG_CASE(4, 4); break;
+        case 8: GH_LONG_CASE(8, 8); break;
+        default: GH_LONG_CASE(16, 16); break;
+    }
+#undef GH_LONG_CASE
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+namespace {
 
 gh_status launch_mid_gather(gh_engine *h) {
     const int64_t M = h->own_count;

@@ -56,19 +56,25 @@ namespace {
 // midpoints of their owned edges -> LDS, and new0 = pos + Fs -> out_new (pt.py:796-799 for every
 // vertex the intersection phase does not touch: Fs + 0 == Fs exactly; the few touched vertices are
 // redone by stats_fix_kernel).  Returns this thread's column sums of new0 for the fp64 statistics.
-template <int D, int LD, int NT>
+template <int D, int LD, int NT, bool LONG>
 __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const int32_t *__restrict__ rowptr,
                                            const int32_t *__restrict__ adj, const int32_t *__restrict__ first_edge,
                                            int v0, int v1, int fe0, int64_t row_lo, float L_min, float neg_k,
                                            float *__restrict__ Fs, float *__restrict__ out_new, float *mids,
-                                           double (&sx)[LD], double (&sxx)[LD]) {
+                                           double (&sx)[LD], double (&sxx)[LD], const gh_long_args &la) {
 #pragma unroll
     for (int d = 0; d < LD; ++d) { sx[d] = 0.0; sxx[d] = 0.0; }
     for (int i = v0 + threadIdx.x; i < v1; i += NT) {
         const int64_t x = row_lo + i;
         float px[LD], F[LD], nw[LD];
         gh_load_row<LD>(pos, x, px);
-        spring_pull<D, LD, true>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mids, first_edge[i] - fe0);
+        // LONG: the graph has hub rows (their forces come from spring_long_kernel); kept out of the
+        // common instantiation, where the extra path costs 8 VGPRs and with them a wave of occupancy
+        if constexpr (LONG)
+            spring_row<D, LD, true>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mids, first_edge[i] - fe0,
+                                    la, i, Fs + (int64_t)i * LD);
+        else
+            spring_pull<D, LD, true>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mids, first_edge[i] - fe0);
         gh_store_row<LD>(Fs, i, F);
 #pragma unroll
         for (int d = 0; d < LD; ++d) {
@@ -100,13 +106,13 @@ __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const dou
 }
 
 
-template <int D, int LD, int R, int NT>
+template <int D, int LD, int R, int NT, bool LONG>
 __global__ __launch_bounds__(NT) void spring_scan_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
     const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
     const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
     float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
-    const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
+    const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, gh_long_args la) {
     constexpr int TILE = NT * R;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     constexpr int HITBUF = TILE * LD * 4 / 16;  // hit records reuse the midpoint tile's LDS
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     __shared__ double red[(NT / 64) * 2 * LD];
     {
         double sx[LD], sxx[LD];
-        gh_phase_a<D, LD, NT>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx);
+        gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx, la);
         gh_block_stats<LD, NT>(sx, sxx, red, blockstats);  // contains the barrier that ends phase A
     }
 
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
     float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
     const gh_h8 *__restrict__ qA, const int32_t *__restrict__ qexact, int S, uint64_t *__restrict__ cand,
-    int32_t *__restrict__ cnt) {
+    int32_t *__restrict__ cnt, gh_long_args la) {
     constexpr int LD = 4, NT = 256, TILE = NT * R, NB = 2 * R, HITBUF = 512;
     static_assert(D <= 3, "one 16-deep contraction holds three split coordinates");
     __shared__ float4 tile[TILE];                    // fp32 midpoints of the owned edges (x, y, z, 0)
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     __shared__ double red[(NT / 64) * 2 * LD];
     {
         double sx[LD], sxx[LD];
-        gh_phase_a<D, LD, NT>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx);
+        gh_phase_a<D, LD, NT, true>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx, la);
         gh_block_stats<LD, NT>(sx, sxx, red, blockstats);  // contains the barrier that ends phase A
     }
 
@@ -311,20 +317,27 @@ void launch_mfma(gh_engine *h) {
     spring_scan_mfma_kernel<D, R><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min,
         -h->prm.k_attr, h->d_Fs, h->d_new, h->d_blockstats, h->d_q, reinterpret_cast<const gh_h8 *>(h->d_qA),
-        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt);
+        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h));
+}
+
+template <int D, int LD, int R, int NT, bool LONG>
+void launch_l(gh_engine *h) {
+    spring_scan_kernel<D, LD, R, NT, LONG><<<dim3((unsigned)h->n_vblocks), dim3(NT), 0, h->stream>>>(
+        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
+        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h));
 }
 
 template <int D, int LD, int R, int NT>
 void launch(gh_engine *h) {
-    spring_scan_kernel<D, LD, R, NT><<<dim3((unsigned)h->n_vblocks), dim3(NT), 0, h->stream>>>(
-        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
-        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt);
+    if (gh_make_long_args(h).n > 0) launch_l<D, LD, R, NT, true>(h);
+    else launch_l<D, LD, R, NT, false>(h);
 }
 
 }  // namespace
 
 gh_status gh_launch_spring_scan(gh_engine *h) {
     if (h->n_vblocks == 0) return GH_OK;
+    GH_TRY_ST(gh_launch_spring_long(h, h->d_Fs, 0));  // hubs first: their rows' forces are read back in phase A
     gh_scope t(h, "spring_scan");
     int nt, r;
     fused_cfg(h->LD, h->D, h->own_count, &nt, &r);

@@ -58,10 +58,20 @@ def edge_owner_is_second(edge_ids):
     return (x >> np.uint64(31)) != 0
 
 
+LONG_DEG = 128  # csrc/common.h GH_LONG_DEG: rows with more neighbours are hubs
+
+
 def owned_edge_ids(edges, row_lo, row_hi):
-    """Ids of the edges a rank with rows [row_lo, row_hi) owns under the hashed rule."""
+    """Ids of the edges a rank with rows [row_lo, row_hi) owns under the hashed rule (vertex numbers as
+    given: an engine that reorders vertices internally partitions its internal rows the same way).
+    An edge between a hub and a short row belongs to the short row; otherwise the hash decides."""
     edges = np.asarray(edges).reshape(-1, 2)
     second = edge_owner_is_second(np.arange(len(edges)))
+    if len(edges):
+        is_hub = np.bincount(edges.ravel()) > LONG_DEG
+        hub_u, hub_v = is_hub[edges[:, 0]], is_hub[edges[:, 1]]
+        if is_hub.any():
+            second = np.where(hub_u != hub_v, hub_u, second)
     owner = np.where(second, edges[:, 1], edges[:, 0])
     return np.nonzero((owner >= row_lo) & (owner < row_hi))[0]
 

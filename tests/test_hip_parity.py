@@ -256,7 +256,8 @@ def test_device_sampler():
                                             (2, "hashed", 30011, 3), (3, "hashed", 30011, 3),
                                             (3, "hashed", 2001, 3),     # few edges: per-query search of d_mid
                                             (2, "hashed", 9001, 5),     # D without a templated spring kernel
-                                            (3, "hashed", 20001, 16)])
+                                            (3, "hashed", 20001, 16),
+                                            (3, "hashed-hubs", 30011, 3)])  # rows with thousands of neighbours
 def test_partitioned_engines_equal_single_engine(world, rule, n, D):
     """The split step (gh_step_begin / gh_step_merge / gh_step_finish) with row partitions: `world`
     engines on ONE GPU, collectives emulated with device copies, must reproduce the unpartitioned
@@ -267,6 +268,16 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D):
     from graphem_rapids_amd.distributed import HipShardEngine, owned_edge_ids, partition_edges, partition_rows
     k, S = 10, 256
     edges, pos, _ = _random_case(n - 1, D, 8, k, S, seed=21)  # last vertex isolated
+    if rule == "hashed-hubs":   # two hubs (in different row blocks) on top, and an edge between them
+        rule = "hashed"
+        rngh = np.random.default_rng(3)
+        extra = [np.array([[100, n - 50]])]
+        for hub, deg in ((100, 5000), (n - 50, 700)):
+            nb = rngh.choice(n - 1, size=deg, replace=False)
+            nb = nb[nb != hub]
+            extra.append(np.stack([np.minimum(hub, nb), np.maximum(hub, nb)], axis=1))
+        edges = np.ascontiguousarray(np.unique(np.concatenate([np.sort(edges.astype(np.int64), axis=1)] + extra), axis=0),
+                                     dtype=np.int32)
     pos = np.vstack([pos, np.zeros((1, D), np.float32)])
     rng = np.random.default_rng(4)
     stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(3)]).astype(np.int32)
