@@ -26,18 +26,22 @@
 // are resident and their gather / VALU phases interleave better.
 // GRAPHEM_HIP_FUSED_CFG="NT,R" overrides the LD = 4 default for experiments.
 // Small graphs get smaller tiles so that there are still >= ~1000 workgroups for 256 CUs.
-// The split-f16 MFMA form of the pre-filter is exact and tested, but opt-in (GRAPHEM_HIP_MFMA=1): the
-// fused kernel is bound by the random row gathers of its spring phase (128 us of the 1M-vertex
-// graph's 164 us with the scan switched off; the chip gathers 8M random 16-byte rows of a 16 MB
-// table in 108 us at best, tools/micro/gather_bench.hip), under which the packed-VALU scan already
-// hides; the MFMA form scans in 12 us instead of ~60 but its larger register and LDS footprint
-// (115 VGPRs, 35 KB) lowers the occupancy that the gathers need: 175 us in total against 164 us.
-static bool fused_mfma(int LD, int D) { return LD == 4 && D <= 3 && getenv("GRAPHEM_HIP_MFMA") != nullptr; }
-static void fused_cfg(int LD, int D, int64_t own_edges, int *nt, int *r) {
+// Which form of the pre-filter: the split-f16 MFMA form scans 1024 pairs per matrix instruction but
+// has the larger footprint (115 VGPRs, 35 KB of LDS) and the dearer hit path.  At the default 256
+// queries the fused kernel is bound by the spring phase's row gathers, under which the packed-VALU
+// scan hides (1M vertices: 147 us against 165 us for the MFMA form); with more queries the scan
+// shows and the MFMA form wins (S = 1024: 389 vs 436 us, S = 4096: 794 vs 1434 us; S = 512, k = 15:
+// still 307 vs 263 us).  GRAPHEM_HIP_MFMA=1 / =0 forces either form.
+static bool fused_mfma(int LD, int D, int64_t S) {
+    if (LD != 4 || D > 3) return false;
+    if (const char *e = getenv("GRAPHEM_HIP_MFMA")) return atoi(e) != 0;
+    return S >= 1024;
+}
+static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int *r) {
     *nt = 256;
     *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
     if (LD <= 4 && own_edges < 1500000) *r = 2;
-    if (LD <= 4 && own_edges < 400000 && !fused_mfma(LD, D)) *nt = 128;  // the MFMA form needs 256 threads
+    if (LD <= 4 && own_edges < 400000 && !fused_mfma(LD, D, S)) *nt = 128;  // the MFMA form needs 256 threads
     const char *e = getenv("GRAPHEM_HIP_FUSED_CFG");
     if (e && LD <= 4) {
         int a = 0, b = 0;
@@ -46,7 +50,7 @@ static void fused_cfg(int LD, int D, int64_t own_edges, int *nt, int *r) {
 }
 int gh_fused_tile(const gh_engine *h) {
     int nt, r;
-    fused_cfg(h->LD, h->D, h->own_count, &nt, &r);
+    fused_cfg(h->LD, h->D, h->S, h->own_count, &nt, &r);
     return nt * r;
 }
 
@@ -277,11 +281,20 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
                 for (int i = 2; i < 16; ++i) mn = min(mn, __float_as_int(f[i]));
                 asm volatile("" : "+v"(mn));  // opaque: else the compiler drops the tree for 16 tests + branches
                 if (mn <= 0) {  // rare: result row (i&3) + 8(i>>2) + 4*half, column = this lane's reference
-                    const int j = w * (64 * R) + b * 32 + col;
+                    // sign bits of the 16 values, f[0] in bit 15 ... f[15] in bit 0 (a candidate has F < 0:
+                    // the slack in C0 and T is twice the error bound), then one exact re-check per set bit
+                    uint32_t m = 0;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int s = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
-                        if (f[i] <= 0.0f && s < nq && j < nedges) park(s_lo, s, j);
+                    for (int i = 0; i < 16; ++i) m = __builtin_amdgcn_alignbit(m, __float_as_uint(f[i]), 31);
+                    const int j = w * (64 * R) + b * 32 + col;
+                    if (j < nedges) {
+                        while (m) {
+                            const int bit = 31 - __builtin_clz(m);
+                            m &= ~(1u << bit);
+                            const int i = 15 - bit;
+                            const int s = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
+                            if (s < nq) park(s_lo, s, j);
+                        }
                     }
                 }
                 f = fn;
@@ -340,14 +353,14 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
     GH_TRY_ST(gh_launch_spring_long(h, h->d_Fs, 0));  // hubs first: their rows' forces are read back in phase A
     gh_scope t(h, "spring_scan");
     int nt, r;
-    fused_cfg(h->LD, h->D, h->own_count, &nt, &r);
+    fused_cfg(h->LD, h->D, h->S, h->own_count, &nt, &r);
 #define GH_FUSED_D(NTT, RR)                                   \
     switch (h->D) {                                           \
         case 2: launch<2, 4, RR, NTT>(h); break;              \
         case 3: launch<3, 4, RR, NTT>(h); break;              \
         default: launch<4, 4, RR, NTT>(h); break;             \
     }
-    if (fused_mfma(h->LD, h->D) && nt == 256) {
+    if (fused_mfma(h->LD, h->D, h->S) && nt == 256) {
         if (r == 8) { if (h->D == 2) launch_mfma<2, 8>(h); else launch_mfma<3, 8>(h); }
         else if (r == 4) { if (h->D == 2) launch_mfma<2, 4>(h); else launch_mfma<3, 4>(h); }
         else { if (h->D == 2) launch_mfma<2, 2>(h); else launch_mfma<3, 2>(h); }

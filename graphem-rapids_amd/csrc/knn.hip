@@ -616,7 +616,9 @@ int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile) {
         const long v = atol(e);
         if (v >= 2 && v <= Mtot / (4 * (int64_t)K)) return v;
     }
-    int64_t r = (int64_t)sqrt(4.6 * (double)Mtot / ((double)S * K));
+    // beyond 256 queries the threshold kernel's workgroups no longer run all at once and its cost grows
+    // with S like the hits do, so the balance point stops moving
+    int64_t r = (int64_t)sqrt(4.6 * (double)Mtot / ((double)(S < 256 ? S : 256) * K));
     const int64_t by_list = 4096 / K;
     if (r > by_list) r = by_list;
     if (r > 256) r = 256;

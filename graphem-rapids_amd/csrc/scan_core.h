@@ -141,14 +141,14 @@ __device__ __forceinline__ void gh_flush_hits(const uint64_t *hkey, const int *h
 // eps = 2^-17 on both sides plus the absolute 2^-20 is twice that, and also covers the rounding of
 // the exact fma-chain distance the decision is finally taken on (gh_scan_queries' rare path, the
 // same here).  f16 range: pieces stay finite for |coordinate| <= GH_MF_RANGE and tau <= GH_MF_TAU_MAX
-// (C0 <= 3 * 64^2, |T| < 65504); anything outside is marked "never passes" (GH_MF_NEVER in the C0 or
+// (C0 <= 3 * 128^2 = 49152, |T| < 65504); anything outside is marked "never passes" (GH_MF_NEVER in the C0 or
 // -T slot, > any other term) and handled exactly by the caller: queries through the list qexact,
 // references by the lane that owns them.
 // Cost: 32 cycles of the matrix pipe + ~10 VALU instructions (min tree over the 16 accumulators,
 // compare, branch) per 1024 pairs, against 5 packed VALU instructions per 4 pairs per lane above.
 typedef _Float16 gh_h8 __attribute__((ext_vector_type(8)));
 typedef float gh_f16x __attribute__((ext_vector_type(16)));
-#define GH_MF_RANGE 64.0f
+#define GH_MF_RANGE 128.0f
 #define GH_MF_TAU_MAX 49000.0f
 #define GH_MF_NEVER 60000.0f
 #define GH_MF_EPS 7.62939453125e-06f   /* 2^-17 */

@@ -470,16 +470,14 @@ def _fused_step_keys(n, D, edges, pos, sampled, k):
     (50000, 3, 8, "some"),       # 1% of the vertices far outside the f16 range of the MFMA filter
     (5000, 3, 8, "all"),         # every coordinate outside it: exact scans only
     (50000, 3, 8, "tiny"),       # coordinates ~1e-4: distances near the absolute slack of the filter
+    (60000, 3, 8, "S1100"),      # 1100 queries: several query groups, the last one ragged (MFMA is the default form here)
 ])
 def test_fused_scan_knn_is_exact(form, n, D, deg, outliers, monkeypatch):
     """KNN of the fused spring+scan kernel (read back after gh_step_begin) against the oracle, for
-    both forms of its pre-filter: packed fp32 VALU (default) and split-f16 MFMA (GRAPHEM_HIP_MFMA=1).  The
+    both forms of its pre-filter: packed fp32 VALU (default below 1024 queries) and split-f16 MFMA.  The
     filter is conservative and the decision exact, so ids AND distance bits must be identical."""
-    if form == "mfma":
-        monkeypatch.setenv("GRAPHEM_HIP_MFMA", "1")
-    else:
-        monkeypatch.delenv("GRAPHEM_HIP_MFMA", raising=False)
-    k, S = 10, 256
+    monkeypatch.setenv("GRAPHEM_HIP_MFMA", "1" if form == "mfma" else "0")
+    k, S = 10, (1100 if outliers == "S1100" else 256)
     edges, pos, sampled = _random_case(n, D, deg, k, S, seed=101)
     rng = np.random.default_rng(7)
     if outliers == "some":
