@@ -360,11 +360,19 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
         gh_setup_item(sa, t, [=](int64_t v, int d) { return (nw[v * LD + d] - ms[d]) / ms[LD + d]; });
         return;
     }
-    const int64_t total = rows * LD;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)g_norm * blockDim.x) {
-        const int d = (int)(t % LD);
-        const float c = nw[t] - ms[d];
-        pos[row_lo * LD + t] = d < D ? c / ms[LD + d] : 0.0f;
+    // 16 bytes per thread and step (LD is a multiple of 4, rows are 16-byte aligned)
+    const int64_t total4 = rows * LD / 4;
+    const float4 *src = reinterpret_cast<const float4 *>(nw);
+    float4 *dst = reinterpret_cast<float4 *>(pos + row_lo * LD);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4; t += (int64_t)g_norm * blockDim.x) {
+        const int d0 = (int)((t * 4) % LD);
+        const float4 v = src[t];
+        float4 o;
+        o.x = d0 + 0 < D ? (v.x - ms[d0 + 0]) / ms[LD + d0 + 0] : 0.0f;
+        o.y = d0 + 1 < D ? (v.y - ms[d0 + 1]) / ms[LD + d0 + 1] : 0.0f;
+        o.z = d0 + 2 < D ? (v.z - ms[d0 + 2]) / ms[LD + d0 + 2] : 0.0f;
+        o.w = d0 + 3 < D ? (v.w - ms[d0 + 3]) / ms[LD + d0 + 3] : 0.0f;
+        dst[t] = o;
     }
 }
 
@@ -428,14 +436,19 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
         });
         return;
     }
-    const int64_t total = n * LD;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)g_norm * blockDim.x) {
-        const int64_t i = t / LD;
-        const int d = (int)(t % LD);
+    const int64_t total4 = n * LD / 4;  // 16 bytes per thread and step
+    float4 *dst = reinterpret_cast<float4 *>(pos);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4; t += (int64_t)g_norm * blockDim.x) {
+        const int64_t i = t * 4 / LD;
+        const int d0 = (int)((t * 4) % LD);
         const int64_t r = i / chunk;
-        const float *rowsrc = reinterpret_cast<const float *>(gbuf + r * slot);
-        const float c = rowsrc[(i - r * chunk) * LD + d] - ms[d];
-        pos[t] = d < D ? c / ms[LD + d] : 0.0f;
+        const float4 v = *reinterpret_cast<const float4 *>(gbuf + r * slot + ((i - r * chunk) * LD + d0) * sizeof(float));
+        float4 o;
+        o.x = d0 + 0 < D ? (v.x - ms[d0 + 0]) / ms[LD + d0 + 0] : 0.0f;
+        o.y = d0 + 1 < D ? (v.y - ms[d0 + 1]) / ms[LD + d0 + 1] : 0.0f;
+        o.z = d0 + 2 < D ? (v.z - ms[d0 + 2]) / ms[LD + d0 + 2] : 0.0f;
+        o.w = d0 + 3 < D ? (v.w - ms[d0 + 3]) / ms[LD + d0 + 3] : 0.0f;
+        dst[t] = o;
     }
 }
 
@@ -736,7 +749,7 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
     h->presetup_valid = false;  // positions change: whatever set-up was done ahead is stale
     if (h->rows == 0) return with_cleanup ? gh_launch_inter_cleanup(h) : GH_OK;
     gh_scope t(h, "normalise");
-    const int64_t total = h->rows * h->LD;
+    const int64_t total = h->rows * h->LD / 4;  // float4 elements
     unsigned grid = grid_for(total, 256);
     if (grid > 2048) grid = 2048;
     gh_setup_args sa{};
@@ -763,7 +776,7 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
 gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
     h->presetup_valid = false;
     gh_scope t(h, "normalise_gathered");
-    unsigned grid = grid_for(h->n * h->LD, 256);
+    unsigned grid = grid_for(h->n * h->LD / 4, 256);
     if (grid > 2048) grid = 2048;
     const bool presetup = next_mode >= 0 && h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused && h->S > 0 &&
                           h->k > 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
