@@ -321,13 +321,16 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
                                                        int32_t *__restrict__ tflag,
                                                        const int32_t *__restrict__ touched,
                                                        const int32_t *__restrict__ tcount, int nfix, int g_norm,
-                                                       gh_setup_args sa, int32_t *__restrict__ qexact) {
-    const bool setup_block = (int)blockIdx.x >= g_norm;
+                                                       int n_setup, gh_setup_args sa, int32_t *__restrict__ qexact) {
+    // the set-up workgroups come FIRST in the grid: their chains of dependent gathers start at once and
+    // run under the streaming of the others
+    const bool setup_block = (int)blockIdx.x < n_setup;
+    const int nb = (int)blockIdx.x - n_setup;  // index among the normalising workgroups
     // also zero what the intersection phase touched (acc != nullptr): the integrate kernel that
     // read those accumulators has finished; tcount itself is reset by the next KNN setup
     if (acc && !setup_block) {
         const int64_t nt = (int64_t)(*tcount) * LD;
-        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)g_norm * blockDim.x) {
+        for (int64_t t = nb * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)g_norm * blockDim.x) {
             const int64_t x = touched[t / LD];
             const int d = (int)(t % LD);
             acc[x * LD + d] = 0.0;
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
     }
     __syncthreads();
     if (setup_block) {
-        const int64_t t = ((int64_t)blockIdx.x - g_norm) * blockDim.x + threadIdx.x;
+        const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (t == 0) qexact[0] = 0;
         // position of vertex v, component d < D, exactly as the normalising threads below compute it
         gh_setup_item(sa, t, [=](int64_t v, int d) { return (nw[v * LD + d] - ms[d]) / ms[LD + d]; });
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
     const int64_t total4 = rows * LD / 4;
     const float4 *src = reinterpret_cast<const float4 *>(nw);
     float4 *dst = reinterpret_cast<float4 *>(pos + row_lo * LD);
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4; t += (int64_t)g_norm * blockDim.x) {
+    for (int64_t t = nb * (int64_t)blockDim.x + threadIdx.x; t < total4; t += (int64_t)g_norm * blockDim.x) {
         const int d0 = (int)((t * 4) % LD);
         const float4 v = src[t];
         float4 o;
@@ -385,11 +388,13 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
                                                                 double *__restrict__ acc, int32_t *__restrict__ tflag,
                                                                 const int32_t *__restrict__ touched,
                                                                 const int32_t *__restrict__ tcount, int g_norm,
-                                                                gh_setup_args sa, int32_t *__restrict__ qexact) {
-    const bool setup_block = (int)blockIdx.x >= g_norm;  // the next iteration's KNN set-up, as in normalise_kernel
+                                                                int n_setup, gh_setup_args sa,
+                                                                int32_t *__restrict__ qexact) {
+    const bool setup_block = (int)blockIdx.x < n_setup;  // the next iteration's KNN set-up, as in normalise_kernel
+    const int nb = (int)blockIdx.x - n_setup;
     if (!setup_block) {
         const int64_t nt = (int64_t)(*tcount) * LD;
-        for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)g_norm * blockDim.x) {
+        for (int64_t t = nb * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)g_norm * blockDim.x) {
             const int64_t x = touched[t / LD];
             const int d = (int)(t % LD);
             acc[x * LD + d] = 0.0;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
     }
     __syncthreads();
     if (setup_block) {
-        const int64_t t = ((int64_t)blockIdx.x - g_norm) * blockDim.x + threadIdx.x;
+        const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (t == 0) qexact[0] = 0;
         gh_setup_item(sa, t, [=](int64_t v, int d) {
             const int64_t r = v / chunk;
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
     }
     const int64_t total4 = n * LD / 4;  // 16 bytes per thread and step
     float4 *dst = reinterpret_cast<float4 *>(pos);
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total4; t += (int64_t)g_norm * blockDim.x) {
+    for (int64_t t = nb * (int64_t)blockDim.x + threadIdx.x; t < total4; t += (int64_t)g_norm * blockDim.x) {
         const int64_t i = t * 4 / LD;
         const int d0 = (int)((t * 4) % LD);
         const int64_t r = i / chunk;
@@ -760,8 +765,8 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
     }
     normalise_kernel<<<dim3(grid + extra), dim3(256), sizeof(float) * 2 * h->LD, h->stream>>>(
         h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos,
-        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount, gh_fix_blocks(h->LD), (int)grid, sa,
-        h->d_qexact);
+        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount, gh_fix_blocks(h->LD), (int)grid,
+        (int)extra, sa, h->d_qexact);
     GH_LAUNCH_CHECK();
     if (presetup) {
         h->presetup_valid = true;
@@ -789,7 +794,7 @@ gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
     const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * h->LD * (size_t)h->g_world;
     normalise_gathered_kernel<<<dim3(grid + extra), dim3(256), smem, h->stream>>>(
         h->d_gbuf, h->g_slot, h->g_chunk, h->g_world, h->D, h->LD, h->n, gh_fix_blocks(h->LD), h->d_pos, h->d_acc,
-        h->d_tflag, h->d_touched, h->d_tcount, (int)grid, sa, h->d_qexact);
+        h->d_tflag, h->d_touched, h->d_tcount, (int)grid, (int)extra, sa, h->d_qexact);
     GH_LAUNCH_CHECK();
     if (presetup) {
         h->presetup_valid = true;
