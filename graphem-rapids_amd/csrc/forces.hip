@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(
     __syncthreads();
     if (threadIdx.x < 2 * LD) {
         const double v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        blockstats[(int64_t)blockIdx.x * 2 * LD + threadIdx.x] = v;
+        blockstats[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;  // [entry][workgroup]: the reducers read contiguously
     }
 }
 
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void stats_reduce_kernel(const double *__restr
                                                           double *__restrict__ stats) {
     const int c = blockIdx.x;  // column of the (2*LD) record
     double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += blockstats[(int64_t)b * 2 * LD + c];
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += blockstats[(int64_t)c * nblocks + b];
     __shared__ double red[4];
     const double a = gh_wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
     {
         const int c = blockIdx.x;  // gridDim.x == 2 * LD
         double s = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += blockstats[(int64_t)b * 2 * LD + c];
+        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += blockstats[(int64_t)c * nblocks + b];
         const double a = gh_wave_sum(s);
         if (lane == 0) red[w][0] = a;
         __syncthreads();

@@ -90,7 +90,7 @@ __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const 
     }
 }
 
-// Workgroup reduction of the per-thread column sums -> blockstats[blockIdx.x][2*LD] (fixed order).
+// Workgroup reduction of the per-thread column sums -> blockstats[entry][blockIdx.x], entry < 2*LD (fixed order).
 template <int LD, int NT>
 __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const double (&sxx)[LD], double *red /* [NT/64][2*LD] */,
                                                double *__restrict__ blockstats) {
@@ -105,7 +105,7 @@ __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const dou
         double v = red[threadIdx.x];
 #pragma unroll
         for (int ww = 1; ww < NT / 64; ++ww) v += red[ww * 2 * LD + threadIdx.x];
-        blockstats[(int64_t)blockIdx.x * 2 * LD + threadIdx.x] = v;
+        blockstats[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;  // [entry][workgroup]: the reducers read contiguously
     }
 }
 
