@@ -26,16 +26,18 @@
 // are resident and their gather / VALU phases interleave better.
 // GRAPHEM_HIP_FUSED_CFG="NT,R" overrides the LD = 4 default for experiments.
 // Small graphs get smaller tiles so that there are still >= ~1000 workgroups for 256 CUs.
-// Which form of the pre-filter: the split-f16 MFMA form scans 1024 pairs per matrix instruction but
-// has the larger footprint (115 VGPRs, 35 KB of LDS) and the dearer hit path.  At the default 256
-// queries the fused kernel is bound by the spring phase's row gathers, under which the packed-VALU
-// scan hides (1M vertices: 147 us against 165 us for the MFMA form); with more queries the scan
-// shows and the MFMA form wins (S = 1024: 389 vs 436 us, S = 4096: 794 vs 1434 us; S = 512, k = 15:
-// still 307 vs 263 us).  GRAPHEM_HIP_MFMA=1 / =0 forces either form.
+// Which form of the pre-filter.  The split-f16 MFMA form scans 1024 pairs per matrix instruction; it
+// has the larger footprint (115 VGPRs, 35 KB of LDS against 75 and 22 KB), which costs the spring
+// phase's gathers a wave of occupancy, and wins all the same: 1M vertices, 256 queries: 4410 vs 4300
+// it/s over the first 55 iterations and 4700 vs 4440 in the steady state of a long run
+// (tools/soak_s.py); 100K vertices 10760 vs 9730; 1024 queries 433 vs 566 us per iteration, 4096
+// queries 640 vs 1434 us for the kernel.  GRAPHEM_HIP_MFMA=0 selects the packed-VALU form (D <= 3;
+// D = 4 and the LD = 8 / 16 kernels always use it).
 static bool fused_mfma(int LD, int D, int64_t S) {
+    (void)S;
     if (LD != 4 || D > 3) return false;
     if (const char *e = getenv("GRAPHEM_HIP_MFMA")) return atoi(e) != 0;
-    return S >= 1024;
+    return true;
 }
 static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int *r) {
     *nt = 256;

@@ -474,7 +474,7 @@ def _fused_step_keys(n, D, edges, pos, sampled, k):
 ])
 def test_fused_scan_knn_is_exact(form, n, D, deg, outliers, monkeypatch):
     """KNN of the fused spring+scan kernel (read back after gh_step_begin) against the oracle, for
-    both forms of its pre-filter: packed fp32 VALU (default below 1024 queries) and split-f16 MFMA.  The
+    both forms of its pre-filter: split-f16 MFMA (default for D <= 3) and packed fp32 VALU.  The
     filter is conservative and the decision exact, so ids AND distance bits must be identical."""
     monkeypatch.setenv("GRAPHEM_HIP_MFMA", "1" if form == "mfma" else "0")
     k, S = 10, (1100 if outliers == "S1100" else 256)
