@@ -193,9 +193,10 @@ def main():
                     roofline["traffic_rate_GBps"] = tb / (scan_us * 1e-6) / 1e9
                     roofline["traffic_frac_of_peak"] = tb / (scan_us * 1e-6) / HBM_PEAK
             # the same kernel's arithmetic side (F_knn = 3 D S E per launch) against the fp32 vector
-            # peak (= dense fp32 MFMA peak); the pre-filter spends fewer instructions per pair than this count
+            # peak (= dense fp32 MFMA peak): the precision the result is exact in; the pre-filter itself runs on the
+            # f16 matrix pipe and spends far fewer instructions per pair than this count
             flops_scan = 3.0 * D * S * E_rank
-            knn_fp32 = {"kernel": dom, "bound": "mfma", "pipe": "fp32 VALU, packed v_pk_*_f32",
+            knn_fp32 = {"kernel": dom, "bound": "mfma", "pipe": "pre-filter on v_mfma_f32_32x32x16_f16 with split-f16 operands (D <= 3), packed fp32 VALU otherwise; exact fp32 re-check",
                         "achieved": flops_scan / (scan_us * 1e-6) / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
                         "frac": flops_scan / (scan_us * 1e-6) / FP32_PEAK, "algorithmic_flops_per_launch": flops_scan}
         b_iter = 16.0 * E + 36.0 * n * D                       # B_iter = 16E + 36nD
