@@ -200,13 +200,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     __shared__ float4 qrec[GH_SCAN_QGROUP];          // (q_0, q_1, q_2, tau) for the exact re-check
     __shared__ uint64_t hkey[HITBUF];
     __shared__ int hq[HITBUF];
-    __shared__ int hcount;
+    __shared__ uint16_t badlist[TILE];               // references outside the f16 range of the filter
+    __shared__ int hcount, nbad;
     float *mids = reinterpret_cast<float *>(tile);
 
     const int v0 = vblock[blockIdx.x], v1 = vblock[blockIdx.x + 1];
     const int fe0 = first_edge[v0];
     const int nedges = first_edge[v1] - fe0;
-    if (threadIdx.x == 0) hcount = 0;
+    if (threadIdx.x == 0) { hcount = 0; nbad = 0; }
 
     __shared__ double red[(NT / 64) * 2 * LD];
     {
@@ -220,15 +221,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int col = lane & 31, hsel = lane >> 5;
     gh_h8 B[NB];
-    uint32_t bad = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int j = w * (64 * R) + b * 32 + col;
         const float4 mv4 = tile[j < nedges ? j : 0];
         const float mv[3] = {mv4.x, mv4.y, mv4.z};
-        if (!gh_mf_ref_col(mv, j < nedges, hsel, B[b])) bad |= 1u << b;
+        // out of the f16 range: listed, and scanned exactly by the whole workgroup after each query group
+        if (!gh_mf_ref_col(mv, j < nedges, hsel, B[b]) && hsel == 0) badlist[atomicAdd(&nbad, 1)] = (uint16_t)j;
     }
-    if (hsel) bad = 0;
 
     auto park = [&](int s_lo, int s, int j) {  // exact decision on pair (query s of the group, reference j)
         const float4 qr = qrec[s];
@@ -309,18 +309,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
             if (s < 0 || s >= nq) continue;
             for (int j = threadIdx.x; j < nedges; j += NT) park(s_lo, s, j);
         }
-        // ... and of this lane's out-of-range references against every query of the group
-        if (bad) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if (!(bad >> b & 1u)) continue;
-                const int j = w * (64 * R) + b * 32 + col;
-                for (int s = 0; s < nq; ++s) {
-                    const gh_h8 hi = qa[2 * s + 1];
-                    if ((float)hi[4] == GH_MF_NEVER) continue;  // a listed query: the loop above has done this pair
-                    park(s_lo, s, j);
-                }
-            }
+        // ... and of the tile's out-of-range references against every query of the group: all threads, one
+        // pair each (a layout in which a hub has flown off takes thousands of midpoints out of range)
+        const int nb_ = nbad;  // complete: the staging barrier of this group came after the B operands were built
+        for (int p = threadIdx.x; p < nb_ * nq; p += NT) {
+            const int s = p % nq;
+            const gh_h8 hi = qa[2 * s + 1];
+            if ((float)hi[4] == GH_MF_NEVER) continue;  // a listed query: the loop above has done this pair
+            park(s_lo, s, badlist[p / nq]);
         }
     }
     __syncthreads();
