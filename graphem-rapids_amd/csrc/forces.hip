@@ -271,7 +271,16 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
     {
         const int c = blockIdx.x;  // gridDim.x == 2 * LD
         double s = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += blockstats[(int64_t)c * nblocks + b];
+        // four independent partial sums per thread (loads in flight), combined in a fixed order
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        const double *col = blockstats + (int64_t)c * nblocks;
+        int b = threadIdx.x;
+        for (; b + 3 * (int)blockDim.x < nblocks; b += 4 * blockDim.x) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += col[b + u * blockDim.x];
+        }
+        for (int u = 0; b < nblocks; b += blockDim.x, ++u) s4[u] += col[b];
+        s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         const double a = gh_wave_sum(s);
         if (lane == 0) red[w][0] = a;
         __syncthreads();

@@ -42,7 +42,7 @@ static bool fused_mfma(int LD, int D, int64_t S) {
 static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int *r) {
     *nt = 256;
     *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
-    if (LD <= 4 && own_edges < 1500000) *r = 2;
+    if (LD <= 4 && (own_edges < 1500000 || fused_mfma(LD, D, S))) *r = 2;  // MFMA form: 95 VGPRs / 27 KB instead of 115 / 37
     if (LD <= 4 && own_edges < 400000 && !fused_mfma(LD, D, S)) *nt = 128;  // the MFMA form needs 256 threads
     const char *e = getenv("GRAPHEM_HIP_FUSED_CFG");
     if (e && LD <= 4) {
