@@ -201,6 +201,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     __shared__ uint64_t hkey[HITBUF];
     __shared__ int hq[HITBUF];
     __shared__ uint16_t badlist[TILE];               // references outside the f16 range of the filter
+    __shared__ uint32_t ids[TILE];                   // edge ids of the tile's references (the exact path must not wait for memory)
     __shared__ int hcount, nbad;
     float *mids = reinterpret_cast<float *>(tile);
 
@@ -241,12 +242,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
             d2 = fmaf(df, df, d2);
         }
         if (d2 <= qr.w) {
-            const uint32_t id = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
+            const uint32_t id = ids[j];
             const int p = atomicAdd(&hcount, 1);
             if (p < HITBUF) { hkey[p] = gh_key(d2, id); hq[p] = s_lo + s; }
             else gh_append_candidate(cand, cnt, s_lo + s, gh_key(d2, id));
         }
     };
+    for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
+    // (visible to every thread after the staging barrier of the first query group)
 
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
