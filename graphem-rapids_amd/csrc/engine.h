@@ -151,6 +151,7 @@ gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq,
                                int D, int K, uint64_t *d_keys, std::string *err);
 // fused.hip
 gh_status gh_radial_topk_device(gh_engine *h, int K, uint64_t *d_part, int nparts, int32_t *d_ids);
+bool gh_fused_uses_mfma(const gh_engine *h);       // the fused kernel's pre-filter runs on the matrix pipe
 int gh_fused_tile(const gh_engine *h);              // edges per fused workgroup
 gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world);  // -> d_keys_cur

@@ -50,6 +50,7 @@ static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int 
         if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 128 || a == 256) && (b == 2 || b == 4 || b == 8)) { *nt = a; *r = b; }
     }
 }
+bool gh_fused_uses_mfma(const gh_engine *h) { return h->fused_scan && fused_mfma(h->LD, h->D, h->S); }
 int gh_fused_tile(const gh_engine *h) {
     int nt, r;
     fused_cfg(h->LD, h->D, h->S, h->own_count, &nt, &r);

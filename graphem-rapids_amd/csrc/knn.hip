@@ -611,14 +611,15 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
 // 81 for the 1M-vertex graph (M = 4M), 26 for M = 400K.  Bounds: the list holds GH_CAND_CAP
 // candidates (mean K*stride kept <= 4096), a workgroup parks its hits in LDS (mean
 // S*K*stride*tile/M kept near 300 for a buffer of >= 1024), and the subset stays well above K rows.
-int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile) {
+int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile, bool mfma) {
     if (const char *e = getenv("GRAPHEM_HIP_SUBSET_STRIDE")) {  // tuning override
         const long v = atol(e);
         if (v >= 2 && v <= Mtot / (4 * (int64_t)K)) return v;
     }
     // beyond 256 queries the threshold kernel's workgroups no longer run all at once and its cost grows
     // with S like the hits do, so the balance point stops moving
-    int64_t r = (int64_t)sqrt(4.6 * (double)Mtot / ((double)(S < 256 ? S : 256) * K));
+    // (the MFMA form's hits cost less than half as much -- ~0.1 us per unit of stride -- so its balance sits higher)
+    int64_t r = (int64_t)sqrt((mfma ? 7.0 : 4.6) * (double)Mtot / ((double)(S < 256 ? S : 256) * K));
     const int64_t by_list = 4096 / K;
     if (r > by_list) r = by_list;
     if (r > 256) r = 256;
@@ -655,7 +656,7 @@ bool gh_knn_scan_path(const gh_engine *h) {
 gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint64_t iter) {
     const int64_t Mtot = own_edges(h);
     const bool scan = gh_knn_scan_path(h);
-    const int64_t st = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h)) : 1;
+    const int64_t st = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h)) : 1;
     const int64_t M1 = scan ? (Mtot + st - 1) / st : 0;
     return gh_setup_args{h->d_edges, sampled, mode, h->E, h->prm.seed, iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
                          h->d_ovf, h->part.edge_lo, h->d_own_eids, M1, st, h->d_midsub};
@@ -682,7 +683,7 @@ gh_status gh_knn_prepare(gh_engine *h) {
 // tau of every query from the compact subset (gh_knn_prepare made it).  Needs gh_knn_scan_path(h).
 gh_status gh_knn_thresholds(gh_engine *h) {
     const int64_t Mtot = own_edges(h);
-    const int64_t st = subset_stride(Mtot, h->K, h->S, gh_fused_tile(h));
+    const int64_t st = subset_stride(Mtot, h->K, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h));
     const int64_t M1 = (Mtot + st - 1) / st;
     const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
     gh_scope t(h, "knn_threshold");
