@@ -12,10 +12,12 @@ adj = gra.edges_to_adjacency(n, gra.random_regular_edges(n, 8, seed=0))
 laplacian_embedding_hip(gra.generate_random_regular(1000, 4, 0), 2)  # warm-up (library load)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-emb, info = laplacian_embedding_hip(adj, D, return_info=True)
+method = "lanczos" if "--lanczos" in sys.argv else "trlan"
+emb, info = laplacian_embedding_hip(adj, D, return_info=True, method=method)
 torch.cuda.synchronize()
 t_gpu = time.perf_counter() - t0
-print(f"n={n}: GPU Lanczos {t_gpu:.3f} s, {info['steps']} steps, converged={info['converged']}, eigenvalues={info['eigenvalues']}")
+print(f"n={n}: GPU {method} {t_gpu:.3f} s, {info['steps']} steps, {info['runs']} runs, converged={info['converged']}, "
+      f"eigenvalues={info['eigenvalues']}, residuals={info['residuals']}", flush=True)
 if "--scipy" in sys.argv:
     sym = sp.csr_matrix(adj + adj.T); sym.data = np.ones_like(sym.data)
     L = laplacian(sym, normed=True)
