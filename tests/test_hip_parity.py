@@ -530,3 +530,69 @@ def test_skewed_degrees_hubs(reorder):
     eng.run(3)                      # device sampler on the same paths
     assert np.isfinite(eng.get_positions()).all()
     eng.close()
+
+
+def _random_simple_graph(rng, n, m):
+    """m distinct undirected edges u < v on n vertices (fewer if the graph is too small), CSR order."""
+    u = rng.integers(0, n, size=3 * m + 8)
+    v = rng.integers(0, n, size=3 * m + 8)
+    keep = u != v
+    e = np.unique(np.stack([np.minimum(u, v)[keep], np.maximum(u, v)[keep]], axis=1), axis=0)
+    if len(e) > m:
+        e = e[np.sort(rng.permutation(len(e))[:m])]
+    return np.ascontiguousarray(e, dtype=np.int32)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_small_configurations(seed):
+    """Fuzz of the per-query / generic kernels: random sparse graphs (isolated vertices, uneven degrees), random
+    dimension, neighbour count and sample size, including S >= E (no sampling) and k + 1 == E."""
+    from graphem_rapids_amd import _native
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(6, 400))
+    edges = _random_simple_graph(rng, n, int(rng.integers(3, 4 * n)))
+    E = len(edges)
+    D = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 13, 16, 20]))
+    k = int(rng.integers(1, min(E - 1, 40) + 1)) if E > 1 else 0
+    if seed % 6 == 0 and E > 1:
+        k = E - 1                                   # k + 1 == E: every edge is a neighbour
+    S = int(rng.integers(1, 2 * E + 2))              # S >= E: the engine uses every edge (pt.py:412)
+    pos = (rng.standard_normal((n, D)) * rng.choice([0.05, 1.0, 30.0])).astype(np.float32)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, min(S, E))
+    eng.set_positions(pos)
+    sampled = np.arange(E, dtype=np.int32) if S >= E else rng.permutation(E)[:S].astype(np.int32)
+    assert np.array_equal(eng.spring_forces(), oracle.spring_forces(pos, edges, 1.0, 0.2))
+    if k > 0:
+        assert np.array_equal(eng.knn_midpoints(sampled), oracle.knn_midpoints(pos, edges, sampled, k))
+    eng.step(None if S >= E else sampled)
+    ref = oracle.step(pos, edges, sampled, k, 1.0, 0.2, 0.5)
+    got = eng.get_positions()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() <= 2e-4, (n, E, D, k, S)
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_fused_configurations(seed):
+    """Fuzz of the fused spring+scan path (>= 16K own edges): random dimension among the templated ones,
+    neighbour count up to 63, sample size up to 700, uneven degrees, optional internal reordering."""
+    from graphem_rapids_amd import _native
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(4000, 30000))
+    edges = _random_simple_graph(rng, n, int(rng.integers(17000, 90000)))
+    E = len(edges)
+    D = int(rng.choice([2, 3, 3, 3, 4, 8, 16]))
+    k = int(rng.choice([1, 5, 10, 15, 31, 32, 63]))
+    S = int(rng.choice([1, 7, 64, 256, 257, 512, 700]))
+    pos = (rng.standard_normal((n, D)) * rng.choice([0.1, 1.0, 5.0])).astype(np.float32)
+    sampled = rng.permutation(E)[:S].astype(np.int32)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, reorder=("bfs" if seed % 2 else "off"))
+    eng.set_positions(pos)
+    assert np.array_equal(eng.spring_forces(), oracle.spring_forces(pos, edges, 1.0, 0.2))
+    assert np.array_equal(eng.knn_midpoints(sampled), oracle.knn_midpoints(pos, edges, sampled, k))
+    eng.step(sampled)
+    ref = oracle.step(pos, edges, sampled, k, 1.0, 0.2, 0.5)
+    assert np.abs(eng.get_positions() - ref).max() <= 2e-4, (n, E, D, k, S)
+    eng.run(3)
+    assert np.isfinite(eng.get_positions()).all()
+    eng.close()
