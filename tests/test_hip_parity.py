@@ -596,3 +596,56 @@ def test_random_fused_configurations(seed):
     eng.run(3)
     assert np.isfinite(eng.get_positions()).all()
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_partitioned_configurations(seed):
+    """Fuzz of the multi-rank split step on one GPU: random world size, graph (uneven degrees, sometimes a hub),
+    dimension, neighbour count; device sampler on every rank (ids must agree) for two of the three iterations."""
+    import torch
+    from graphem_rapids_amd import _native
+    from graphem_rapids_amd.distributed import HipShardEngine, partition_rows
+    rng = np.random.default_rng(3000 + seed)
+    world = int(rng.choice([2, 3, 5]))
+    n = int(rng.integers(6000, 25000))
+    edges = _random_simple_graph(rng, n, int(rng.integers(20000, 70000)))
+    if seed % 2:
+        hub = int(rng.integers(0, n))
+        nb = rng.choice(n, size=1500, replace=False)
+        nb = nb[nb != hub]
+        extra = np.stack([np.minimum(hub, nb), np.maximum(hub, nb)], axis=1)
+        edges = np.ascontiguousarray(np.unique(np.concatenate([edges.astype(np.int64), extra]), axis=0), dtype=np.int32)
+    D = int(rng.choice([2, 3, 3, 4, 8]))
+    k, S = int(rng.choice([5, 10, 20])), int(rng.choice([64, 256, 300]))
+    pos = rng.standard_normal((n, D)).astype(np.float32)
+    first = rng.permutation(len(edges))[:S].astype(np.int32)
+    single = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=7)
+    single.set_positions(pos)
+    single.step(first)
+    single.run(2)                      # device sampler, iterations 1 and 2
+    ref = single.get_positions()
+    single.close()
+    shards = []
+    for r in range(world):
+        chunk, lo, hi = partition_rows(n, world, r)
+        sh = HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 7, (lo, hi, 0, 0, _native.EDGES_HASHED), 0)
+        sh.gather_layout(world, r, chunk)
+        sh.set_positions(pos)
+        shards.append(sh)
+    for t in range(3):
+        for sh in shards:
+            sh.step_begin(first if t == 0 else None)
+        gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()
+        for sh in shards:
+            sh.step_merge(gathered, world)
+        slots = torch.stack([sh.gbuf[r].clone() for r, sh in enumerate(shards)])
+        for sh in shards:
+            sh.gbuf.copy_(slots)
+            sh.step_finish_gathered()
+    torch.cuda.synchronize()
+    outs = [sh.get_positions() for sh in shards]
+    for sh in shards:
+        sh.eng.close()
+    assert np.abs(outs[0] - ref).max() <= 5e-6, (world, n, len(edges), D, k, S)
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
