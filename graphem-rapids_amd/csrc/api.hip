@@ -287,7 +287,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     std::vector<int32_t> vblock;
     {
         const int tile = gh_fused_tile(h);
-        const bool dim_ok = D == 2 || D == 3 || D == 4 || D == 8 || D == 16;
+        const bool dim_ok = gh_dim_templated(D);
         bool ok = h->fused_mid && dim_ok;
         if (ok) {
             vblock.push_back(0);

@@ -149,6 +149,18 @@ __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const
 }
 
 
+// Embedding dimensions with compile-time kernels (spring pull, fused spring+scan, hub sums, intersection
+// pairs): every D from 2 to 16, so that e.g. n_components = 6 does not fall onto the generic
+// one-thread-per-vertex kernels (2.4-2.8x slower at 1M vertices); larger D use those.  The norm order (gh_sumsq<D>) is the reference's for every D, so each D is its own
+// instantiation rather than a padded neighbour.
+__host__ __device__ inline bool gh_dim_templated(int D) {
+    return D >= 2 && D <= 16;
+}
+// X(D, LD) for every templated dimension
+#define GH_FOR_EACH_DIM(X)                                                                                    \
+    X(2, 4) X(3, 4) X(4, 4) X(5, 8) X(6, 8) X(7, 8) X(8, 8) X(9, 16) X(10, 16) X(11, 16) X(12, 16) X(13, 16) X(14, 16) \
+        X(15, 16) X(16, 16)
+
 // ---------------------------------------------------------------------------------
 // Long rows (hubs).  A thread walking a pull list of thousands of entries eight gathers at a time
 // holds its whole workgroup up for milliseconds, so rows with more than GH_LONG_DEG neighbours get

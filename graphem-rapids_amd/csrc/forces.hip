@@ -559,7 +559,7 @@ __global__ void arange_kernel(int64_t S, int32_t *__restrict__ sampled) {
 
 inline unsigned grid_for(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
 
-bool spring_is_templated(int D) { return D == 2 || D == 3 || D == 4 || D == 8 || D == 16; }
+bool spring_is_templated(int D) { return gh_dim_templated(D); }
 
 // WRITE_MID only when the engine's edge range follows row ownership (h->fused_mid).
 template <bool WRITE_MID>
@@ -573,17 +573,15 @@ gh_status launch_spring(gh_engine *h, float *outF, int64_t f_row0) {
     if (la.n > 0) spring_kernel<DD, LL, WRITE_MID, true><<<dim3(grid), dim3(256), 0, h->stream>>>(GH_SPRING_ARGS); \
     else spring_kernel<DD, LL, WRITE_MID, false><<<dim3(grid), dim3(256), 0, h->stream>>>(GH_SPRING_ARGS)
     GH_TRY_ST(gh_launch_spring_long(h, outF, f_row0));  // hubs first: spring_row reads their forces back
+#define GH_SPRING_ONE(DD, LL) case DD: GH_SPRING_CASE(DD, LL); break;
     switch (h->D) {
-        case 2: GH_SPRING_CASE(2, 4); break;
-        case 3: GH_SPRING_CASE(3, 4); break;
-        case 4: GH_SPRING_CASE(4, 4); break;
-        case 8: GH_SPRING_CASE(8, 8); break;
-        case 16: GH_SPRING_CASE(16, 16); break;
+        GH_FOR_EACH_DIM(GH_SPRING_ONE)
         default:
             spring_generic_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(
                 h->d_pos, h->D, h->LD, h->d_rowptr, h->d_adj, h->part.row_lo, h->rows, h->prm.L_min, neg_k, outF,
                 f_row0, h->d_tmpF2);
     }
+#undef GH_SPRING_ONE
 #undef GH_SPRING_CASE
 #undef GH_SPRING_ARGS
     GH_LAUNCH_CHECK();
@@ -592,7 +590,7 @@ gh_status launch_spring(gh_engine *h, float *outF, int64_t f_row0) {
 
 }  // namespace
 
-static bool spring_is_templated_d(int D) { return D == 2 || D == 3 || D == 4 || D == 8 || D == 16; }
+static bool spring_is_templated_d(int D) { return gh_dim_templated(D); }
 
 gh_long_args gh_make_long_args(const gh_engine *h) {
     if (h->nlong == 0 || !spring_is_templated_d(h->D)) return gh_long_args{nullptr, nullptr, nullptr, 0};
@@ -610,13 +608,12 @@ gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0) {
         h->d_pos, h->d_rowptr, h->d_adj, la.rows, h->d_long_eptr, la.n, h->part.row_lo, h->prm.L_min, neg_k, h->d_long_terms); \
     long_sum_kernel<DD, LL><<<dim3((unsigned)((la.n + 3) / 4)), dim3(256), 0, h->stream>>>(h->d_long_terms, la.rows,   \
                                                                                           h->d_long_eptr, la.n, outF, f_row0)
+#define GH_LONG_ONE(DD, LL) case DD: GH_LONG_CASE(DD, LL); break;
     switch (h->D) {
-        case 2: GH_LONG_CASE(2, 4); break;
-        case 3: GH_LONG_CASE(3, 4); break;
-        case 4: GH_LONG_CASE(4, 4); break;
-        case 8: GH_LONG_CASE(8, 8); break;
-        default: GH_LONG_CASE(16, 16); break;
+        GH_FOR_EACH_DIM(GH_LONG_ONE)
+        default: break;  // gh_make_long_args returns none for other dimensions
     }
+#undef GH_LONG_ONE
 #undef GH_LONG_CASE
     GH_LAUNCH_CHECK();
     return GH_OK;

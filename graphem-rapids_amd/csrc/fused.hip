@@ -374,9 +374,23 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
         else if (nt == 128 && r == 4) { GH_FUSED_D(128, 4) }
         else { GH_FUSED_D(128, 2) }
     } else if (h->LD == 8) {
-        launch<8, 8, 4, 256>(h);
+        switch (h->D) {
+            case 5: launch<5, 8, 4, 256>(h); break;
+            case 6: launch<6, 8, 4, 256>(h); break;
+            case 7: launch<7, 8, 4, 256>(h); break;
+            default: launch<8, 8, 4, 256>(h); break;
+        }
     } else if (h->LD == 16) {
-        launch<16, 16, 2, 256>(h);
+        switch (h->D) {
+            case 9: launch<9, 16, 2, 256>(h); break;
+            case 10: launch<10, 16, 2, 256>(h); break;
+            case 11: launch<11, 16, 2, 256>(h); break;
+            case 12: launch<12, 16, 2, 256>(h); break;
+            case 13: launch<13, 16, 2, 256>(h); break;
+            case 14: launch<14, 16, 2, 256>(h); break;
+            case 15: launch<15, 16, 2, 256>(h); break;
+            default: launch<16, 16, 2, 256>(h); break;
+        }
     } else {
         h->err = "fused spring+scan launched for an unsupported dimension";
         return GH_ERR_RUNTIME;

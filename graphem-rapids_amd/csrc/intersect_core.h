@@ -80,12 +80,11 @@ __device__ __forceinline__ void gh_intersect_pair_any(const float *__restrict__ 
                                                       float k_inter, double *__restrict__ acc,
                                                       int32_t *__restrict__ tflag, int32_t *__restrict__ touched,
                                                       int32_t *__restrict__ tcount, float *__restrict__ diff) {
+#define GH_INTERSECT_ONE(DD, LL) \
+    case DD: gh_intersect_pair_t<DD, LL>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
     switch (D) {
-        case 2: gh_intersect_pair_t<2, 4>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
-        case 3: gh_intersect_pair_t<3, 4>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
-        case 4: gh_intersect_pair_t<4, 4>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
-        case 8: gh_intersect_pair_t<8, 8>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
-        case 16: gh_intersect_pair_t<16, 16>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount); break;
+        GH_FOR_EACH_DIM(GH_INTERSECT_ONE)
         default: gh_intersect_pair(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, diff);
     }
+#undef GH_INTERSECT_ONE
 }
