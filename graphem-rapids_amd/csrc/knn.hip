@@ -113,7 +113,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
                    min_u64(readlane_u64(v, 32), readlane_u64(v, 48)));
 }
 
-#define GH_EXTRACT_MAX_K 64
+#define GH_EXTRACT_MAX_K 128
 
 // K smallest of the keys an NT-thread workgroup holds in registers (NPT per thread, unused
 // slots = GH_KEY_INF), written ascending to out[0..K) in LDS.  Each of the NT/64 waves extracts
@@ -122,7 +122,6 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 // -- and the survivors are ranked by counting.  wsc: (NT/64) * GH_EXTRACT_MAX_K keys of LDS scratch.
 template <int NPT, int NT = 256>
 __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *out, uint64_t *wsc) {
-    static_assert((NT / 64) * GH_EXTRACT_MAX_K <= NT || NT == 256, "one thread per surviving key in the merge");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int r = 0; r < K; ++r) {
         uint64_t m = keys[0];
@@ -138,8 +137,8 @@ __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *o
         for (int j = 0; j < NPT; ++j) keys[j] = keys[j] == m ? GH_KEY_INF : keys[j];
     }
     __syncthreads();
-    const int t = threadIdx.x, n4 = (NT / 64) * K;
-    if (t < n4) {
+    const int n4 = (NT / 64) * K;
+    for (int t = threadIdx.x; t < n4; t += NT) {
         const uint64_t key = wsc[t];
         int rank = 0;
         for (int j = 0; j < n4; ++j) {

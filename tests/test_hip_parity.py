@@ -168,6 +168,9 @@ def _random_case(n, D, deg, k, S, seed):
     (3000, 5, 4, 10, 256),      # below the scan threshold: per-query kernel, generic spring
     (2000, 20, 4, 10, 64),      # generic D
     (900, 40, 6, 40, 128),      # generic D, large k
+    (20000, 3, 8, 100, 256),    # K = 101: still the scan path (extraction up to 128 keys)
+    (20000, 3, 8, 127, 64),     # K = 128: its upper end
+    (20000, 3, 8, 130, 64),     # K = 131: the per-query sort kernel
 ])
 def test_random_graphs_against_oracle(n, D, deg, k, S):
     from graphem_rapids_amd import _native
