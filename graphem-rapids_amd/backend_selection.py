@@ -54,6 +54,7 @@ def estimate_memory_usage(n_vertices, n_components, n_edges=None, n_neighbors=10
     e = n_edges if n_edges is not None else 5 * n_vertices
     s = min(sample_size, e)
     per_vertex = ld * 4 * 4 + n_components * 4 + ld * 8 + 4   # pos, new, 2 scratch, io, fp64 accumulators, flag
-    per_edge = 8 + 8                                           # edge list + pull lists
-    per_query = 4096 * 8 + (n_neighbors + 1) * 8 + n_neighbors * (4 + 4 * ld) + 16 * n_neighbors
+    scan = e >= 16384 and n_components >= 2 and ld <= 16 and n_neighbors + 1 <= 128   # csrc/knn.hip gh_knn_scan_path
+    per_edge = 8 + 8 + 4 * ld + (2 * ld if scan else 0)       # edge list, pull lists, midpoints, threshold subset
+    per_query = (8192 * 8 if scan else 0) + 32 * 4 + (n_neighbors + 1) * 16 + n_neighbors * (4 + 4 * ld) + 16 * n_neighbors
     return n_vertices * per_vertex + e * per_edge + s * per_query

@@ -320,7 +320,9 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_first_edge, (size_t)h->rows + 1, true);
     GH_A(d_mid, (size_t)h->own_count * h->LD, true);
     GH_A(d_Fs, (size_t)h->rows * h->LD, true);
-    GH_A(d_midsub, (size_t)(h->own_count / 2 + 2) * h->LD, true);
+    // candidate lists and the threshold subset exist only for the filtered scan (64 KiB per query)
+    const bool scan_path = gh_knn_scan_path(h);
+    GH_A(d_midsub, scan_path ? (size_t)(h->own_count / 2 + 2) * h->LD : 1, true);
     if (hashed) GH_A(d_own_eids, own_eids.size() + 1, true);
     if (h->nlong) {
         GH_A(d_long_rows, long_rows.size(), false);
@@ -344,7 +346,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_qscan, S * (size_t)(h->LD + 4), true);
     GH_A(d_qA, S * 16, true);
     GH_A(d_qexact, S + 1, true);
-    GH_A(d_cand, S * GH_CAND_CAP, false);
+    GH_A(d_cand, scan_path ? S * GH_CAND_CAP : 1, false);
     GH_A(d_cnt, S * GH_CNT_STRIDE, true);
     GH_A(d_ovf, S, true);
     GH_A(d_dbg_cnt, 2 * S, true);
@@ -437,6 +439,18 @@ extern "C" const float *gh_positions_unpadded_device(gh_handle h) {
 extern "C" int32_t gh_row_stride(gh_handle h) { return h ? h->LD : 0; }
 
 // ---- the loop ----------------------------------------------------------------------
+static bool whole_graph(gh_engine *h) {
+    return h->part.row_lo == 0 && h->part.row_hi == h->n &&
+           (h->part.edge_rule == GH_EDGES_HASHED || (h->part.edge_lo == 0 && h->part.edge_hi == h->E));
+}
+// gh_step / gh_run / the per-phase entry points merge with world = 1 and normalise with the own rows'
+// statistics: on a row partition that would silently corrupt the positions.
+static gh_status check_whole(gh_engine *h, const char *what) {
+    if (whole_graph(h) && !h->d_gbuf) return GH_OK;
+    h->err = std::string(what) + " needs the whole graph on one rank; a partitioned engine runs gh_step_begin / "
+             "gh_step_merge / gh_step_finish_gathered (or gh_run_partitioned)";
+    return GH_ERR_INVALID;
+}
 static gh_status check_k(gh_engine *h) {
     if ((int64_t)h->K > h->E) {
         h->err = "selected index k out of range";  // torch.topk's message (pt.py:583)
@@ -459,6 +473,9 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
     if (host_ids) {
         for (int64_t i = 0; i < h->S; ++i)
             if (host_ids[i] < 0 || host_ids[i] >= h->E) { h->err = "sampled edge id out of range"; return GH_ERR_INVALID; }
+        // a set-up done ahead (inside the last normalise launch) left ITS ids in d_sampled and built the query
+        // records from them: overwriting the ids makes it stale
+        h->presetup_valid = false;
         GH_HIP(hipMemcpyAsync(h->d_sampled, host_ids, sizeof(int32_t) * (size_t)h->S, hipMemcpyHostToDevice, h->stream));
         GH_HIP(hipStreamSynchronize(h->stream));
         return GH_OK;
@@ -509,6 +526,7 @@ static gh_status step_finish(gh_engine *h, int next_mode = -1, int32_t *next_ids
 
 extern "C" gh_status gh_step(gh_handle h, const int32_t *sampled) {
     GH_TRY(check_handle(h));
+    GH_TRY(check_whole(h, "gh_step"));
     GH_TRY(check_k(h));
     GH_TRY(set_sample(h, sampled, nullptr));
     GH_TRY(step_begin(h, true));
@@ -521,6 +539,7 @@ extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_st
     GH_TRY(check_handle(h));
     if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
     if (iters == 0) return GH_OK;
+    GH_TRY(check_whole(h, "gh_run"));
     GH_TRY(check_k(h));
     const bool use_stream = sample_stream && h->S < h->E;
     if (use_stream) {
@@ -636,10 +655,6 @@ extern "C" gh_status gh_radial_topk(gh_handle h, int32_t k, int32_t *ids) {
 }
 
 // ---- per-phase entry points --------------------------------------------------------
-static bool whole_graph(gh_engine *h) {
-    return h->part.row_lo == 0 && h->part.row_hi == h->n &&
-           (h->part.edge_rule == GH_EDGES_HASHED || (h->part.edge_lo == 0 && h->part.edge_hi == h->E));
-}
 
 extern "C" gh_status gh_spring_forces(gh_handle h, float *F) {
     GH_TRY(check_handle(h));
@@ -651,7 +666,7 @@ extern "C" gh_status gh_spring_forces(gh_handle h, float *F) {
 extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32_t *knn) {
     GH_TRY(check_handle(h));
     if (!knn) { h->err = "knn is NULL"; return GH_ERR_INVALID; }
-    if (!whole_graph(h)) { h->err = "per-phase entry points need the whole graph on one rank"; return GH_ERR_INVALID; }
+    GH_TRY(check_whole(h, "gh_knn_midpoints"));
     GH_TRY(check_k(h));
     if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
     GH_TRY(set_sample(h, sampled, nullptr));
@@ -667,6 +682,7 @@ extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32
 extern "C" gh_status gh_intersection_forces(gh_handle h, const int32_t *sampled, const int32_t *knn, float *F) {
     GH_TRY(check_handle(h));
     if (!knn || !F) { h->err = "NULL argument"; return GH_ERR_INVALID; }
+    GH_TRY(check_whole(h, "gh_intersection_forces"));
     if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
     for (int64_t i = 0; i < h->S * h->k; ++i)
         if (knn[i] < 0 || knn[i] >= h->E) { h->err = "neighbour edge id out of range"; return GH_ERR_INVALID; }
@@ -687,7 +703,7 @@ extern "C" gh_status gh_intersection_forces(gh_handle h, const int32_t *sampled,
 extern "C" gh_status gh_integrate_normalise(gh_handle h, const float *Fs, const float *Fi, float *out) {
     GH_TRY(check_handle(h));
     if (!Fs || !Fi || !out) { h->err = "NULL argument"; return GH_ERR_INVALID; }
-    if (!whole_graph(h)) { h->err = "per-phase entry points need the whole graph on one rank"; return GH_ERR_INVALID; }
+    GH_TRY(check_whole(h, "gh_integrate_normalise"));
     const size_t bytes = sizeof(float) * (size_t)h->n * h->D;
     GH_HIP(hipMemcpyAsync(h->d_io, Fs, bytes, hipMemcpyHostToDevice, h->stream));
     GH_TRY(gh_launch_pad(h, h->d_io, h->d_tmpF));

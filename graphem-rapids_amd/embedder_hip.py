@@ -119,9 +119,12 @@ class GraphEmbedderHIP:
             sampler = "torch" if self.n_edges <= (1 << 20) else "device"
         self.sampler = sampler
 
+        # the device sampler's key: an unseeded embedder draws it from torch's global generator, so unseeded
+        # runs differ from each other (like the reference's) while torch.manual_seed still controls both samplers
+        self._engine_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         self._engine = _native.Engine(
             self.n, n_components, self._edges_np, L_min, k_attr, k_inter, n_neighbors, self.sample_size,
-            seed=0 if seed is None else seed, device_id=self.device.index)
+            seed=self._engine_seed, device_id=self.device.index)
         if self.verbose:
             self.logger.info("Initialized GraphEmbedderHIP on %s", self.device)
             self.logger.info("Graph: %d vertices, %d edges, %dD", self.n, self.n_edges, self.n_components)

@@ -112,25 +112,35 @@ def generate_random_regular(n=100, d=3, seed=0):
     return edges_to_adjacency(n, random_regular_edges(n, d, seed))
 
 
-def load_snap_edge_list(path):
-    """SNAP text edge list -> (vertices, edges): '#' comment lines, 'src<ws>dst' rows, labels
-    compacted to 0..n-1, undirected and deduplicated with u < v (format handled by the
-    reference's SNAPDataset parser, datasets.py:306-357; no download, no NetworkX)."""
+def load_snap_edge_list(path, directed=False, relabel=True):
+    """SNAP text edge list -> (vertices, edges), the format and the rules of the reference's
+    SNAPDataset.load() (datasets.py:306-357): lines starting with '#' are comments, a row is
+    'src<ws>dst' (further columns ignored, rows with fewer than two fields skipped); an undirected
+    dataset (directed=False) becomes the sorted unique pairs with u < v (self-loops and repeats in
+    either direction drop out), a directed one keeps its rows as they come; vertices = the sorted
+    labels that occur in the edges.
+
+    relabel=False returns exactly what the reference's loader returns (original labels).
+    relabel=True (default) compacts the labels to 0..n-1 in sorted-label order -- what the
+    reference's load_dataset_as_networkx does next with convert_node_labels_to_integers
+    (datasets.py:761-782) -- so that `edges` indexes an n x n adjacency directly; `vertices` is then
+    arange(n).  No download, no NetworkX, no Python-level pair handling (vectorised numpy)."""
     src, dst = [], []
     with open(path, "r", encoding="utf-8") as fh:
         for line in fh:
-            if not line or line[0] == "#":
+            if line.startswith("#"):
                 continue
-            parts = line.split()
-            if len(parts) < 2:
-                continue
-            src.append(int(parts[0]))
-            dst.append(int(parts[1]))
-    a = np.asarray(src, dtype=np.int64)
-    b = np.asarray(dst, dtype=np.int64)
-    labels, inv = np.unique(np.concatenate([a, b]), return_inverse=True)
-    a, b = inv[:len(a)], inv[len(a):]
-    lo, hi = np.minimum(a, b), np.maximum(a, b)
-    keep = lo != hi
-    e = np.unique(np.column_stack([lo[keep], hi[keep]]), axis=0)
-    return np.arange(len(labels)), e
+            parts = line.strip().split()
+            if len(parts) >= 2:
+                src.append(int(parts[0]))
+                dst.append(int(parts[1]))
+    edges = np.column_stack([np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64)]).reshape(-1, 2)
+    if not directed and len(edges):
+        lo, hi = np.minimum(edges[:, 0], edges[:, 1]), np.maximum(edges[:, 0], edges[:, 1])
+        keep = lo != hi
+        edges = np.unique(np.column_stack([lo[keep], hi[keep]]), axis=0)
+    vertices = np.unique(edges.ravel())
+    if relabel:
+        edges = np.searchsorted(vertices, edges)
+        vertices = np.arange(len(vertices), dtype=np.int64)
+    return vertices, edges

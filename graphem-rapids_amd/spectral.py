@@ -15,6 +15,7 @@ Like the reference's result, the embedding is defined up to the sign of each eig
 rotation inside a degenerate eigenspace; tests compare eigenvalues and subspaces, not entries.
 """
 import ctypes
+import logging
 
 import numpy as np
 import scipy.sparse as sp
@@ -22,11 +23,17 @@ import torch
 
 from . import _native
 
+logger = logging.getLogger(__name__)
+
 
 def symmetrised_csr(adjacency):
-    """A + A^T with all weights 1 (pt.py:351-352), CSR with sorted indices."""
+    """A + A^T with all weights 1 (pt.py:351-352), CSR with sorted indices, diagonal removed:
+    csgraph.laplacian(normed=True) (pt.py:355) leaves self-loops out of the degree and overwrites the
+    diagonal of L, so they must not reach the operator either."""
     a = sp.csr_matrix(adjacency + adjacency.transpose())
     a.data = np.ones_like(a.data)
+    a.setdiag(0)
+    a.eliminate_zeros()
     a.sort_indices()
     return a
 
@@ -225,6 +232,9 @@ def laplacian_embedding_hip(adjacency, n_components, device="cuda:0", tol=1e-6, 
         if len(theta) > want + len(new):      # keep a few spare copies so the next complement is right
             theta, X = theta[: want + len(new)], X[:, : want + len(new)]
     theta, X = theta[:want], X[:, :want]
+    if not converged:  # the reference falls back to its random start on ArpackNoConvergence; say so at least
+        logger.warning("laplacian_embedding_hip: not converged after %d matvecs (largest relative residual %.2e); "
+                       "using the current Ritz vectors", total_steps, float(np.max(resid)))
     emb = X[:, 1:want].to(torch.float32).cpu().numpy()          # drop the first (pt.py:365)
     if return_info:
         return emb, {"steps": total_steps, "runs": runs, "converged": converged, "eigenvalues": 2.0 - theta,

@@ -18,8 +18,8 @@ _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "graphem_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("graphem_oracle.c", "aten_cdist_topk.cpp", "Makefile")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True, stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -38,6 +38,8 @@ def lib():
         L.go_knn_midpoints.restype = i32
         L.go_knn_midpoints_cdist_mm.argtypes = [_f32p, i32, _i32p, i64, _i32p, i64, i32, _i32p]
         L.go_knn_midpoints_cdist_mm.restype = i32
+        L.go_knn_midpoints_aten.argtypes = [_f32p, i32, _i32p, i64, _i32p, i64, i32, _i32p, ctypes.c_void_p]
+        L.go_knn_midpoints_aten.restype = i32
         L.go_intersection_forces.argtypes = [_f32p, i64, i32, _i32p, _i32p, i64, _i32p, i32, f32, _f32p,
                                              ctypes.POINTER(i64)]
         L.go_intersection_forces.restype = None
@@ -91,6 +93,29 @@ def knn_midpoints(pos, edges, sampled, k, return_dist=False, cdist_mm=False):
     if err:
         raise MemoryError("oracle allocation failed")
     return (knn, dist) if return_dist else knn
+
+
+def knn_midpoints_aten(pos, edges, sampled, k, return_col0=False):
+    """The reference's own neighbour ids: ATen's cdist (matmul form) + topk, rounding and tie order included
+    (oracle/aten_cdist_topk.cpp; pt.py:580-583).  With return_col0 also the id the reference drops as
+    "self" (pt.py:421) -- not always the sampled edge, SURVEY quirk Q3."""
+    pos, edges, sampled = _c(pos, np.float32), _c(edges, np.int32), _c(sampled, np.int32)
+    S = sampled.shape[0]
+    knn = np.empty((S, k), dtype=np.int32)
+    col0 = np.empty(S, dtype=np.int32)
+    err = lib().go_knn_midpoints_aten(pos, pos.shape[1], edges, edges.shape[0], sampled, S, k, knn, col0.ctypes.data)
+    if err == 1:
+        raise RuntimeError("selected index k out of range")
+    return (knn, col0) if return_col0 else knn
+
+
+def step_aten(pos, edges, sampled, k, L_min=1.0, k_attr=0.2, k_inter=0.5, colmajor=False):
+    """One iteration with the KNN phase as ATen computes it (knn_midpoints_aten); the other phases as step()."""
+    pos = _c(pos, np.float32)
+    Fs = spring_forces(pos, edges, L_min, k_attr)
+    knn = knn_midpoints_aten(pos, edges, sampled, k)
+    Fi = intersection_forces(pos, edges, sampled, knn, k_inter)
+    return integrate_normalise(pos, Fs, Fi, colmajor=colmajor)
 
 
 def intersection_forces(pos, edges, sampled, knn, k_inter=0.5, return_count=False):
