@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_terms, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_midsub, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_ticket, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -322,7 +322,8 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_Fs, (size_t)h->rows * h->LD, true);
     // candidate lists and the threshold subset exist only for the filtered scan (64 KiB per query)
     const bool scan_path = gh_knn_scan_path(h);
-    GH_A(d_midsub, scan_path ? (size_t)(h->own_count / 2 + 2) * h->LD : 1, true);
+    GH_A(d_gmin, (size_t)gh_gmin_floats(h), true);  // also fixes the threshold subset (thr_stride, thr_M1)
+    GH_A(d_sub_uv, (size_t)h->thr_M1 * 2, false);
     if (hashed) GH_A(d_own_eids, own_eids.size() + 1, true);
     if (h->nlong) {
         GH_A(d_long_rows, long_rows.size(), false);
@@ -341,6 +342,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_tflag, (size_t)n, true);
     GH_A(d_touched, 4 * S * (size_t)h->k, false);
     GH_A(d_tcount, 1, true);
+    GH_A(d_ticket, 1, true);
     GH_A(d_sampled, S, true);
     GH_A(d_q, S * (size_t)(h->LD + 4), true);
     GH_A(d_qscan, S * (size_t)(h->LD + 4), true);
@@ -374,6 +376,18 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         hipStreamSynchronize(h->stream) != hipSuccess) {
         h->err = "upload of the graph failed";
         return bail(GH_ERR_HIP);
+    }
+    if (h->thr_M1 > 0) {  // endpoints of the threshold subset: every thr_stride-th own edge
+        std::vector<int32_t> sub((size_t)h->thr_M1 * 2);
+        for (int64_t j = 0; j < h->thr_M1; ++j) {
+            const int64_t e = hashed ? (int64_t)own_eids[(size_t)(j * h->thr_stride)] : h->part.edge_lo + j * h->thr_stride;
+            sub[(size_t)(2 * j)] = edges[2 * e];
+            sub[(size_t)(2 * j + 1)] = edges[2 * e + 1];
+        }
+        if (hipMemcpy(h->d_sub_uv, sub.data(), sizeof(int32_t) * sub.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            h->err = "upload of the threshold subset failed";
+            return bail(GH_ERR_HIP);
+        }
     }
     if (!h->order_host.empty()) {
         st = dev_alloc(h, &h->d_order, (size_t)n, false);
@@ -489,6 +503,7 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
 // fuse_intersect: single-rank step, the KNN kernels also run the intersection phase.
 static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
     h->intersect_done = false;
+    h->fix_done = false;
     h->new0_ready = false;
     if (h->S == 0 || h->k == 0) {  // nothing sampled / no neighbours asked for: spring forces only
         h->sample_pending = false;

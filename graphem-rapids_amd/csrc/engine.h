@@ -64,7 +64,9 @@ struct gh_engine {
     int64_t long_entries = 0;
     float *d_mid = nullptr;       // (own_count, LD) midpoints of the own edges, current iteration
     float *d_Fs = nullptr;        // (rows, LD) spring forces of the own rows
-    float *d_midsub = nullptr;    // (ceil(own edges / 2), LD) compact midpoints of the threshold subsets
+    float *d_gmin = nullptr;      // (S, Gpad) group minima of the threshold subset (setup_core.h), float bits
+    int32_t *d_sub_uv = nullptr;  // (thr_M1, 2) endpoints of the subset edges
+    int64_t thr_stride = 0, thr_M1 = 0;  // the subset: every thr_stride-th own edge, thr_M1 of them (0: not chosen yet)
     int32_t *d_vblock = nullptr;  // (n_vblocks + 1) vertex ranges of the fused spring+scan workgroups
     int n_vblocks = 0;
     bool force_unfused = false;   // GRAPHEM_HIP_UNFUSED set: keep the separate spring / scan kernels
@@ -90,6 +92,8 @@ struct gh_engine {
     size_t stream_ids_cap = 0;
     bool new0_ready = false;      // the fused kernel of this step wrote d_new = pos + Fs and its block sums
     bool intersect_done = false;  // the KNN kernels of this step already ran the intersection phase
+    bool fix_done = false;        // ... and finished the step's statistics (the stats_fix part, knn.hip fix_args)
+    int32_t *d_ticket = nullptr;  // (1) arrival counter of that launch, zero between launches
     bool presetup_valid = false;  // the last normalise launch also ran the KNN set-up of iteration presetup_iter
     int presetup_mode = 0;        //   with this sample mode / id pointer (gh_knn_prepare then skips its kernel)
     const int32_t *presetup_ids = nullptr;
@@ -144,6 +148,8 @@ gh_status gh_knn_local(gh_engine *h, bool fuse_intersect);  // d_sampled, d_mid 
 bool gh_knn_scan_path(const gh_engine *h);
 struct gh_setup_args;
 gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint64_t iter);  // setup_core.h
+unsigned gh_setup_blocks(const gh_setup_args &a);
+int64_t gh_gmin_floats(const gh_engine *h);   // size of d_gmin
 gh_status gh_knn_prepare(gh_engine *h);
 gh_status gh_knn_thresholds(gh_engine *h);
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);

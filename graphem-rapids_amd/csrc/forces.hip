@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
                                                        int n_setup, gh_setup_args sa, int32_t *__restrict__ qexact) {
     // the set-up workgroups come FIRST in the grid: their chains of dependent gathers start at once and
     // run under the streaming of the others
+    __shared__ __align__(16) unsigned char setup_lds[GH_SETUP_LDS_BYTES];
     const bool setup_block = (int)blockIdx.x < n_setup;
     const int nb = (int)blockIdx.x - n_setup;  // index among the normalising workgroups
     // also zero what the intersection phase touched (acc != nullptr): the integrate kernel that
@@ -369,7 +370,9 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
         const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (t == 0) qexact[0] = 0;
         // position of vertex v, component d < D, exactly as the normalising threads below compute it
-        gh_setup_item(sa, t, [=](int64_t v, int d) { return (nw[v * LD + d] - ms[d]) / ms[LD + d]; });
+        auto getp = [=](int64_t v, int d) { return (nw[v * LD + d] - ms[d]) / ms[LD + d]; };
+        if (sa.tiles > 0) gh_setup_block_any(sa, (int)blockIdx.x, getp, setup_lds);
+        else gh_setup_item(sa, t, getp);
         return;
     }
     // 16 bytes per thread and step (LD is a multiple of 4, rows are 16-byte aligned)
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
                                                                 const int32_t *__restrict__ tcount, int g_norm,
                                                                 int n_setup, gh_setup_args sa,
                                                                 int32_t *__restrict__ qexact) {
+    __shared__ __align__(16) unsigned char setup_lds[GH_SETUP_LDS_BYTES];
     const bool setup_block = (int)blockIdx.x < n_setup;  // the next iteration's KNN set-up, as in normalise_kernel
     const int nb = (int)blockIdx.x - n_setup;
     if (!setup_block) {
@@ -443,11 +447,13 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
     if (setup_block) {
         const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (t == 0) qexact[0] = 0;
-        gh_setup_item(sa, t, [=](int64_t v, int d) {
+        auto getp = [=](int64_t v, int d) {
             const int64_t r = v / chunk;
             const float *rowsrc = reinterpret_cast<const float *>(gbuf + r * slot);
             return (rowsrc[(v - r * chunk) * LD + d] - ms[d]) / ms[LD + d];
-        });
+        };
+        if (sa.tiles > 0) gh_setup_block_any(sa, (int)blockIdx.x, getp, setup_lds);
+        else gh_setup_item(sa, t, getp);
         return;
     }
     const int64_t total4 = n * LD / 4;  // 16 bytes per thread and step
@@ -650,6 +656,11 @@ gh_status gh_launch_mid_only(gh_engine *h) { return launch_mid_gather(h); }
 
 // new = pos + (Fs + Fi) for the own rows -> d_new, column statistics -> d_stats.
 gh_status gh_launch_integrate(gh_engine *h) {
+    if (h->fix_done) {  // the select launch of this step has finished the statistics as well (knn.hip fix_args)
+        h->fix_done = false;
+        h->new0_ready = false;
+        return GH_OK;
+    }
     if (h->new0_ready && h->rows > 0) {  // the fused kernel already wrote pos + Fs and its partial sums
         h->new0_ready = false;
         gh_scope t(h, "stats_fix");
@@ -767,7 +778,7 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
     unsigned extra = 0;
     if (presetup) {
         sa = gh_make_setup_args(h, next_mode, next_mode == 0 ? next_ids : h->d_sampled, h->iter + 1);
-        extra = grid_for(h->S + sa.M1 * h->LD, 256);
+        extra = gh_setup_blocks(sa);
     }
     normalise_kernel<<<dim3(grid + extra), dim3(256), sizeof(float) * 2 * h->LD, h->stream>>>(
         h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos,
@@ -795,7 +806,7 @@ gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
     unsigned extra = 0;
     if (presetup) {
         sa = gh_make_setup_args(h, next_mode, h->d_sampled, h->iter + 1);
-        extra = grid_for(h->S + sa.M1 * h->LD, 256);
+        extra = gh_setup_blocks(sa);
     }
     const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * h->LD * (size_t)h->g_world;
     normalise_gathered_kernel<<<dim3(grid + extra), dim3(256), smem, h->stream>>>(

@@ -50,18 +50,17 @@ __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi
 }
 
 // ---------------------------------------------------------------------------------
-// One launch sets a KNN search up: (a) this iteration's sample ids -- given, drawn by the device
-// sampler, or arange when S >= E (pt.py:403-413); (b) the S query records: midpoint of the
-// sampled edge (pt.py:785, pt.py:410) + tau = inf, and the candidate-list reset; (c) the compact
-// copy of the midpoints of every `stride`-th own edge that the threshold kernel works on
-// (M1 ~ E/64 rows gathered from positions: the full midpoint array is never needed for it).
-// mode: 0 ids already in `sampled`, 1 device sampler, 2 arange.
+// One launch sets a KNN search up from the CURRENT positions (setup_core.h): sample ids, query
+// records, list reset and -- on the scan path, a.tiles > 0 -- the group minima of the threshold
+// subset.  (In a run the same work rides in the previous iteration's normalise launch instead.)
 __global__ __launch_bounds__(256) void knn_setup_kernel(const float *__restrict__ pos, gh_setup_args a,
                                                        int32_t *__restrict__ tcount, int32_t *__restrict__ qexact) {
-    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t == 0) { *tcount = 0; qexact[0] = 0; }  // the previous iteration's normalise kernel has consumed it
+    __shared__ __align__(16) unsigned char lds[GH_SETUP_LDS_BYTES];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *tcount = 0; qexact[0] = 0; }  // the previous iteration's normalise kernel has consumed it
     const int LD = a.LD;
-    gh_setup_item(a, t, [=](int64_t v, int d) { return pos[v * LD + d]; });
+    auto getp = [=](int64_t v, int d) { return pos[v * LD + d]; };
+    if (a.tiles > 0) gh_setup_block_any(a, (int)blockIdx.x, getp, lds);
+    else gh_setup_item(a, blockIdx.x * (int64_t)blockDim.x + threadIdx.x, getp);
 }
 
 // Bitonic sort of n2 (power of two) keys in LDS by one 256-thread workgroup, ascending.
@@ -377,113 +376,170 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
     gh_flush_hits<GH_SCAN_HITBUF>(hkey, hq, &hcount, cand, cnt);
 }
 
-// Threshold kernel: one workgroup per query streams the compact subset (M1 rows, coalesced
-// 16-byte loads, L2-resident) and returns tau = the K-th smallest squared distance in it: an
-// upper bound of the true K-th distance, since the K-th order statistic of a subset can only be
-// larger.  Survivors of the running threshold are parked in LDS; the K smallest are extracted
-// only when the buffer could overflow (twice in practice) and at the end.
-template <int LD, int NT, int RPT /* rows per thread per pass */>
-__global__ __launch_bounds__(NT) void knn_threshold_kernel(const float *__restrict__ midsub, int64_t M1, int D,
-                                                           float *__restrict__ qt, float *__restrict__ qscan,
-                                                           int QS, int QT, int K, _Float16 *__restrict__ qA,
-                                                           int32_t *__restrict__ qexact,
-                                                           int32_t *__restrict__ tcount_reset) {
-    constexpr int BUF = 4096, NPT = BUF / NT;
+// tau of one query = the K-th smallest of its G group minima (setup_core.h): an upper bound of its
+// K-th smallest distance over ALL own edges.  One wave per query: the minima sit NV per lane in
+// registers (more than 64 * NV groups: folded by min, which only makes groups coarser), K rounds of a
+// wave-wide minimum retire the smallest value each (equal values retire together: the bound can only
+// get looser).  Then the pre-filter records of the scan (scan_core.h).
+__global__ __launch_bounds__(64) void knn_tau_kernel(const uint32_t *__restrict__ gmin, int64_t G, int64_t Gpad, int D,
+                                                    float *__restrict__ qt, float *__restrict__ qscan, int QS, int QT,
+                                                    int K, _Float16 *__restrict__ qA, int32_t *__restrict__ qexact,
+                                                    int32_t *__restrict__ tcount_reset) {
+    constexpr int NV = 32;
     // set-up done inside the previous normalise launch: the touched-list counter is reset here instead
     if (tcount_reset && blockIdx.x == 0 && threadIdx.x == 0) *tcount_reset = 0;
-    __shared__ uint64_t buf[BUF];
-    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
-    __shared__ uint64_t red[(NT / 64) * GH_EXTRACT_MAX_K];
-    __shared__ int cnt;
-    __shared__ float qs[LD];
     const int64_t qi = blockIdx.x;
-    if (threadIdx.x < LD) qs[threadIdx.x] = threadIdx.x < D ? qt[qi * QS + threadIdx.x] : 0.0f;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    float q[LD];
+    const int lane = threadIdx.x;
+    const uint32_t *row = gmin + qi * Gpad;
+    const float qcoord = lane < D ? qt[qi * QS + lane] : 0.0f;  // lane d holds coordinate d (issued with the loads below)
+    uint32_t v[NV];
 #pragma unroll
-    for (int d = 0; d < LD; ++d) q[d] = qs[d];
-    float tau = INFINITY;
-
-    auto cut = [&](int c) {  // keep the K smallest of buf[0..c), tighten tau
-        block_extract_adaptive<NPT, NT>(buf, c, K, best, red);
-        if (threadIdx.x < K) buf[threadIdx.x] = best[threadIdx.x];
-        if (threadIdx.x == 0) cnt = c < K ? c : K;
-        tau = c >= K ? gh_key_d2(best[K - 1]) : INFINITY;
-        __syncthreads();
-    };
-
-    // pass 0: the first 2048 rows all survive (tau = inf) and establish the threshold
-    const int64_t head = M1 < 2048 ? M1 : 2048;
-    for (int64_t r = threadIdx.x; r < head; r += NT) {
-        float mv[LD];
-        gh_load_row<LD>(midsub, r, mv);
-        float s = 0.0f;
+    for (int j = 0; j < NV; ++j) v[j] = 0x7F800000u;
+    for (int64_t base = 0; base < G; base += 64 * NV) {
 #pragma unroll
-        for (int d = 0; d < LD; ++d) {  // pad columns are 0 on both sides: fma(0,0,s) == s
-            const float t = q[d] - mv[d];
-            s = fmaf(t, t, s);
+        for (int j = 0; j < NV; ++j) {
+            const int64_t i = base + j * 64 + lane;
+            const uint32_t x = i < G ? row[i] : 0x7F800000u;
+            v[j] = min(v[j], x);
         }
-        buf[r] = gh_key(s, (uint32_t)r);
     }
-    __syncthreads();
-    cut((int)head);
-    // later passes: RPT rows per thread, the NEXT pass's loads are issued before this pass is
-    // processed so the L2 latency overlaps the compute; survivors are rare
-    float nxt[RPT][LD];
+    uint32_t kth = 0x7F800000u;
+    for (int r = 0; r < K; ++r) {
+        uint32_t m = v[0];
 #pragma unroll
-    for (int j = 0; j < RPT; ++j) {
-        const int64_t r = head + j * NT + threadIdx.x;
-        gh_load_row<LD>(midsub, r < M1 ? r : 0, nxt[j]);
+        for (int j = 1; j < NV; ++j) m = min(m, v[j]);
+        m = gh_row_min_u32(m);
+        m = min(min((uint32_t)__builtin_amdgcn_readlane((int)m, 0), (uint32_t)__builtin_amdgcn_readlane((int)m, 16)),
+                min((uint32_t)__builtin_amdgcn_readlane((int)m, 32), (uint32_t)__builtin_amdgcn_readlane((int)m, 48)));
+        kth = m;
+        if (m == 0x7F800000u) break;  // fewer than K occupied groups: tau = inf, the candidate lists overflow, exact fallback
+#pragma unroll
+        for (int j = 0; j < NV; ++j) v[j] = v[j] == m ? 0x7F800000u : v[j];
     }
-    for (int64_t base = head; base < M1; base += NT * RPT) {
-        float mv[RPT][LD];
+    const float tau = __uint_as_float(kth);
+    float qs[16];
+    float qn = 0.0f;
 #pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-#pragma unroll
-            for (int d = 0; d < LD; ++d) mv[j][d] = nxt[j][d];
-        }
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const int64_t r = base + NT * RPT + j * NT + threadIdx.x;
-            gh_load_row<LD>(midsub, r < M1 ? r : 0, nxt[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) {
-            const int64_t r = base + j * NT + threadIdx.x;
-            float s = 0.0f;
-#pragma unroll
-            for (int d = 0; d < LD; ++d) {
-                const float t = q[d] - mv[j][d];
-                s = fmaf(t, t, s);
-            }
-            if (r < M1 && s <= tau) {
-                const int p = atomicAdd(&cnt, 1);
-                if (p < BUF) buf[p] = gh_key(s, (uint32_t)r);
-            }
-        }
-        // No barrier in this loop: with tau set the buffer fills by ~K/pass.  Should it ever fill up
-        // (thousands of rows within tau: ties), further survivors are dropped, which keeps tau a
-        // valid -- merely looser -- upper bound.
+    for (int d = 0; d < 16; ++d) {   // every lane gets all coordinates (coordinates past D are 0: fma(0, 0, s) == s)
+        qs[d] = __shfl(qcoord, d, 64);
+        qn = fmaf(qs[d], qs[d], qn);
     }
-    __syncthreads();
-    cut(cnt < BUF ? cnt : BUF);
-    if (threadIdx.x == 0) {
+    // scan record of the pre-filter (scan_core.h): (-2q, t),  t = tau - |q|^2 + eps*(2|q|^2 + tau)
+    if (lane < QS) qscan[qi * QS + lane] = lane < D ? -2.0f * qcoord : 0.0f;
+    if (lane == 0) {
         qt[qi * QS + QT] = tau;
-        // scan record of the pre-filter (scan_core.h): (-2q, t),  t = tau - |q|^2 + eps*(2|q|^2 + tau)
-        float qn = 0.0f;
-        for (int d = 0; d < D; ++d) qn = fmaf(qs[d], qs[d], qn);
-        for (int d = 0; d < QS; ++d) qscan[qi * QS + d] = d < D ? -2.0f * qs[d] : 0.0f;
         const float eps = gh_filter_eps(D);
         // + 1e-30: a must-pass value is then strictly negative even when every magnitude is 0 (the
         // MFMA form of the filter tests sign bits)
         qscan[qi * QS + QT] = fmaf(eps, fmaf(2.0f, qn, tau), tau - qn) + 1e-30f;
-        if (qA && D <= 3) {  // operand row of the MFMA form of the filter (scan_core.h)
-            _Float16 row[16];
-            if (!gh_mf_query_row(qs, D, tau, row)) qexact[1 + atomicAdd(&qexact[0], 1)] = (int32_t)qi;
-            for (int k = 0; k < 16; ++k) qA[qi * 16 + k] = row[k];
+    }
+    if (qA && D <= 3) {  // operand row of the MFMA form of the filter (scan_core.h): lane k stores element k
+        _Float16 rowh[16];
+        const bool ok = gh_mf_query_row(qs, D, tau, rowh);
+        if (lane == 0 && !ok) qexact[1 + atomicAdd(&qexact[0], 1)] = (int32_t)qi;
+        _Float16 mine = rowh[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) mine = lane == k ? rowh[k] : mine;
+        if (lane < 16) qA[qi * 16 + lane] = mine;
+    }
+}
+
+// The tail of a single-rank fused step inside the select launch (was stats_fix_kernel, its own launch
+// of 2*LD workgroups: 9-12 us on the critical path).  fx.stats == nullptr: not used.
+//   * workgroups S .. S+2*LD-1 reduce one column of the fused kernel's per-workgroup sums each ->
+//     stats[c] (fixed order);
+//   * every workgroup takes a ticket when it is done; the LAST one then owns the rows the
+//     intersection phase touched: new = pos + (Fs + Fi) replaces new0 = pos + Fs (pt.py:796-799) and the
+//     column sums of (new - new0), (new^2 - new0^2) go to the first correction row pair of the
+//     statistics buffer (normalise_kernel adds the rows up).  Release / acquire at agent scope around the
+//     ticket (MI355X guide, Guideline 16): the touched list is written with plain stores by other CUs.
+struct fix_args {
+    const double *blockstats;
+    int nblocks;
+    const float *pos, *Fs;
+    const double *acc;
+    const int32_t *touched, *tcount;
+    int64_t row_lo, rows;
+    float *out_new;
+    double *stats;
+    int32_t *ticket;
+    int LD, nfix;
+};
+
+template <int LD>
+__device__ void fix_touched_rows(const fix_args &fx, double (*red)[2 * 16]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double dx[LD], dxx[LD];
+#pragma unroll
+    for (int d = 0; d < LD; ++d) { dx[d] = 0.0; dxx[d] = 0.0; }
+    const int nt = __hip_atomic_load(fx.tcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+        const int64_t x = __hip_atomic_load(&fx.touched[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int64_t i = x - fx.row_lo;
+        if (i < 0 || i >= fx.rows) continue;
+        float p[LD], f[LD], nw[LD];
+        gh_load_row<LD>(fx.pos, x, p);
+        gh_load_row<LD>(fx.Fs, i, f);
+#pragma unroll
+        for (int d = 0; d < LD; ++d) {
+            const float n0 = p[d] + f[d];
+            const float tot = f[d] + (float)__hip_atomic_load(&fx.acc[x * LD + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nw[d] = p[d] + tot;
+            dx[d] += (double)nw[d] - (double)n0;
+            dxx[d] += (double)nw[d] * (double)nw[d] - (double)n0 * (double)n0;
+        }
+        gh_store_row<LD>(fx.out_new, i, nw);
+    }
+#pragma unroll
+    for (int d = 0; d < LD; ++d) {
+        const double a = gh_wave_sum(dx[d]), b = gh_wave_sum(dxx[d]);
+        if (lane == 0) { red[w][d] = a; red[w][LD + d] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * LD)
+        fx.stats[2 * LD + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    // the other correction row pairs stay zero (the stand-alone stats_fix_kernel fills one per workgroup)
+    for (int i = 4 * LD + threadIdx.x; i < (2 + 2 * fx.nfix) * LD; i += blockDim.x) fx.stats[i] = 0.0;
+}
+
+// Column c of the per-workgroup sums -> stats[c] (the first part of stats_fix_kernel, same order).
+__device__ void fix_reduce_column(const fix_args &fx, int c, double (*red)[2 * 16]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double s4[4] = {0.0, 0.0, 0.0, 0.0};
+    const double *col = fx.blockstats + (int64_t)c * fx.nblocks;
+    int b = threadIdx.x;
+    for (; b + 3 * (int)blockDim.x < fx.nblocks; b += 4 * blockDim.x) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += col[b + u * blockDim.x];
+    }
+    for (int u = 0; b < fx.nblocks; b += blockDim.x, ++u) s4[u] += col[b];
+    const double a = gh_wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+    if (lane == 0) red[w][0] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) fx.stats[c] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+}
+
+// Ticket + last-arriver part; call with the whole workgroup, after all its global writes.
+__device__ void fix_finish(const fix_args &fx, int total, double (*red)[2 * 16], int *last_flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // no agent-scope release here: right after the fused kernel the L2s hold tens of MB of dirty lines and a
+        // buffer_wbl2 per workgroup cost +20 us (measured).  What the last workgroup reads from this launch is either
+        // written by atomics (acc, tcount: performed at the memory side) or by write-through stores (the touched
+        // list, intersect_core.h); __syncthreads() above has drained every wave's stores (vmcnt(0)).
+        const int t = atomicAdd(fx.ticket, 1);
+        *last_flag = t == total - 1;
+        if (t == total - 1) {
+            *fx.ticket = 0;  // nobody else touches it before the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
     }
+    __syncthreads();
+    if (!*last_flag) return;
+    if (fx.LD == 4) fix_touched_rows<4>(fx, red);
+    else if (fx.LD == 8) fix_touched_rows<8>(fx, red);
+    else fix_touched_rows<16>(fx, red);
 }
 
 // One workgroup per query: K smallest of the candidate list; final -> K best keys (and the
@@ -494,13 +550,20 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
                                                          int K, int final_level, float *__restrict__ tau, int QS,
                                                          uint64_t *__restrict__ out_keys,
                                                          int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
-                                                         search_args fb, inter_args ia) {
+                                                         search_args fb, inter_args ia, fix_args fx, int S) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats (exact search only)
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
+    __shared__ double fred[4][2 * 16];
+    __shared__ int last_flag;
     constexpr int NPT = GH_CAND_CAP / 256;
     const int64_t qi = blockIdx.x;
+    if (qi >= S) {  // the column reducers of the fused step's statistics (fx.stats set)
+        fix_reduce_column(fx, (int)(qi - S), fred);
+        fix_finish(fx, (int)gridDim.x, fred, &last_flag);
+        return;
+    }
     const int c = cnt[qi * GH_CNT_STRIDE];
     __syncthreads();
     if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; }
@@ -517,6 +580,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     } else if (threadIdx.x == 0) {
         tau[qi * QS] = gh_key_d2(best[K - 1]);
     }
+    if (fx.stats) fix_finish(fx, (int)gridDim.x, fred, &last_flag);
 }
 
 // Merge the per-rank key lists (world, S, K) into the K globally best keys per query (S, K).
@@ -631,12 +695,23 @@ int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile, bool mfma) {
 
 // fb_mid: midpoint rows for the exact search of overflowed queries, or null (gather the endpoints).
 gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect, const float *fb_mid) {
-    gh_scope t(h, with_intersect ? "knn_select_intersect" : "knn_select");
-    knn_select_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
+    // single-rank fused step: the statistics of the step are finished in this launch too (fix_args)
+    const bool with_fix = final_level && with_intersect && h->new0_ready && h->rows > 0 && h->LD <= 16 &&
+                          !getenv("GRAPHEM_HIP_SEPARATE_FIX");
+    fix_args fx{};
+    unsigned extra = 0;
+    if (with_fix) {
+        fx = fix_args{h->d_blockstats, h->n_vblocks, h->d_pos, h->d_Fs, h->d_acc, h->d_touched, h->d_tcount, h->part.row_lo,
+                      h->rows, h->d_new, h->d_stats, h->d_ticket, h->LD, gh_fix_blocks(h->LD)};
+        extra = 2u * (unsigned)h->LD;
+    }
+    gh_scope t(h, with_fix ? "knn_select_intersect_fix" : with_intersect ? "knn_select_intersect" : "knn_select");
+    knn_select_kernel<<<dim3((unsigned)h->S + extra), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
         h->d_cand, h->d_cnt, h->K, final_level ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), gh_qs(h->D, h->LD),
         h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S,
-        make_search_args(h, fb_mid, h->own_count, 1, 1), make_inter_args(h, with_intersect));
+        make_search_args(h, fb_mid, h->own_count, 1, 1), make_inter_args(h, with_intersect), fx, (int)h->S);
     GH_LAUNCH_CHECK();
+    if (with_fix) h->fix_done = true;
     return GH_OK;
 }
 
@@ -653,12 +728,26 @@ bool gh_knn_scan_path(const gh_engine *h) {
 // Sample ids (if still pending), query records, list reset and -- on the scan path -- the compact
 // threshold subset: one launch.
 gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint64_t iter) {
-    const int64_t Mtot = own_edges(h);
-    const bool scan = gh_knn_scan_path(h);
-    const int64_t st = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h)) : 1;
-    const int64_t M1 = scan ? (Mtot + st - 1) / st : 0;
+    if (h->thr_stride == 0) {  // fixed at the first use: d_gmin is sized from it
+        const int64_t Mtot = own_edges(h);
+        const bool scan = gh_knn_scan_path(h);
+        h->thr_stride = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h)) : 1;
+        h->thr_M1 = scan ? (Mtot + h->thr_stride - 1) / h->thr_stride : 0;
+    }
+    const int tiles = (int)((h->thr_M1 + GH_THR_TILE - 1) / GH_THR_TILE);
     return gh_setup_args{h->d_edges, sampled, mode, h->E, h->prm.seed, iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
-                         h->d_ovf, h->part.edge_lo, h->d_own_eids, M1, st, h->d_midsub};
+                         h->d_ovf, h->part.edge_lo, h->d_own_eids, reinterpret_cast<const int2 *>(h->d_sub_uv), h->thr_M1, h->thr_stride, h->d_gmin,
+                         (int64_t)tiles * GH_THR_GROUPS, tiles};
+}
+
+// Workgroups of 256 threads a set-up takes (knn_setup_kernel, or the head of a normalise launch).
+unsigned gh_setup_blocks(const gh_setup_args &a) {
+    return a.tiles > 0 ? (unsigned)a.tiles : (unsigned)((a.S + 255) / 256);
+}
+int64_t gh_gmin_floats(const gh_engine *h) {
+    if (!gh_knn_scan_path(h)) return 1;
+    const gh_setup_args a = gh_make_setup_args(const_cast<gh_engine *>(h), 0, nullptr, 0);
+    return h->S * a.Gpad + 4;
 }
 
 gh_status gh_knn_prepare(gh_engine *h) {
@@ -672,43 +761,19 @@ gh_status gh_knn_prepare(gh_engine *h) {
     if (done) return GH_OK;
     const gh_setup_args a = gh_make_setup_args(h, mode, h->d_sampled_cur, h->iter);
     gh_scope t(h, "knn_setup");
-    const int64_t threads = h->S + a.M1 * h->LD;
-    knn_setup_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_pos, a, h->d_tcount,
-                                                                                          h->d_qexact);
+    knn_setup_kernel<<<dim3(gh_setup_blocks(a)), dim3(256), 0, h->stream>>>(h->d_pos, a, h->d_tcount, h->d_qexact);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
 
-// tau of every query from the compact subset (gh_knn_prepare made it).  Needs gh_knn_scan_path(h).
+// tau of every query from the group minima the set-up left in d_gmin.  Needs gh_knn_scan_path(h).
 gh_status gh_knn_thresholds(gh_engine *h) {
-    const int64_t Mtot = own_edges(h);
-    const int64_t st = subset_stride(Mtot, h->K, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h));
-    const int64_t M1 = (Mtot + st - 1) / st;
+    const gh_setup_args a = gh_make_setup_args(h, 0, h->d_sampled_cur, h->iter);
     const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
-    gh_scope t(h, "knn_threshold");
-    // Threads per query workgroup: one workgroup streams its M1 rows pass by pass and each pass is a
-    // memory round trip, so long subsets want more rows in flight (measured, LD = 4: 49K rows
-    // 39 us with 256 threads, 30 us with 512; 99K rows 61 -> 45 us with 1024); short ones and large
-    // K (more waves = a longer merge in the extraction) stay at 256.
-    int nt = (M1 < 24 * 1024 || h->K > 32) ? 256 : M1 < 64 * 1024 ? 512 : 1024;
-    int rpt = nt == 512 ? -1 : 0;  // 512 threads: half the rows per thread
-    if (const char *e = getenv("GRAPHEM_HIP_THRESH_CFG")) sscanf(e, "%d,%d", &nt, &rpt);  // tuning: "NT,RPT"
-#define GH_THR(LDv, NTv, RPTv)                                                                                       \
-    knn_threshold_kernel<LDv, NTv, RPTv><<<dim3((unsigned)h->S), dim3(NTv), 0, h->stream>>>(h->d_midsub, M1, h->D,    \
-                                                                                           h->d_q, h->d_qscan, QS, QT, h->K,           \
-        reinterpret_cast<_Float16 *>(h->d_qA), h->d_qexact, h->tcount_reset_pending ? h->d_tcount : nullptr)
-#define GH_THR_LD(LDv, R0)                                                                                           \
-    const bool half = rpt == -1 || rpt == R0 / 2;                                                                    \
-    if (nt == 256) { if (half) GH_THR(LDv, 256, R0 / 2); else GH_THR(LDv, 256, R0); }                                \
-    else if (nt == 512) { if (half) GH_THR(LDv, 512, R0 / 2); else GH_THR(LDv, 512, R0); }                           \
-    else { if (half) GH_THR(LDv, 1024, R0 / 2); else GH_THR(LDv, 1024, R0); }
-    switch (h->LD) {
-        case 4: { GH_THR_LD(4, 8) } break;
-        case 8: { GH_THR_LD(8, 4) } break;
-        default: { GH_THR_LD(16, 2) } break;
-    }
-#undef GH_THR_LD
-#undef GH_THR
+    gh_scope t(h, "knn_tau");
+    knn_tau_kernel<<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(
+        reinterpret_cast<const uint32_t *>(h->d_gmin), a.Gpad, a.Gpad, h->D, h->d_q, h->d_qscan, QS, QT, h->K,
+        reinterpret_cast<_Float16 *>(h->d_qA), h->d_qexact, h->tcount_reset_pending ? h->d_tcount : nullptr);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

@@ -1,13 +1,24 @@
 #pragma once
-// The per-iteration KNN set-up as work items, shared by knn_setup_kernel (knn.hip: reads the
-// positions) and normalise_kernel (forces.hip: runs the NEXT iteration's set-up in the same launch,
-// taking every position it needs as normalise(new row) -- the same arithmetic the normalising
-// threads apply, hence the same bits -- so it does not wait for them).
-//   item t <  S           : sample id t of the iteration (given / device sampler / arange, pt.py:403-413),
-//                           query record = midpoint of that edge (pt.py:785, pt.py:410) + tau = inf,
-//                           candidate-list and overflow reset
-//   item t >= S           : element (t - S) of the compact (M1, LD) midpoint subset the threshold kernel
-//                           streams: every stride-th own edge
+// The per-iteration KNN set-up, shared by knn_setup_kernel (knn.hip: reads the positions) and the
+// normalise kernels (forces.hip: run the NEXT iteration's set-up in the same launch, taking every
+// position they need as normalise(new row) -- the same arithmetic the normalising threads apply, hence
+// the same bits -- so it does not wait for them).
+//
+// Per query (gh_setup_query): sample id of the iteration (given / device sampler / arange,
+// pt.py:403-413), query record = midpoint of that edge (pt.py:785, pt.py:410) + tau = inf,
+// candidate-list and overflow reset.
+//
+// On the filtered-scan path the set-up also produces what the threshold tau of every query is taken
+// from (gh_setup_block): the squared distances from all S queries to a subset of the own edges (every
+// stride-th, M1 of them), reduced to GROUP MINIMA.  A workgroup takes a tile of GH_THR_TILE subset edges
+// (two row gathers each, midpoints to LDS) and evaluates the exact distance chain of every query against
+// them, keeping the minimum over each group of GH_THR_GSIZE consecutive subset edges ->
+// gmin[query][tile * GH_THR_GROUPS + group].  The K-th smallest
+// of a query's group minima bounds its K-th smallest distance from above (K different groups hold
+// K different edges that close), and with 32 edges per group it is almost always THE K-th smallest of
+// the subset; knn_tau_kernel (knn.hip) extracts it.  This replaced a kernel that streamed a
+// materialised copy of the subset once per query and selected the exact K-th smallest (30 us at
+// 1 M vertices; it was bound by its two K-smallest extractions and its L2 round trips).
 #include "common.h"
 #include "engine.h"
 #include "scan_core.h"
@@ -24,31 +35,140 @@ struct gh_setup_args {
     int32_t *cnt, *ovf;
     int64_t e_lo;
     const int32_t *own_eids;
-    int64_t M1, stride;
-    float *midsub;
+    const int2 *sub_uv;      // (M1) endpoints of the subset edges (static: spares the set-up two dependent loads)
+    int64_t M1, stride;      // subset of the own edges the thresholds come from (0 rows: not on the scan path)
+    float *gmin;             // (S, Gpad) group minima as float bits
+    int64_t Gpad;            // row stride of gmin = 16 * tiles
+    int tiles;               // ceil(M1 / 256): workgroups of gh_setup_block
 };
 
+#define GH_THR_TILE 128    /* subset edges per set-up workgroup */
+#define GH_THR_GSIZE 32    /* subset edges per group */
+#define GH_THR_GROUPS (GH_THR_TILE / GH_THR_GSIZE)   /* group minima per tile and query */
+
+// Sample id, query record and list reset of query t (every query exactly once per iteration).
 template <class P /* float(int64_t vertex, int d) */>
 __device__ __forceinline__ void gh_setup_item(const gh_setup_args &a, int64_t t, P getp) {
-    if (t < a.S) {
-        int32_t e32;
-        if (a.mode == 1) { e32 = gh_sample_id(a.E, a.seed, a.iter, t); a.sampled[t] = e32; }
-        else if (a.mode == 2) { e32 = (int32_t)t; a.sampled[t] = e32; }
-        else e32 = a.sampled[t];
-        const int QS = gh_qs(a.D, a.LD);
-        const int64_t e = e32;
-        const int64_t u = a.edges[2 * e], v = a.edges[2 * e + 1];
-        for (int d = 0; d < QS; ++d) a.qt[t * QS + d] = d < a.D ? (getp(u, d) + getp(v, d)) / 2.0f : 0.0f;
-        a.qt[t * QS + gh_qtau(a.D, a.LD)] = INFINITY;
-        a.cnt[t * GH_CNT_STRIDE] = 0;
-        a.ovf[t] = 0;
-        return;
-    }
-    const int64_t g = t - a.S;
-    if (g >= a.M1 * a.LD) return;
-    const int64_t j = g / a.LD;
-    const int d = (int)(g % a.LD);
-    const int64_t e = a.own_eids ? (int64_t)a.own_eids[j * a.stride] : a.e_lo + j * a.stride;
+    if (t >= a.S) return;
+    int32_t e32;
+    if (a.mode == 1) { e32 = gh_sample_id(a.E, a.seed, a.iter, t); a.sampled[t] = e32; }
+    else if (a.mode == 2) { e32 = (int32_t)t; a.sampled[t] = e32; }
+    else e32 = a.sampled[t];
+    const int QS = gh_qs(a.D, a.LD);
+    const int64_t e = e32;
     const int64_t u = a.edges[2 * e], v = a.edges[2 * e + 1];
-    a.midsub[g] = d < a.D ? (getp(u, d) + getp(v, d)) / 2.0f : 0.0f;
+    for (int d = 0; d < QS; ++d) a.qt[t * QS + d] = d < a.D ? (getp(u, d) + getp(v, d)) / 2.0f : 0.0f;
+    a.qt[t * QS + gh_qtau(a.D, a.LD)] = INFINITY;
+    a.cnt[t * GH_CNT_STRIDE] = 0;
+    a.ovf[t] = 0;
+}
+
+// Minimum over each row of 16 lanes of non-negative float bits (they order like unsigned integers):
+// quad swaps, half-row and row mirrors on the DPP datapath; every lane returns its row's minimum.
+template <int CTRL>
+__device__ __forceinline__ uint32_t gh_dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t gh_row_min_u32(uint32_t v) {
+    v = min(v, gh_dpp_u32<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = min(v, gh_dpp_u32<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = min(v, gh_dpp_u32<0x141>(v));  // row_half_mirror
+    v = min(v, gh_dpp_u32<0x140>(v));  // row_mirror
+    return v;
+}
+
+// Tile `blk` of the threshold subset against all S queries -> gmin (see the header comment).  Whole
+// 256-thread workgroup; lds: GH_SETUP_LDS_BYTES.  A LANE OWNS A QUERY (its coordinates stay in
+// registers: sample id, the edge, two row gathers), the tile's GH_THR_TILE subset midpoints sit in LDS
+// and stream past every lane as broadcast reads: per pair the exact distance chain and one integer min,
+// no cross-lane traffic; after every GH_THR_GSIZE references the running minimum is one group minimum.
+// (The first version put references on lanes and reduced over them on the DPP datapath: 256 dependent
+// LDS-read / DPP chains per wave, 40 us.)  Workgroup 0 also does the per-query set-up items.
+#define GH_SETUP_LDS_BYTES (GH_THR_TILE * 16 * 4)
+template <int LD, class P>
+__device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, P getp, unsigned char *lds) {
+    float4 *rsh = reinterpret_cast<float4 *>(lds);     // [GH_THR_TILE][LD / 4]
+    const int t = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);  // inside a normalise launch these waves sit among streaming ones: their chains go first
+    // this lane's first query (every workgroup needs all of them; issued before the tile so that both chains of
+    // dependent loads -- id -> edge -> rows here, endpoints -> rows below -- are in flight together)
+    auto query = [&](int64_t s, int32_t &e32, float (&q)[LD]) {
+        if (a.mode == 1) e32 = gh_sample_id(a.E, a.seed, a.iter, s);
+        else if (a.mode == 2) e32 = (int32_t)s;
+        else e32 = a.sampled[s];
+        const int2 uv = reinterpret_cast<const int2 *>(a.edges)[e32];
+#pragma unroll
+        for (int d = 0; d < LD; ++d) q[d] = d < a.D ? (getp(uv.x, d) + getp(uv.y, d)) / 2.0f : 0.0f;
+    };
+    float q[LD];
+    int32_t e32 = 0;
+    if (t < a.S) query(t, e32, q);
+    if (t < GH_THR_TILE) {
+        const int64_t j = (int64_t)blk * GH_THR_TILE + t;
+        float m[LD];
+#pragma unroll
+        for (int d = 0; d < LD; ++d) m[d] = 0.0f;
+        if (j < a.M1) {
+            const int2 uv = a.sub_uv[j];
+#pragma unroll
+            for (int d = 0; d < LD; ++d)
+                if (d < a.D) m[d] = (getp(uv.x, d) + getp(uv.y, d)) / 2.0f;
+        } else {
+            m[0] = INFINITY;  // padding slot: (q - inf)^2 = inf for every finite query
+        }
+#pragma unroll
+        for (int i = 0; i < LD / 4; ++i) rsh[t * (LD / 4) + i] = make_float4(m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]);
+    }
+    __syncthreads();
+    for (int64_t s0 = 0; s0 < a.S; s0 += 256) {
+        const int64_t s = s0 + t;
+        if (s >= a.S) continue;   // no barrier below
+        if (s0 > 0) query(s, e32, q);
+        if (blk == 0) {  // the set-up item of this query (gh_setup_item), from the coordinates at hand
+            if (a.mode != 0) a.sampled[s] = e32;
+            const int QS = gh_qs(a.D, a.LD);
+#pragma unroll
+            for (int d = 0; d < LD; ++d)
+                if (d < QS) a.qt[s * QS + d] = q[d];  // pad coordinates are 0
+            for (int d = LD; d < QS; ++d) a.qt[s * QS + d] = 0.0f;
+            a.qt[s * QS + gh_qtau(a.D, a.LD)] = INFINITY;
+            a.cnt[s * GH_CNT_STRIDE] = 0;
+            a.ovf[s] = 0;
+        }
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.gmin) + s * a.Gpad + (int64_t)blk * GH_THR_GROUPS;
+#pragma unroll 1
+        for (int g4 = 0; g4 < GH_THR_GROUPS; g4 += 4) {
+            uint32_t mn[4];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                uint32_t best = 0x7F800000u;
+#pragma unroll
+                for (int r = 0; r < GH_THR_GSIZE; ++r) {
+                    const int ref = (g4 + gg) * GH_THR_GSIZE + r;
+                    float d2 = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < LD / 4; ++i) {
+                        const float4 mv = rsh[ref * (LD / 4) + i];  // broadcast read
+                        const float mm[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {  // pad coordinates are 0 on both sides: fma(0, 0, s) == s
+                            const float df = q[4 * i + c] - mm[c];
+                            d2 = fmaf(df, df, d2);
+                        }
+                    }
+                    best = min(best, __float_as_uint(d2));
+                }
+                mn[gg] = best;
+            }
+            *reinterpret_cast<uint4 *>(dst + g4) = make_uint4(mn[0], mn[1], mn[2], mn[3]);
+        }
+    }
+}
+
+// Runtime row stride -> the instantiation (the scan path has LD in {4, 8, 16}).
+template <class P>
+__device__ __forceinline__ void gh_setup_block_any(const gh_setup_args &a, int blk, P getp, unsigned char *lds) {
+    if (a.LD == 4) gh_setup_block<4>(a, blk, getp, lds);
+    else if (a.LD == 8) gh_setup_block<8>(a, blk, getp, lds);
+    else gh_setup_block<16>(a, blk, getp, lds);
 }
