@@ -23,6 +23,8 @@ SYMBOLS = [
     "gh_positions_rows_allocated", "gh_knn_points", "gh_stats_rows", "gh_spmv_symnorm",
     "gh_spectral_last_error", "gh_gather_layout", "gh_gather_buffer_device", "gh_gather_slot_bytes",
     "gh_step_finish_gathered", "gh_vertex_order", "gh_positions_unpadded_device", "gh_radial_topk",
+    "gh_comm_unique_id", "gh_comm_init_rccl", "gh_loopback_group_create", "gh_loopback_group_destroy",
+    "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error",
 ]
 
 
@@ -121,6 +123,22 @@ def load():
     L.gh_knn_points.restype = ctypes.c_int
     L.gh_knn_last_counts.argtypes = [vp, vp, vp, vp]
     L.gh_knn_last_counts.restype = ctypes.c_int
+    L.gh_comm_unique_id.argtypes = [vp]
+    L.gh_comm_unique_id.restype = ctypes.c_int
+    L.gh_comm_init_rccl.argtypes = [vp, i32, i32, vp]
+    L.gh_comm_init_rccl.restype = ctypes.c_int
+    L.gh_loopback_group_create.argtypes = [i32]
+    L.gh_loopback_group_create.restype = vp
+    L.gh_loopback_group_destroy.argtypes = [vp]
+    L.gh_loopback_group_destroy.restype = None
+    L.gh_comm_init_loopback.argtypes = [vp, vp, i32]
+    L.gh_comm_init_loopback.restype = ctypes.c_int
+    L.gh_comm_destroy.argtypes = [vp]
+    L.gh_comm_destroy.restype = ctypes.c_int
+    L.gh_run_partitioned.argtypes = [vp, i32, vp]
+    L.gh_run_partitioned.restype = ctypes.c_int
+    L.gh_comm_last_error.argtypes = []
+    L.gh_comm_last_error.restype = ctypes.c_char_p
     L.gh_device_count.argtypes = []
     L.gh_device_count.restype = i32
     L.gh_version.argtypes = []
@@ -299,6 +317,26 @@ class Engine:
     def step_finish_gathered(self):
         self._chk(self.lib.gh_step_finish_gathered(self.handle))
 
+    # the whole partitioned run in one call (csrc/comm.hip)
+    def comm_init_rccl(self, world, rank, unique_id):
+        """unique_id: the 128 bytes rank 0 got from comm_unique_id(), the same on every rank."""
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self.lib.gh_comm_init_rccl(self.handle, int(world), int(rank), ctypes.cast(buf, ctypes.c_void_p)))
+
+    def comm_init_loopback(self, group, rank):
+        self._chk(self.lib.gh_comm_init_loopback(self.handle, group, int(rank)))
+
+    def comm_destroy(self):
+        self._chk(self.lib.gh_comm_destroy(self.handle))
+
+    def run_partitioned(self, iters, sample_stream=None):
+        ss = None
+        if sample_stream is not None:
+            ss = np.ascontiguousarray(sample_stream, dtype=np.int32)
+            if self.S < self.E and ss.shape != (iters, self.S):
+                raise ValueError(f"sample_stream must have shape {(iters, self.S)}, got {ss.shape}")
+        self._chk(self.lib.gh_run_partitioned(self.handle, int(iters), ptr(ss)))
+
     def positions_device_ptr(self):
         return self.lib.gh_positions_device(self.handle)
 
@@ -342,6 +380,15 @@ def knn_points(query, reference, k, device_id=0):
                               query.shape[1], int(k), ptr(out))
     raise_for(st, None)
     return out
+
+
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator (ncclGetUniqueId); rank 0 makes it, every rank gets a copy."""
+    buf = ctypes.create_string_buffer(128)
+    st = load().gh_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p))
+    if st != GH_OK:
+        raise RuntimeError(load().gh_comm_last_error().decode())
+    return buf.raw
 
 
 def device_count():

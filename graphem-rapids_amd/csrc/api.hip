@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_terms, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_ticket, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -342,7 +342,6 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_tflag, (size_t)n, true);
     GH_A(d_touched, 4 * S * (size_t)h->k, false);
     GH_A(d_tcount, 1, true);
-    GH_A(d_ticket, 1, true);
     GH_A(d_sampled, S, true);
     GH_A(d_q, S * (size_t)(h->LD + 4), true);
     GH_A(d_qscan, S * (size_t)(h->LD + 4), true);
@@ -407,6 +406,7 @@ extern "C" void gh_destroy(gh_handle h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     resolve_timers(h);
+    gh_comm_free(h);
     free_all(h);
     delete h;
 }
@@ -503,7 +503,7 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
 // fuse_intersect: single-rank step, the KNN kernels also run the intersection phase.
 static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
     h->intersect_done = false;
-    h->fix_done = false;
+    h->stats_reduced = false;
     h->new0_ready = false;
     if (h->S == 0 || h->k == 0) {  // nothing sampled / no neighbours asked for: spring forces only
         h->sample_pending = false;
@@ -550,25 +550,34 @@ extern "C" gh_status gh_step(gh_handle h, const int32_t *sampled) {
     return step_finish(h, sampled ? -1 : (h->S >= h->E ? 2 : 1));
 }
 
+// Uploads an (iters, S) host id stream for a run (validated); *d_ids = nullptr when the run draws its own ids
+// (no stream given, or S >= E where the reference uses arange, pt.py:412).
+gh_status gh_upload_sample_stream(gh_engine *h, int32_t iters, const int32_t *sample_stream, const int32_t **d_ids) {
+    *d_ids = nullptr;
+    if (!sample_stream || h->S >= h->E || iters <= 0) return GH_OK;
+    const size_t cnt = (size_t)iters * (size_t)h->S;
+    for (size_t i = 0; i < cnt; ++i)
+        if (sample_stream[i] < 0 || sample_stream[i] >= h->E) { h->err = "sampled edge id out of range"; return GH_ERR_INVALID; }
+    if (cnt > h->stream_ids_cap) {
+        if (h->d_stream_ids) { GH_HIP(hipStreamSynchronize(h->stream)); GH_HIP(hipFree(h->d_stream_ids)); h->d_stream_ids = nullptr; }
+        GH_TRY(dev_alloc(h, &h->d_stream_ids, cnt, false));
+        h->stream_ids_cap = cnt;
+    }
+    GH_HIP(hipMemcpyAsync(h->d_stream_ids, sample_stream, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    *d_ids = h->d_stream_ids;
+    return GH_OK;
+}
+
 extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_stream) {
     GH_TRY(check_handle(h));
     if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
     if (iters == 0) return GH_OK;
     GH_TRY(check_whole(h, "gh_run"));
     GH_TRY(check_k(h));
-    const bool use_stream = sample_stream && h->S < h->E;
-    if (use_stream) {
-        const size_t cnt = (size_t)iters * (size_t)h->S;
-        for (size_t i = 0; i < cnt; ++i)
-            if (sample_stream[i] < 0 || sample_stream[i] >= h->E) { h->err = "sampled edge id out of range"; return GH_ERR_INVALID; }
-        if (cnt > h->stream_ids_cap) {
-            if (h->d_stream_ids) { GH_HIP(hipStreamSynchronize(h->stream)); GH_HIP(hipFree(h->d_stream_ids)); h->d_stream_ids = nullptr; }
-            GH_TRY(dev_alloc(h, &h->d_stream_ids, cnt, false));
-            h->stream_ids_cap = cnt;
-        }
-        GH_HIP(hipMemcpyAsync(h->d_stream_ids, sample_stream, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, h->stream));
-        GH_HIP(hipStreamSynchronize(h->stream));
-    }
+    const int32_t *d_ids = nullptr;
+    GH_TRY(gh_upload_sample_stream(h, iters, sample_stream, &d_ids));
+    const bool use_stream = d_ids != nullptr;
     for (int32_t t = 0; t < iters; ++t) {
         GH_TRY(set_sample(h, nullptr, use_stream ? h->d_stream_ids + (size_t)t * h->S : nullptr));
         GH_TRY(step_begin(h, true));
@@ -595,6 +604,14 @@ extern "C" gh_status gh_step_begin(gh_handle h, const int32_t *sampled) {
     GH_TRY(check_k(h));
     h->last_step_own_ids = sampled == nullptr;
     GH_TRY(set_sample(h, sampled, nullptr));
+    return step_begin(h, false);
+}
+// Part 1 of a split step with the ids already on the device (a row of an uploaded stream), or nullptr: the
+// engine draws them itself, identically on every rank (comm.hip gh_run_partitioned).
+gh_status gh_step_begin_device_ids(gh_engine *h, const int32_t *dev_ids) {
+    GH_TRY(check_k(h));
+    h->last_step_own_ids = dev_ids == nullptr;
+    GH_TRY(set_sample(h, nullptr, dev_ids));
     return step_begin(h, false);
 }
 extern "C" gh_status gh_set_stream(gh_handle h, void *hip_stream, int32_t use_own) {

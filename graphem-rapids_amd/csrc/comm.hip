@@ -1,0 +1,228 @@
+// The partitioned layout loop without the host language in it:
+// gh_run_partitioned enqueues, per iteration, part 1 (spring pull + KNN scan of the own rows / edges), the
+// all-gather of the ranks' S x (k+1) keys, part 2 (merge, intersection forces, integrate own rows), the
+// in-place all-gather of the ranks' slots (new rows + column statistics) and part 3 (normalise all n rows) --
+// kernels and collectives on ONE stream, no host synchronisation inside the loop.
+//
+// Collective backends behind one small interface:
+//   RCCL      ncclAllGather on the engine's stream.  librccl.so is opened at gh_comm_init_rccl() (dlopen), so the
+//             library itself has no link-time dependency on it; the communicator is created from a 128-byte
+//             unique id that rank 0 makes (gh_comm_unique_id) and the caller distributes (torch.distributed,
+//             MPI, a file: whatever launched the ranks).
+//   loopback  several engines of ONE process (one thread per engine) exchange through device-to-device copies
+//             at a host rendezvous.  Lets the multi-rank loop run -- and be tested -- on a single GPU, where
+//             RCCL refuses two ranks on one device.
+#include "common.h"
+#include "engine.h"
+
+#include <dlfcn.h>
+#include <string.h>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include <rccl/rccl.h>
+
+// ---- RCCL through dlopen -------------------------------------------------------------------
+namespace {
+
+struct rccl_api {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+rccl_api *rccl() {
+    static rccl_api api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *nm : names) {
+            api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) { api.err = std::string("cannot open librccl.so: ") + dlerror(); return; }
+        auto sym = [&](const char *s) { void *p = dlsym(api.lib, s); if (!p) api.err = std::string("librccl.so lacks ") + s; return p; };
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return &api;
+}
+
+thread_local std::string g_comm_error;
+
+}  // namespace
+
+// ---- loopback group -----------------------------------------------------------------------
+struct gh_loop_group {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void *> send;
+    bool failed = false;
+
+    // every rank calls with the same sequence of collectives; returns after all ranks arrived
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
+struct gh_comm {
+    int world = 1, rank = 0;
+    ncclComm_t nccl = nullptr;          // RCCL backend
+    gh_loop_group *loop = nullptr;      // loopback backend
+    uint64_t *d_gathered = nullptr;     // (world, S, K) keys of all ranks
+};
+
+static gh_status comm_all_gather(gh_engine *h, const void *send, void *recv, size_t bytes, const char *what) {
+    gh_comm *c = h->comm;
+    gh_scope t(h, what);
+    if (c->nccl) {
+        const ncclResult_t r = rccl()->AllGather(send, recv, bytes, ncclUint8, c->nccl, h->stream);
+        if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + rccl()->GetErrorString(r); return GH_ERR_RUNTIME; }
+        return GH_OK;
+    }
+    // loopback: what the ranks send must be complete before anybody copies it, and nobody may start
+    // overwriting its send buffer (the next iteration) before everybody has copied
+    gh_loop_group *g = c->loop;
+    GH_HIP(hipStreamSynchronize(h->stream));
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->send[(size_t)c->rank] = send;
+    }
+    g->barrier();
+    for (int r = 0; r < c->world; ++r) {
+        void *dst = static_cast<unsigned char *>(recv) + (size_t)r * bytes;
+        const void *src = g->send[(size_t)r];
+        if (dst != src) GH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+    GH_HIP(hipStreamSynchronize(h->stream));
+    g->barrier();
+    return GH_OK;
+}
+
+extern "C" const char *gh_comm_last_error(void) { return g_comm_error.c_str(); }
+
+extern "C" gh_status gh_comm_unique_id(void *out128) {
+    if (!out128) { g_comm_error = "out is NULL"; return GH_ERR_INVALID; }
+    rccl_api *api = rccl();
+    if (!api->err.empty()) { g_comm_error = api->err; return GH_ERR_RUNTIME; }
+    ncclUniqueId id;
+    const ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) { g_comm_error = std::string("ncclGetUniqueId: ") + api->GetErrorString(r); return GH_ERR_RUNTIME; }
+    memcpy(out128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return GH_OK;
+}
+
+static gh_status comm_common(gh_engine *h, int world, int rank) {
+    if (h->comm) { h->err = "a communicator is already attached"; return GH_ERR_INVALID; }
+    if (!h->d_gbuf || h->g_world != world || h->g_rank != rank) {
+        h->err = "call gh_gather_layout(world, rank, chunk) first, with the same world and rank";
+        return GH_ERR_INVALID;
+    }
+    h->comm = new (std::nothrow) gh_comm();
+    if (!h->comm) { h->err = "out of host memory"; return GH_ERR_NOMEM; }
+    h->comm->world = world;
+    h->comm->rank = rank;
+    if (hipMalloc(reinterpret_cast<void **>(&h->comm->d_gathered), sizeof(uint64_t) * (size_t)world * h->S * h->K + 16) != hipSuccess) {
+        delete h->comm; h->comm = nullptr;
+        h->err = "hipMalloc of the gathered key buffer failed";
+        return GH_ERR_NOMEM;
+    }
+    return GH_OK;
+}
+
+extern "C" gh_status gh_comm_init_rccl(gh_handle h, int32_t world, int32_t rank, const void *unique_id128) {
+    if (!h) return GH_ERR_INVALID;
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GH_ERR_HIP; }
+    if (!unique_id128 || world < 1 || rank < 0 || rank >= world) { h->err = "bad communicator arguments"; return GH_ERR_INVALID; }
+    rccl_api *api = rccl();
+    if (!api->err.empty()) { h->err = api->err; return GH_ERR_RUNTIME; }
+    GH_TRY_ST(comm_common(h, world, rank));
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id128, NCCL_UNIQUE_ID_BYTES);
+    const ncclResult_t r = api->CommInitRank(&h->comm->nccl, world, id, rank);
+    if (r != ncclSuccess) {
+        h->err = std::string("ncclCommInitRank: ") + api->GetErrorString(r);
+        (void)hipFree(h->comm->d_gathered);
+        delete h->comm; h->comm = nullptr;
+        return GH_ERR_RUNTIME;
+    }
+    return GH_OK;
+}
+
+extern "C" gh_loop_group *gh_loopback_group_create(int32_t world) {
+    if (world < 1) return nullptr;
+    gh_loop_group *g = new (std::nothrow) gh_loop_group();
+    if (!g) return nullptr;
+    g->world = world;
+    g->send.assign((size_t)world, nullptr);
+    return g;
+}
+extern "C" void gh_loopback_group_destroy(gh_loop_group *g) { delete g; }
+
+extern "C" gh_status gh_comm_init_loopback(gh_handle h, gh_loop_group *group, int32_t rank) {
+    if (!h) return GH_ERR_INVALID;
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GH_ERR_HIP; }
+    if (!group || rank < 0 || rank >= group->world) { h->err = "bad loopback group / rank"; return GH_ERR_INVALID; }
+    GH_TRY_ST(comm_common(h, group->world, rank));
+    h->comm->loop = group;
+    return GH_OK;
+}
+
+void gh_comm_free(gh_engine *h) {
+    if (!h->comm) return;
+    if (h->comm->nccl) (void)rccl()->CommDestroy(h->comm->nccl);
+    if (h->comm->d_gathered) (void)hipFree(h->comm->d_gathered);
+    delete h->comm;
+    h->comm = nullptr;
+}
+
+extern "C" gh_status gh_comm_destroy(gh_handle h) {
+    if (!h) return GH_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    gh_comm_free(h);
+    return GH_OK;
+}
+
+extern "C" gh_status gh_run_partitioned(gh_handle h, int32_t iters, const int32_t *sample_stream) {
+    if (!h) return GH_ERR_INVALID;
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GH_ERR_HIP; }
+    if (!h->comm) { h->err = "no communicator: call gh_comm_init_rccl / gh_comm_init_loopback first"; return GH_ERR_INVALID; }
+    if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
+    gh_comm *c = h->comm;
+    const size_t key_bytes = sizeof(uint64_t) * (size_t)h->S * h->K;
+    const int32_t *d_ids = nullptr;
+    GH_TRY_ST(gh_upload_sample_stream(h, iters, sample_stream, &d_ids));   // nullptr: device sampler / arange on every rank
+    for (int32_t t = 0; t < iters; ++t) {
+        GH_TRY_ST(gh_step_begin_device_ids(h, d_ids ? d_ids + (size_t)t * h->S : nullptr));
+        if (h->S > 0 && h->k > 0) {
+            GH_TRY_ST(comm_all_gather(h, h->d_partial, c->d_gathered, key_bytes, "allgather_keys"));
+            GH_TRY_ST(gh_step_merge(h, c->d_gathered, c->world));
+        } else {
+            GH_TRY_ST(gh_step_merge(h, h->d_partial, 1));   // spring forces only: nothing to merge
+        }
+        GH_TRY_ST(comm_all_gather(h, h->d_gbuf + (size_t)c->rank * h->g_slot, h->d_gbuf, (size_t)h->g_slot, "allgather_slots"));
+        GH_TRY_ST(gh_step_finish_gathered(h));
+    }
+    return GH_OK;
+}

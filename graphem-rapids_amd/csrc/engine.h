@@ -28,8 +28,11 @@ struct gh_timer_slot {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 };
 
+struct gh_comm;   // comm.hip: collective backend of the native partitioned loop
+
 struct gh_engine {
     int device = 0;
+    gh_comm *comm = nullptr;
     int64_t n = 0, E = 0;
     int D = 0, LD = 0, k = 0, K = 0;
     int64_t S = 0;
@@ -92,8 +95,7 @@ struct gh_engine {
     size_t stream_ids_cap = 0;
     bool new0_ready = false;      // the fused kernel of this step wrote d_new = pos + Fs and its block sums
     bool intersect_done = false;  // the KNN kernels of this step already ran the intersection phase
-    bool fix_done = false;        // ... and finished the step's statistics (the stats_fix part, knn.hip fix_args)
-    int32_t *d_ticket = nullptr;  // (1) arrival counter of that launch, zero between launches
+    bool stats_reduced = false;   // ... and reduced the fused kernel's workgroup sums into d_stats (knn_select_kernel)
     bool presetup_valid = false;  // the last normalise launch also ran the KNN set-up of iteration presetup_iter
     int presetup_mode = 0;        //   with this sample mode / id pointer (gh_knn_prepare then skips its kernel)
     const int32_t *presetup_ids = nullptr;
@@ -143,6 +145,10 @@ struct gh_scope {
     ~gh_scope();
 };
 
+// api.hip / comm.hip
+gh_status gh_upload_sample_stream(gh_engine *h, int32_t iters, const int32_t *sample_stream, const int32_t **d_ids);
+gh_status gh_step_begin_device_ids(gh_engine *h, const int32_t *dev_ids);
+void gh_comm_free(gh_engine *h);
 // knn.hip
 gh_status gh_knn_local(gh_engine *h, bool fuse_intersect);  // d_sampled, d_mid -> d_partial (unfused)
 bool gh_knn_scan_path(const gh_engine *h);

@@ -265,10 +265,10 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
                                                        const int32_t *__restrict__ touched,
                                                        const int32_t *__restrict__ tcount, int64_t row_lo,
                                                        int64_t rows, float *__restrict__ out_new,
-                                                       double *__restrict__ stats) {
+                                                       double *__restrict__ stats, int skip_reduce) {
     __shared__ double red[4][2 * LD];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    {
+    if (!skip_reduce) {  // (the select launch of a single-rank step has done this part already)
         const int c = blockIdx.x;  // gridDim.x == 2 * LD
         double s = 0.0;
         // four independent partial sums per thread (loads in flight), combined in a fixed order
@@ -656,18 +656,14 @@ gh_status gh_launch_mid_only(gh_engine *h) { return launch_mid_gather(h); }
 
 // new = pos + (Fs + Fi) for the own rows -> d_new, column statistics -> d_stats.
 gh_status gh_launch_integrate(gh_engine *h) {
-    if (h->fix_done) {  // the select launch of this step has finished the statistics as well (knn.hip fix_args)
-        h->fix_done = false;
-        h->new0_ready = false;
-        return GH_OK;
-    }
     if (h->new0_ready && h->rows > 0) {  // the fused kernel already wrote pos + Fs and its partial sums
         h->new0_ready = false;
         gh_scope t(h, "stats_fix");
+        const struct reset_flag { gh_engine *e; ~reset_flag() { e->stats_reduced = false; } } reset{h};
 #define GH_FIX_CASE(LL)                                                                                      \
     stats_fix_kernel<LL><<<dim3(gh_fix_blocks(LL)), dim3(256), 0, h->stream>>>(                                  \
         h->d_blockstats, h->n_vblocks, h->d_pos, h->d_Fs, h->d_acc, h->d_touched, h->d_tcount, h->part.row_lo, \
-        h->rows, h->d_new, h->d_stats)
+        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0)
         if (h->LD == 4) GH_FIX_CASE(4);
         else if (h->LD == 8) GH_FIX_CASE(8);
         else GH_FIX_CASE(16);

@@ -37,8 +37,7 @@ __device__ inline void gh_intersect_pair(const float *__restrict__ pos, int D, i
         const float dist = sqrtf(gh_sumsq_rt(diff, D)) + 1e-6f;
         const float dd = dist * dist;
         for (int d = 0; d < D; ++d) atomicAdd(&acc[(int64_t)v[role] * LD + d], (double)((k_inter * diff[d]) / dd));
-        if (atomicExch(&tflag[v[role]], 1) == 0)  // write-through store: read by another CU in the same launch (knn.hip fix_finish)
-            __hip_atomic_store(&touched[atomicAdd(tcount, 1)], v[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (atomicExch(&tflag[v[role]], 1) == 0) touched[atomicAdd(tcount, 1)] = v[role];
     }
 }
 
@@ -71,8 +70,7 @@ __device__ __forceinline__ void gh_intersect_pair_t(const float *__restrict__ po
         const float dd = dist * dist;
 #pragma unroll
         for (int d = 0; d < D; ++d) atomicAdd(&acc[(int64_t)v[role] * LD + d], (double)((k_inter * diff[d]) / dd));
-        if (atomicExch(&tflag[v[role]], 1) == 0)  // write-through store: read by another CU in the same launch (knn.hip fix_finish)
-            __hip_atomic_store(&touched[atomicAdd(tcount, 1)], v[role], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (atomicExch(&tflag[v[role]], 1) == 0) touched[atomicAdd(tcount, 1)] = v[role];
     }
 }
 

@@ -381,11 +381,11 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
 // registers (more than 64 * NV groups: folded by min, which only makes groups coarser), K rounds of a
 // wave-wide minimum retire the smallest value each (equal values retire together: the bound can only
 // get looser).  Then the pre-filter records of the scan (scan_core.h).
+template <int NV>
 __global__ __launch_bounds__(64) void knn_tau_kernel(const uint32_t *__restrict__ gmin, int64_t G, int64_t Gpad, int D,
                                                     float *__restrict__ qt, float *__restrict__ qscan, int QS, int QT,
                                                     int K, _Float16 *__restrict__ qA, int32_t *__restrict__ qexact,
                                                     int32_t *__restrict__ tcount_reset) {
-    constexpr int NV = 32;
     // set-up done inside the previous normalise launch: the touched-list counter is reset here instead
     if (tcount_reset && blockIdx.x == 0 && threadIdx.x == 0) *tcount_reset = 0;
     const int64_t qi = blockIdx.x;
@@ -444,104 +444,6 @@ __global__ __launch_bounds__(64) void knn_tau_kernel(const uint32_t *__restrict_
     }
 }
 
-// The tail of a single-rank fused step inside the select launch (was stats_fix_kernel, its own launch
-// of 2*LD workgroups: 9-12 us on the critical path).  fx.stats == nullptr: not used.
-//   * workgroups S .. S+2*LD-1 reduce one column of the fused kernel's per-workgroup sums each ->
-//     stats[c] (fixed order);
-//   * every workgroup takes a ticket when it is done; the LAST one then owns the rows the
-//     intersection phase touched: new = pos + (Fs + Fi) replaces new0 = pos + Fs (pt.py:796-799) and the
-//     column sums of (new - new0), (new^2 - new0^2) go to the first correction row pair of the
-//     statistics buffer (normalise_kernel adds the rows up).  Release / acquire at agent scope around the
-//     ticket (MI355X guide, Guideline 16): the touched list is written with plain stores by other CUs.
-struct fix_args {
-    const double *blockstats;
-    int nblocks;
-    const float *pos, *Fs;
-    const double *acc;
-    const int32_t *touched, *tcount;
-    int64_t row_lo, rows;
-    float *out_new;
-    double *stats;
-    int32_t *ticket;
-    int LD, nfix;
-};
-
-template <int LD>
-__device__ void fix_touched_rows(const fix_args &fx, double (*red)[2 * 16]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double dx[LD], dxx[LD];
-#pragma unroll
-    for (int d = 0; d < LD; ++d) { dx[d] = 0.0; dxx[d] = 0.0; }
-    const int nt = __hip_atomic_load(fx.tcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-        const int64_t x = __hip_atomic_load(&fx.touched[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int64_t i = x - fx.row_lo;
-        if (i < 0 || i >= fx.rows) continue;
-        float p[LD], f[LD], nw[LD];
-        gh_load_row<LD>(fx.pos, x, p);
-        gh_load_row<LD>(fx.Fs, i, f);
-#pragma unroll
-        for (int d = 0; d < LD; ++d) {
-            const float n0 = p[d] + f[d];
-            const float tot = f[d] + (float)__hip_atomic_load(&fx.acc[x * LD + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            nw[d] = p[d] + tot;
-            dx[d] += (double)nw[d] - (double)n0;
-            dxx[d] += (double)nw[d] * (double)nw[d] - (double)n0 * (double)n0;
-        }
-        gh_store_row<LD>(fx.out_new, i, nw);
-    }
-#pragma unroll
-    for (int d = 0; d < LD; ++d) {
-        const double a = gh_wave_sum(dx[d]), b = gh_wave_sum(dxx[d]);
-        if (lane == 0) { red[w][d] = a; red[w][LD + d] = b; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * LD)
-        fx.stats[2 * LD + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-    // the other correction row pairs stay zero (the stand-alone stats_fix_kernel fills one per workgroup)
-    for (int i = 4 * LD + threadIdx.x; i < (2 + 2 * fx.nfix) * LD; i += blockDim.x) fx.stats[i] = 0.0;
-}
-
-// Column c of the per-workgroup sums -> stats[c] (the first part of stats_fix_kernel, same order).
-__device__ void fix_reduce_column(const fix_args &fx, int c, double (*red)[2 * 16]) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double s4[4] = {0.0, 0.0, 0.0, 0.0};
-    const double *col = fx.blockstats + (int64_t)c * fx.nblocks;
-    int b = threadIdx.x;
-    for (; b + 3 * (int)blockDim.x < fx.nblocks; b += 4 * blockDim.x) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) s4[u] += col[b + u * blockDim.x];
-    }
-    for (int u = 0; b < fx.nblocks; b += blockDim.x, ++u) s4[u] += col[b];
-    const double a = gh_wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
-    if (lane == 0) red[w][0] = a;
-    __syncthreads();
-    if (threadIdx.x == 0) fx.stats[c] = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
-}
-
-// Ticket + last-arriver part; call with the whole workgroup, after all its global writes.
-__device__ void fix_finish(const fix_args &fx, int total, double (*red)[2 * 16], int *last_flag) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // no agent-scope release here: right after the fused kernel the L2s hold tens of MB of dirty lines and a
-        // buffer_wbl2 per workgroup cost +20 us (measured).  What the last workgroup reads from this launch is either
-        // written by atomics (acc, tcount: performed at the memory side) or by write-through stores (the touched
-        // list, intersect_core.h); __syncthreads() above has drained every wave's stores (vmcnt(0)).
-        const int t = atomicAdd(fx.ticket, 1);
-        *last_flag = t == total - 1;
-        if (t == total - 1) {
-            *fx.ticket = 0;  // nobody else touches it before the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (!*last_flag) return;
-    if (fx.LD == 4) fix_touched_rows<4>(fx, red);
-    else if (fx.LD == 8) fix_touched_rows<8>(fx, red);
-    else fix_touched_rows<16>(fx, red);
-}
-
 // One workgroup per query: K smallest of the candidate list; final -> K best keys (and the
 // intersection phase of the query when ia is set), else tighten tau.  A final list that overflowed
 // is not trustworthy: that query is searched exactly over all own edges right here (fb), which is
@@ -550,18 +452,32 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
                                                          int K, int final_level, float *__restrict__ tau, int QS,
                                                          uint64_t *__restrict__ out_keys,
                                                          int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
-                                                         search_args fb, inter_args ia, fix_args fx, int S) {
+                                                         search_args fb, inter_args ia, int S,
+                                                         const double *__restrict__ blockstats, int nblocks,
+                                                         double *__restrict__ stats) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats (exact search only)
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
-    __shared__ double fred[4][2 * 16];
-    __shared__ int last_flag;
     constexpr int NPT = GH_CAND_CAP / 256;
     const int64_t qi = blockIdx.x;
-    if (qi >= S) {  // the column reducers of the fused step's statistics (fx.stats set)
-        fix_reduce_column(fx, (int)(qi - S), fred);
-        fix_finish(fx, (int)gridDim.x, fred, &last_flag);
+    if (qi >= S) {
+        // Workgroups past the queries (single-rank fused steps): column qi - S of the fused kernel's per-workgroup
+        // sums -> stats, in a fixed order.  It depends on the fused kernel only, so it runs beside the selection
+        // instead of in front of the touched-row corrections of stats_fix_kernel (forces.hip).
+        double *dred = reinterpret_cast<double *>(red);
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+        const double *col = blockstats + (qi - S) * nblocks;
+        int b = threadIdx.x;
+        for (; b + 3 * 256 < nblocks; b += 4 * 256) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] += col[b + u * 256];
+        }
+        for (int u = 0; b < nblocks; b += 256, ++u) s4[u] += col[b];
+        const double a = gh_wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3]));
+        if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) stats[qi - S] = ((dred[0] + dred[1]) + dred[2]) + dred[3];
         return;
     }
     const int c = cnt[qi * GH_CNT_STRIDE];
@@ -580,7 +496,6 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     } else if (threadIdx.x == 0) {
         tau[qi * QS] = gh_key_d2(best[K - 1]);
     }
-    if (fx.stats) fix_finish(fx, (int)gridDim.x, fred, &last_flag);
 }
 
 // Merge the per-rank key lists (world, S, K) into the K globally best keys per query (S, K).
@@ -667,13 +582,14 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
     }
 }
 
-// Stride of the threshold subset.  The threshold kernel streams M/stride rows per query
-// (measured: ~21 us + 0.41 us per 1000 rows), the final pass then meets ~K*stride candidates per
-// query, each a divergent exact re-check + LDS append in the scan (measured: ~0.25 us per unit of
-// stride at S*K = 2816, scaling with S*K).  The sum is smallest near sqrt(4.6 * M / (S*K)):
-// 81 for the 1M-vertex graph (M = 4M), 26 for M = 400K.  Bounds: the list holds GH_CAND_CAP
-// candidates (mean K*stride kept <= 4096), a workgroup parks its hits in LDS (mean
-// S*K*stride*tile/M kept near 300 for a buffer of >= 1024), and the subset stays well above K rows.
+// Stride of the threshold subset.  The set-up evaluates M/stride subset edges against every query (inside the
+// normalise launch: ~0.1 us per 1000 rows at 256 queries beyond what the streaming part hides), the final pass then
+// meets ~K*stride candidates per query, each a divergent exact re-check + LDS append in the scan and a key in the
+// selection.  Measured optimum (rr1m, M = 4M, S*K = 2816): 64 (178 us per iteration; 40: 182, 100: 181); M = 400K: 20.
+// That is sqrt(c * M / (S*K)) with c = 3 for the MFMA form of the scan (its hits cost less than half as much as the
+// packed-VALU form's, whose balance sits lower).  Bounds: the list holds GH_CAND_CAP candidates (mean K*stride kept
+// <= 4096), a workgroup parks its hits in LDS (mean S*K*stride*tile/M kept near 300 for a buffer of >= 1024), and the
+// subset must keep well over K groups of GH_THR_GSIZE rows.
 int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile, bool mfma) {
     if (const char *e = getenv("GRAPHEM_HIP_SUBSET_STRIDE")) {  // tuning override
         const long v = atol(e);
@@ -682,36 +598,29 @@ int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile, bool mfma) {
     // beyond 256 queries the threshold kernel's workgroups no longer run all at once and its cost grows
     // with S like the hits do, so the balance point stops moving
     // (the MFMA form's hits cost less than half as much -- ~0.1 us per unit of stride -- so its balance sits higher)
-    int64_t r = (int64_t)sqrt((mfma ? 7.0 : 4.6) * (double)Mtot / ((double)(S < 256 ? S : 256) * K));
+    int64_t r = (int64_t)sqrt((mfma ? 3.0 : 2.0) * (double)Mtot / ((double)(S < 256 ? S : 256) * K));
     const int64_t by_list = 4096 / K;
     if (r > by_list) r = by_list;
     if (r > 256) r = 256;
     const int64_t by_hits = (int64_t)(300.0 * (double)Mtot / ((double)S * K * tile));
     if (r > by_hits) r = by_hits;
     if (r < 2) r = 2;
-    while (r > 2 && Mtot / r < 4 * (int64_t)K) r /= 2;  // keep the subset well above K rows
+    while (r > 2 && Mtot / r < 8 * (int64_t)K * GH_THR_GSIZE) r /= 2;  // at least 8 K groups: tau stays close to the subset's K-th smallest
     return r;
 }
 
 // fb_mid: midpoint rows for the exact search of overflowed queries, or null (gather the endpoints).
 gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect, const float *fb_mid) {
-    // single-rank fused step: the statistics of the step are finished in this launch too (fix_args)
-    const bool with_fix = final_level && with_intersect && h->new0_ready && h->rows > 0 && h->LD <= 16 &&
-                          !getenv("GRAPHEM_HIP_SEPARATE_FIX");
-    fix_args fx{};
-    unsigned extra = 0;
-    if (with_fix) {
-        fx = fix_args{h->d_blockstats, h->n_vblocks, h->d_pos, h->d_Fs, h->d_acc, h->d_touched, h->d_tcount, h->part.row_lo,
-                      h->rows, h->d_new, h->d_stats, h->d_ticket, h->LD, gh_fix_blocks(h->LD)};
-        extra = 2u * (unsigned)h->LD;
-    }
-    gh_scope t(h, with_fix ? "knn_select_intersect_fix" : with_intersect ? "knn_select_intersect" : "knn_select");
-    knn_select_kernel<<<dim3((unsigned)h->S + extra), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
+    // the column sums of the fused kernel's workgroup partials ride along (stats_fix_kernel then skips them)
+    const bool reduce = final_level && h->new0_ready && h->rows > 0 && h->LD <= 16;
+    gh_scope t(h, with_intersect ? "knn_select_intersect" : "knn_select");
+    knn_select_kernel<<<dim3((unsigned)h->S + (reduce ? 2u * (unsigned)h->LD : 0u)), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
         h->d_cand, h->d_cnt, h->K, final_level ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), gh_qs(h->D, h->LD),
         h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S,
-        make_search_args(h, fb_mid, h->own_count, 1, 1), make_inter_args(h, with_intersect), fx, (int)h->S);
+        make_search_args(h, fb_mid, h->own_count, 1, 1), make_inter_args(h, with_intersect), (int)h->S,
+        h->d_blockstats, h->n_vblocks, h->d_stats);
     GH_LAUNCH_CHECK();
-    if (with_fix) h->fix_done = true;
+    h->stats_reduced = reduce;
     return GH_OK;
 }
 
@@ -771,9 +680,15 @@ gh_status gh_knn_thresholds(gh_engine *h) {
     const gh_setup_args a = gh_make_setup_args(h, 0, h->d_sampled_cur, h->iter);
     const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
     gh_scope t(h, "knn_tau");
-    knn_tau_kernel<<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(
-        reinterpret_cast<const uint32_t *>(h->d_gmin), a.Gpad, a.Gpad, h->D, h->d_q, h->d_qscan, QS, QT, h->K,
-        reinterpret_cast<_Float16 *>(h->d_qA), h->d_qexact, h->tcount_reset_pending ? h->d_tcount : nullptr);
+#define GH_TAU(NVv)                                                                                                        \
+    knn_tau_kernel<NVv><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(                                                  \
+        reinterpret_cast<const uint32_t *>(h->d_gmin), a.Gpad, a.Gpad, h->D, h->d_q, h->d_qscan, QS, QT, h->K,              \
+        reinterpret_cast<_Float16 *>(h->d_qA), h->d_qexact, h->tcount_reset_pending ? h->d_tcount : nullptr)
+    // registers per lane for the group minima: the selection rounds rescan them all
+    if (a.Gpad <= 64 * 8) GH_TAU(8);
+    else if (a.Gpad <= 64 * 16) GH_TAU(16);
+    else GH_TAU(32);
+#undef GH_TAU
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

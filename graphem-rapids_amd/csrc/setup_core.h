@@ -15,7 +15,7 @@
 // them, keeping the minimum over each group of GH_THR_GSIZE consecutive subset edges ->
 // gmin[query][tile * GH_THR_GROUPS + group].  The K-th smallest
 // of a query's group minima bounds its K-th smallest distance from above (K different groups hold
-// K different edges that close), and with 32 edges per group it is almost always THE K-th smallest of
+// K different edges that close), and with 64 edges per group it is almost always THE K-th smallest of
 // the subset; knn_tau_kernel (knn.hip) extracts it.  This replaced a kernel that streamed a
 // materialised copy of the subset once per query and selected the exact K-th smallest (30 us at
 // 1 M vertices; it was bound by its two K-smallest extractions and its L2 round trips).
@@ -43,7 +43,7 @@ struct gh_setup_args {
 };
 
 #define GH_THR_TILE 128    /* subset edges per set-up workgroup */
-#define GH_THR_GSIZE 32    /* subset edges per group */
+#define GH_THR_GSIZE 64    /* subset edges per group */
 #define GH_THR_GROUPS (GH_THR_TILE / GH_THR_GSIZE)   /* group minima per tile and query */
 
 // Sample id, query record and list reset of query t (every query exactly once per iteration).
@@ -136,31 +136,38 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
             a.ovf[s] = 0;
         }
         uint32_t *dst = reinterpret_cast<uint32_t *>(a.gmin) + s * a.Gpad + (int64_t)blk * GH_THR_GROUPS;
-#pragma unroll 1
-        for (int g4 = 0; g4 < GH_THR_GROUPS; g4 += 4) {
-            uint32_t mn[4];
+        // a few references in flight per lane only: fully unrolled, the compiler hoists every LDS read of the tile
+        // (512 registers and scratch spills, which also cost the normalising workgroups of the same kernel their occupancy)
+        constexpr int UNR = LD == 4 ? 8 : LD == 8 ? 4 : 2;
+        uint32_t mn[GH_THR_GROUPS];
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                uint32_t best = 0x7F800000u;
+        for (int gg = 0; gg < GH_THR_GROUPS; ++gg) {
+            uint32_t best = 0x7F800000u;
+#pragma unroll UNR
+            for (int r = 0; r < GH_THR_GSIZE; ++r) {
+                const float4 *mrow = rsh + (gg * GH_THR_GSIZE + r) * (LD / 4);
+                float d2 = 0.0f;
 #pragma unroll
-                for (int r = 0; r < GH_THR_GSIZE; ++r) {
-                    const int ref = (g4 + gg) * GH_THR_GSIZE + r;
-                    float d2 = 0.0f;
+                for (int i = 0; i < LD / 4; ++i) {
+                    const float4 mv = mrow[i];  // broadcast read
+                    const float mm[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
-                    for (int i = 0; i < LD / 4; ++i) {
-                        const float4 mv = rsh[ref * (LD / 4) + i];  // broadcast read
-                        const float mm[4] = {mv.x, mv.y, mv.z, mv.w};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {  // pad coordinates are 0 on both sides: fma(0, 0, s) == s
-                            const float df = q[4 * i + c] - mm[c];
-                            d2 = fmaf(df, df, d2);
-                        }
+                    for (int c = 0; c < 4; ++c) {  // pad coordinates are 0 on both sides: fma(0, 0, s) == s
+                        const float df = q[4 * i + c] - mm[c];
+                        d2 = fmaf(df, df, d2);
                     }
-                    best = min(best, __float_as_uint(d2));
                 }
-                mn[gg] = best;
+                best = min(best, __float_as_uint(d2));
             }
-            *reinterpret_cast<uint4 *>(dst + g4) = make_uint4(mn[0], mn[1], mn[2], mn[3]);
+            mn[gg] = best;
+        }
+        static_assert(GH_THR_GROUPS == 2 || GH_THR_GROUPS % 4 == 0, "vector stores of the group minima");
+        if constexpr (GH_THR_GROUPS == 2) {
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(mn[0], mn[1]);
+        } else {
+#pragma unroll
+            for (int g4 = 0; g4 < GH_THR_GROUPS; g4 += 4)
+                *reinterpret_cast<uint4 *>(dst + g4) = make_uint4(mn[g4], mn[g4 + 1], mn[g4 + 2], mn[g4 + 3]);
         }
     }
 }

@@ -23,6 +23,13 @@ Two collectives per iteration: shipping the un-normalised rows together with the
 spares the separate all-reduce (normalising n instead of n/world rows costs a few microseconds,
 a collective tens).
 
+With the product engine the loop itself runs in the C library (`native=True`, the default there):
+gh_run_partitioned (csrc/comm.hip) enqueues kernels and ncclAllGather calls of all iterations on one
+stream -- RCCL opened by the library itself, its communicator bootstrapped here by broadcasting rank 0's
+unique id through torch.distributed.  The Python-driven step below (three ctypes calls and two
+torch.distributed collectives per iteration: +100 us per iteration measured at world = 1) remains for
+injected engines and as a cross-check.
+
 The sample ids are the same on every rank: either passed in, or drawn by the engine's counter
 based sampler from (seed, iteration).  The compute engine is injectable so that the collective
 choreography can be tested with the gloo backend on CPUs (tests/test_distributed_cpu.py).
@@ -124,10 +131,18 @@ class HipShardEngine:
     def sync(self):
         self.eng.sync()
 
+    # native loop (csrc/comm.hip)
+    def comm_init_rccl(self, world, rank, unique_id):
+        self.eng.set_stream(0, use_own=True)   # the library's own stream: nothing of torch's is in the loop any more
+        self.eng.comm_init_rccl(world, rank, unique_id)
+
+    def run_partitioned(self, iters, sample_stream=None):
+        self.eng.run_partitioned(iters, sample_stream)
+
 
 class PartitionedLayout:
     def __init__(self, n, D, edges, L_min=1.0, k_attr=0.2, k_inter=0.5, n_neighbors=10, sample_size=256, seed=0,
-                 rank=None, world=None, device_id=0, engine_factory=None, group=None, edge_ownership="auto"):
+                 rank=None, world=None, device_id=0, engine_factory=None, group=None, edge_ownership="auto", native=None):
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.group = group
@@ -151,6 +166,18 @@ class PartitionedLayout:
         self.K = n_neighbors + 1
         self.S = min(sample_size, len(edges))
         self.gathered = torch.empty((self.world, self.S, self.K), dtype=torch.int64, device=self.engine.pos.device)
+        # the loop in the C library over RCCL whenever the engine offers it (the product engine does)
+        self.native = hasattr(self.engine, "comm_init_rccl") if native is None else bool(native)
+        if self.native:
+            from . import _native
+            dev = self.engine.pos.device
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if self.rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(_native.comm_unique_id()), dtype=torch.uint8))
+            if self.world > 1:
+                src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
+                dist.broadcast(uid, src=src, group=self.group)
+            self.engine.comm_init_rccl(self.world, self.rank, bytes(uid.cpu().numpy().tobytes()))
 
     def set_positions(self, pos):
         self.engine.set_positions(np.ascontiguousarray(pos, dtype=np.float32))
@@ -159,6 +186,9 @@ class PartitionedLayout:
         return self.engine.get_positions()
 
     def step(self, sampled=None):
+        if self.native:
+            self.engine.run_partitioned(1, None if sampled is None else np.asarray(sampled, dtype=np.int32)[None, :])
+            return
         e = self.engine
         e.step_begin(sampled)
         # output in concatenated form (world*S, K): accepted by both the RCCL and the gloo backend
@@ -169,6 +199,9 @@ class PartitionedLayout:
         e.step_finish_gathered()
 
     def run(self, iters, sample_stream=None):
+        if self.native:
+            self.engine.run_partitioned(iters, sample_stream)
+            return
         for t in range(iters):
             self.step(None if sample_stream is None else sample_stream[t])
 

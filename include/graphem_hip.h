@@ -167,6 +167,29 @@ void *gh_gather_buffer_device(gh_handle h);
 int64_t gh_gather_slot_bytes(gh_handle h);
 gh_status gh_step_finish_gathered(gh_handle h);
 
+/* ---- the whole partitioned run as ONE call (no host language in the loop) ----------------------
+ * After gh_create(partition) + gh_gather_layout(world, rank, chunk) + one of the communicator calls,
+ * gh_run_partitioned enqueues `iters` iterations -- part 1, all-gather of the keys, part 2, in-place
+ * all-gather of the slots, part 3 -- on the handle's stream; only the collective backend may block.
+ * Every rank must call it with the same iters and the same sample_stream ((iters, S) host ids, or NULL:
+ * each rank's engine then draws identical ids from (seed, iteration)).
+ *   gh_comm_unique_id        rank 0: 128 bytes to hand to every rank (ncclGetUniqueId)
+ *   gh_comm_init_rccl        RCCL communicator on the engine's device; collectives = ncclAllGather on the engine's
+ *                            stream over xGMI.  librccl.so is opened here, not at load time.
+ *   gh_loopback_group_create / gh_comm_init_loopback
+ *                            `world` engines of one process, one host thread each, exchange by device copies:
+ *                            the same loop on a single GPU (where RCCL refuses two ranks on one device)
+ * Kernel and collective times appear under gh_timing_get as "allgather_keys" / "allgather_slots". */
+typedef struct gh_loop_group gh_loop_group;
+gh_status gh_comm_unique_id(void *out128);
+gh_status gh_comm_init_rccl(gh_handle h, int32_t world, int32_t rank, const void *unique_id128);
+gh_loop_group *gh_loopback_group_create(int32_t world);
+void gh_loopback_group_destroy(gh_loop_group *group);
+gh_status gh_comm_init_loopback(gh_handle h, gh_loop_group *group, int32_t rank);
+gh_status gh_comm_destroy(gh_handle h);
+gh_status gh_run_partitioned(gh_handle h, int32_t iters, const int32_t *sample_stream);
+const char *gh_comm_last_error(void);   /* message of a failed gh_comm_unique_id */
+
 /* ---- instrumentation --------------------------------------------------------- */
 
 /* Names and accumulated GPU milliseconds of the kernels launched since the last

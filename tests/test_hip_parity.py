@@ -339,9 +339,9 @@ def test_unsorted_edge_list_takes_the_gather_path():
 
 
 def test_rccl_driver_single_rank():
-    """The real multi-GPU driver (PartitionedLayout + HipShardEngine + RCCL collectives through
-    torch.distributed 'nccl') with world size 1 on this GPU: in-place position all-gather,
-    int64 key all-gather, fp64 all-reduce, engine on torch's stream.  Must equal the plain engine."""
+    """The real multi-GPU driver (PartitionedLayout + HipShardEngine) with world size 1 on this GPU, both ways:
+    the loop in the C library with ncclAllGather on the library's own RCCL communicator (gh_run_partitioned), and
+    the Python-driven step with torch.distributed 'nccl' collectives on torch's stream.  Must equal the plain engine."""
     import os
     import torch
     import torch.distributed as dist
@@ -362,15 +362,77 @@ def test_rccl_driver_single_rank():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=9, rank=0, world=1, device_id=0)
-        lay.set_positions(pos)
-        lay.run(3, stream)
-        lay.run(2)
-        torch.cuda.synchronize()
-        got = lay.get_positions()
+        got = {}
+        for native in (True, False):   # the loop in the C library over the library's own RCCL communicator / driven from Python
+            lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=9, rank=0, world=1, device_id=0, native=native)
+            assert lay.native == native
+            lay.set_positions(pos)
+            lay.run(3, stream)
+            lay.run(2)
+            lay.sync()
+            torch.cuda.synchronize()
+            got[native] = lay.get_positions()
+            lay.engine.eng.close()
     finally:
         dist.destroy_process_group()
-    assert np.abs(got - ref).max() <= 2e-6
+    assert np.abs(got[True] - ref).max() <= 2e-6
+    assert np.array_equal(got[True], got[False])
+
+
+@pytest.mark.parametrize("world,n,D", [(2, 30011, 3), (3, 30011, 3), (4, 100003, 3), (3, 9001, 5), (2, 20001, 16)])
+def test_native_partitioned_loop_on_the_loopback_backend(world, n, D):
+    """gh_run_partitioned (csrc/comm.hip): the whole multi-rank run inside the C library.  `world` engines on this one
+    GPU, one host thread each, collectives by the in-process loopback backend (RCCL refuses two ranks on one device):
+    the same loop, the same buffers and counts as over RCCL.  Must reproduce the single engine, with a host id stream
+    and with the device sampler, and every rank must end with identical bits."""
+    import threading
+    from graphem_rapids_amd import _native
+    from graphem_rapids_amd.distributed import partition_rows
+    k, S = 10, 256
+    edges, pos, _ = _random_case(n - 1, D, 8, k, S, seed=31)
+    pos = np.vstack([pos, np.zeros((1, D), np.float32)])
+    rng = np.random.default_rng(8)
+    stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(3)]).astype(np.int32)
+    single = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=4)
+    single.set_positions(pos)
+    single.run(3, stream)
+    single.run(2)
+    ref = single.get_positions()
+    single.close()
+
+    lib = _native.load()
+    group = lib.gh_loopback_group_create(world)
+    engines = []
+    for r in range(world):
+        chunk, lo, hi = partition_rows(n, world, r)
+        e = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=4, partition=(lo, hi, 0, 0, _native.EDGES_HASHED))
+        e.gather_layout(world, r, chunk)
+        e.comm_init_loopback(group, r)
+        e.set_positions(pos)
+        engines.append(e)
+    errors = []
+
+    def work(e):
+        try:
+            e.run_partitioned(3, stream)
+            e.run_partitioned(2)
+            e.sync()
+        except Exception as exc:  # pylint: disable=broad-exception-caught
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(e,)) for e in engines]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    outs = [e.get_positions() for e in engines]
+    for e in engines:
+        e.comm_destroy()
+        e.close()
+    lib.gh_loopback_group_destroy(group)
+    assert np.abs(outs[0] - ref).max() <= 2e-6
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
 
 
 def test_large_k_takes_the_sort_kernel():
