@@ -91,6 +91,12 @@ class GraphEmbedderHIP:
         if dtype not in (torch.float32, torch.float64, torch.float16):
             raise ValueError(f"unsupported dtype {dtype}")
         self.dtype = dtype  # storage dtype of the tensor views; the kernels compute in float32
+        if dtype != torch.float32:
+            # the reference computes in whatever dtype it is given (pt.py:56); this backend's kernels are float32
+            # only, so say it instead of silently accepting (positions are still returned / exposed in `dtype`)
+            self._dtype_note = (f"GraphEmbedderHIP computes in float32; dtype={dtype} only sets the dtype of the "
+                                "positions it returns")
+            logging.getLogger(__name__).warning(self._dtype_note)
         self.L_min = L_min
         self.k_attr = k_attr
         self.k_inter = k_inter

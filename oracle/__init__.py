@@ -54,6 +54,14 @@ def lib():
         L.go_column_sums_colmajor.restype = None
         L.go_run_layout.restype = i32
         L.go_num_threads.restype = i32
+        _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+        _i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
+        L.go_pull_lists.argtypes = [_i32p, i64, i64, _i64p, _i32p, _i8p]
+        L.go_pull_lists.restype = None
+        L.go_spring_forces_pull.argtypes = [_f32p, i64, i32, _i64p, _i32p, _i8p, f32, f32, _f32p]
+        L.go_spring_forces_pull.restype = None
+        L.go_step_omp.argtypes = [_f32p, i64, i32, _i32p, i64, _i64p, _i32p, _i8p, _i32p, i64, i32, f32, f32, f32]
+        L.go_step_omp.restype = i32
         _lib = L
     return _lib
 
@@ -155,6 +163,35 @@ def run_layout(pos, edges, sample_stream, k, L_min=1.0, k_attr=0.2, k_inter=0.5,
     if err == 1:
         raise RuntimeError("selected index k out of range")
     return pos
+
+
+class OmpStepper:
+    """bench.py's 'port_omp' baseline: the same algorithm with every phase over all cores (graphem_oracle.c,
+    go_step_omp).  The pull lists are built once per graph, like the GPU engine builds its own at creation."""
+
+    def __init__(self, n, edges):
+        self.n = int(n)
+        self.edges = _c(edges, np.int32)
+        E = self.edges.shape[0]
+        self.rowptr = np.empty(self.n + 1, dtype=np.int64)
+        self.adj = np.empty(2 * E, dtype=np.int32)
+        self.sign = np.empty(2 * E, dtype=np.int8)
+        lib().go_pull_lists(self.edges, E, self.n, self.rowptr, self.adj, self.sign)
+
+    def spring_forces(self, pos, L_min=1.0, k_attr=0.2):
+        pos = _c(pos, np.float32)
+        F = np.empty_like(pos)
+        lib().go_spring_forces_pull(pos, self.n, pos.shape[1], self.rowptr, self.adj, self.sign, L_min, k_attr, F)
+        return F
+
+    def step(self, pos, sampled, k, L_min=1.0, k_attr=0.2, k_inter=0.5):
+        pos = np.array(pos, dtype=np.float32, order="C", copy=True)
+        sampled = _c(sampled, np.int32)
+        err = lib().go_step_omp(pos, self.n, pos.shape[1], self.edges, self.edges.shape[0], self.rowptr, self.adj,
+                                self.sign, sampled, sampled.shape[0], k, L_min, k_attr, k_inter)
+        if err == 1:
+            raise RuntimeError("selected index k out of range")
+        return pos
 
 
 def num_threads():

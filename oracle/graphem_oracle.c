@@ -398,6 +398,101 @@ int go_run_layout(float *pos, int64_t n, int D, const int32_t *edges, int64_t E,
     return GO_OK;
 }
 
+/* ---- bench-only multi-threaded variant (bench.py cpu_baseline "port_omp") --------------------------------
+ * The strongest honest CPU number for the same algorithm: every phase over all cores.  Spring forces as a
+ * per-vertex PULL over lists in the reference's summation order (edges where the vertex is endpoint 0, then
+ * endpoint 1, each in edge order: the two index_add_ calls of pt.py:633-634), so each row is one thread's
+ * sequential sum and the result is BIT-IDENTICAL to go_spring_forces (tests/test_oracle_golden.py).  The KNN
+ * is go_knn_midpoints (already parallel over the queries); combine + normalise with per-thread fp64 column
+ * sums (not ATen's fp32 cascade: agrees with go_integrate_normalise to ~1e-7, checked in the same test). */
+void go_pull_lists(const int32_t *edges, int64_t E, int64_t n, int64_t *rowptr /* n+1 */, int32_t *adj /* 2E */,
+                   int8_t *sign /* 2E: +1 endpoint 0, -1 endpoint 1 */) {
+    memset(rowptr, 0, sizeof(int64_t) * (size_t)(n + 1));
+    for (int64_t e = 0; e < E; ++e) { rowptr[edges[2 * e] + 1]++; rowptr[edges[2 * e + 1] + 1]++; }
+    for (int64_t i = 0; i < n; ++i) rowptr[i + 1] += rowptr[i];
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    memcpy(cur, rowptr, sizeof(int64_t) * (size_t)n);
+    for (int64_t e = 0; e < E; ++e) { const int64_t at = cur[edges[2 * e]]++; adj[at] = edges[2 * e + 1]; sign[at] = 1; }
+    for (int64_t e = 0; e < E; ++e) { const int64_t at = cur[edges[2 * e + 1]]++; adj[at] = edges[2 * e]; sign[at] = -1; }
+    free(cur);
+}
+
+void go_spring_forces_pull(const float *pos, int64_t n, int D, const int64_t *rowptr, const int32_t *adj,
+                           const int8_t *sign, float L_min, float k_attr, float *F) {
+    const float neg_k = -k_attr;
+#pragma omp parallel
+    {
+        float *diff = (float *)malloc(sizeof(float) * (size_t)D);
+#pragma omp for schedule(static)
+        for (int64_t x = 0; x < n; ++x) {
+            float *dst = F + (size_t)x * D;
+            for (int d = 0; d < D; ++d) dst[d] = 0.0f;
+            for (int64_t j = rowptr[x]; j < rowptr[x + 1]; ++j) {
+                /* diff = p[v] - p[u] of the edge (u < v): the neighbour minus x when x is endpoint 0, x minus the
+                 * neighbour when it is endpoint 1; F[u] += f, F[v] += -f */
+                const float *px = pos + (size_t)x * D, *py = pos + (size_t)adj[j] * D;
+                if (sign[j] > 0) for (int d = 0; d < D; ++d) diff[d] = py[d] - px[d];
+                else for (int d = 0; d < D; ++d) diff[d] = px[d] - py[d];
+                const float dist = go_norm2(diff, D) + 1e-6f;
+                const float fm = neg_k * (dist - L_min);
+                for (int d = 0; d < D; ++d) {
+                    const float f = fm * (diff[d] / dist);
+                    dst[d] = dst[d] + (sign[j] > 0 ? f : -f);
+                }
+            }
+        }
+        free(diff);
+    }
+}
+
+int go_step_omp(float *pos, int64_t n, int D, const int32_t *edges, int64_t E, const int64_t *rowptr,
+                const int32_t *adj, const int8_t *sign, const int32_t *sampled, int64_t S, int k, float L_min,
+                float k_attr, float k_inter) {
+    float *Fs = (float *)malloc(sizeof(float) * (size_t)n * D);
+    float *Fi = (float *)malloc(sizeof(float) * (size_t)n * D);
+    int32_t *knn = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S * k > 0 ? S * k : 1));
+    if (!Fs || !Fi || !knn) { free(Fs); free(Fi); free(knn); return GO_ERR_NOMEM; }
+    go_spring_forces_pull(pos, n, D, rowptr, adj, sign, L_min, k_attr, Fs);
+    int err = go_knn_midpoints(pos, D, edges, E, sampled, S, k, knn, NULL);
+    if (err == GO_OK) {
+        go_intersection_forces(pos, n, D, edges, sampled, S, knn, k, k_inter, Fi, NULL);   /* O(S k): serial */
+        double *sum = (double *)calloc((size_t)D, sizeof(double)), *sq = (double *)calloc((size_t)D, sizeof(double));
+#pragma omp parallel
+        {
+            double *ls = (double *)calloc((size_t)2 * D, sizeof(double));
+#pragma omp for schedule(static)
+            for (int64_t i = 0; i < n; ++i)
+                for (int d = 0; d < D; ++d) {
+                    const size_t o = (size_t)i * D + d;
+                    const float tot = Fs[o] + Fi[o];
+                    const float nw = pos[o] + tot;
+                    Fs[o] = nw;
+                    ls[d] += (double)nw;
+                    ls[D + d] += (double)nw * (double)nw;
+                }
+#pragma omp critical
+            for (int d = 0; d < D; ++d) { sum[d] += ls[d]; sq[d] += ls[D + d]; }
+            free(ls);
+        }
+        for (int d = 0; d < D; ++d) {
+            const double m = sum[d] / (double)n;
+            double var = (sq[d] - sum[d] * m) / (double)(n - 1);
+            if (var < 0.0) var = 0.0;
+            sum[d] = (double)(float)m;
+            sq[d] = (double)((float)sqrt(var) + 1e-6f);
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i)
+            for (int d = 0; d < D; ++d) {
+                const size_t o = (size_t)i * D + d;
+                pos[o] = (Fs[o] - (float)sum[d]) / (float)sq[d];
+            }
+        free(sum); free(sq);
+    }
+    free(Fs); free(Fi); free(knn);
+    return err;
+}
+
 int go_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

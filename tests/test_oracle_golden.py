@@ -111,3 +111,28 @@ def test_row_norm_matches_torch(D):
     F.index_add_(0, torch.from_numpy(edges[:, 0]).long(), ef)
     F.index_add_(0, torch.from_numpy(edges[:, 1]).long(), -ef)
     assert np.array_equal(oracle.spring_forces(pos, edges, 1.0, 0.2), F.numpy())
+
+
+def test_bench_baselines_equal_the_oracle(golden):
+    """bench.py's CPU baselines are the same algorithm: the all-cores port (oracle.OmpStepper: spring forces by
+    per-vertex pull, bit-identical; normalise with fp64 column sums) and the PyTorch-CPU restatement
+    (oracle/torch_cpu.py: the reference's torch ops without its MemoryManager wrappers)."""
+    import torch
+    from oracle import torch_cpu
+    g = golden
+    edges, n, k = g["edges"], int(g["n"]), int(g["k"])
+    Lm, ka, ki = (float(x) for x in g["params"])
+    st = oracle.OmpStepper(n, edges)
+    te = torch.from_numpy(edges.astype(np.int64))
+    for t in g["steps"]:
+        pos, sampled = g[f"pos_{t}"], g[f"sampled_{t}"]
+        assert np.array_equal(st.spring_forces(pos, Lm, ka), g[f"F_spring_{t}"])
+        out = st.step(pos, sampled, k, Lm, ka, ki)
+        assert np.abs(out - g[f"pos_next_{t}"]).max() <= 2e-6
+        tp = torch_cpu.step(torch.from_numpy(np.ascontiguousarray(pos)), te, torch.from_numpy(sampled.astype(np.int64)),
+                            k, Lm, ka, ki).numpy()
+        assert np.abs(tp - g[f"pos_next_{t}"]).max() <= 2e-6
+        tk = torch_cpu.knn_midpoints((torch.from_numpy(np.ascontiguousarray(pos))[te[:, 0]] +
+                                      torch.from_numpy(np.ascontiguousarray(pos))[te[:, 1]]) / 2.0,
+                                     torch.from_numpy(sampled.astype(np.int64)), k).numpy()
+        assert np.array_equal(tk, g[f"knn_{t}"])

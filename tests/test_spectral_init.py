@@ -63,3 +63,42 @@ def test_embedder_init_option_and_layout_runs():
     assert np.linalg.norm(p0 - q @ (q.T @ p0)) < 1e-4
     out = emb.run_layout(5)
     assert np.isfinite(out).all()
+
+
+def test_spans_the_reference_held_start_of_c1():
+    """on BASELINE configs[0]'s graph the GPU solver must span what the REFERENCE itself started
+    from -- `p0` of tests/golden/c1_er1000.npz is the reference's own Laplacian embedding (pt.py:364-365, ARPACK).
+    C1 has isolated vertices and small components, so eigenvalue 0 is degenerate and the embedding is any basis of a
+    part of that null space: compare as subspaces of the wanted eigenspace, and check every reference column is an
+    eigenvector combination the solver's operator accepts (residual)."""
+    import graphem_rapids_amd as gra
+    from conftest import load_golden
+    from graphem_rapids_amd.spectral import laplacian_embedding_hip
+    g = load_golden("c1_er1000")
+    n, D = int(g["n"]), int(g["D"])
+    adj = gra.edges_to_adjacency(n, g["edges"])
+    L, vals, vecs = _reference_eig(adj, n)
+    p0 = g["p0"].astype(np.float64)
+    # the reference's columns are (to fp32) eigenvectors of the same Laplacian, each for one eigenvalue lam_j
+    lam = np.array([(p0[:, j] @ (L @ p0[:, j])) / (p0[:, j] @ p0[:, j]) for j in range(D)])
+    for j in range(D):
+        r = L @ p0[:, j] - lam[j] * p0[:, j]
+        assert np.linalg.norm(r) <= 1e-4 * np.linalg.norm(p0[:, j])
+    emb, info = laplacian_embedding_hip(adj, D, return_info=True, tol=1e-10)
+    assert info["converged"]
+    # wanted eigenvalues: the D+1 smallest; the solver's must equal the dense ones, and the reference's Rayleigh
+    # quotients must lie among them
+    np.testing.assert_allclose(np.sort(info["eigenvalues"][: D + 1]), vals[: D + 1], atol=1e-7)
+    top = vals[D]
+    assert np.all(lam <= top + 1e-5)
+    # both embeddings lie in the eigenspace of eigenvalues <= top (its dimension exceeds D + 1 when 0 is degenerate)
+    basis = vecs[:, vals <= top + 1e-7]
+    for M in (p0, emb.astype(np.float64)):
+        Q, _ = np.linalg.qr(M)
+        resid = Q - basis @ (basis.T @ Q)
+        assert np.abs(resid).max() <= 2e-4
+    if vals[1] - vals[0] > 1e-6 and vals[D + 1] - vals[D] > 1e-6:   # connected, and a gap behind the wanted set: THE subspace
+        Qa, _ = np.linalg.qr(p0)
+        Qb, _ = np.linalg.qr(emb.astype(np.float64))
+        sv = np.linalg.svd(Qa.T @ Qb, compute_uv=False)
+        assert sv.min() >= 1.0 - 1e-6, sv
