@@ -87,7 +87,9 @@ __device__ __forceinline__ uint32_t gh_row_min_u32(uint32_t v) {
 #define GH_SETUP_LDS_BYTES (GH_THR_TILE * 16 * 4)
 template <int LD, class P>
 __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, P getp, unsigned char *lds) {
-    float4 *rsh = reinterpret_cast<float4 *>(lds);     // [GH_THR_TILE][LD / 4]
+    // the tile in LDS as PAIRS of subset edges, component-interleaved: pair p, coordinate d -> (m_2p[d], m_2p+1[d]),
+    // so that the distance chain of two references runs on packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32)
+    gh_f2 *rsh = reinterpret_cast<gh_f2 *>(lds);     // [GH_THR_TILE / 2][LD]
     const int t = threadIdx.x;
     __builtin_amdgcn_s_setprio(3);  // inside a normalise launch these waves sit among streaming ones: their chains go first
     // this lane's first query (every workgroup needs all of them; issued before the tile so that both chains of
@@ -116,8 +118,9 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
         } else {
             m[0] = INFINITY;  // padding slot: (q - inf)^2 = inf for every finite query
         }
+        float *slot = reinterpret_cast<float *>(rsh + (t >> 1) * LD) + (t & 1);
 #pragma unroll
-        for (int i = 0; i < LD / 4; ++i) rsh[t * (LD / 4) + i] = make_float4(m[4 * i], m[4 * i + 1], m[4 * i + 2], m[4 * i + 3]);
+        for (int d = 0; d < LD; ++d) slot[2 * d] = m[d];
     }
     __syncthreads();
     for (int64_t s0 = 0; s0 < a.S; s0 += 256) {
@@ -136,7 +139,7 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
             a.ovf[s] = 0;
         }
         uint32_t *dst = reinterpret_cast<uint32_t *>(a.gmin) + s * a.Gpad + (int64_t)blk * GH_THR_GROUPS;
-        // a few references in flight per lane only: fully unrolled, the compiler hoists every LDS read of the tile
+        // a few pairs in flight per lane only: fully unrolled, the compiler hoists every LDS read of the tile
         // (512 registers and scratch spills, which also cost the normalising workgroups of the same kernel their occupancy)
         constexpr int UNR = LD == 4 ? 8 : LD == 8 ? 4 : 2;
         uint32_t mn[GH_THR_GROUPS];
@@ -144,20 +147,19 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
         for (int gg = 0; gg < GH_THR_GROUPS; ++gg) {
             uint32_t best = 0x7F800000u;
 #pragma unroll UNR
-            for (int r = 0; r < GH_THR_GSIZE; ++r) {
-                const float4 *mrow = rsh + (gg * GH_THR_GSIZE + r) * (LD / 4);
-                float d2 = 0.0f;
+            for (int r = 0; r < GH_THR_GSIZE / 2; ++r) {
+                const float4 *mrow = reinterpret_cast<const float4 *>(rsh + (gg * (GH_THR_GSIZE / 2) + r) * LD);
+                gh_f2 d2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int i = 0; i < LD / 4; ++i) {
-                    const float4 mv = mrow[i];  // broadcast read
-                    const float mm[4] = {mv.x, mv.y, mv.z, mv.w};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {  // pad coordinates are 0 on both sides: fma(0, 0, s) == s
-                        const float df = q[4 * i + c] - mm[c];
-                        d2 = fmaf(df, df, d2);
-                    }
+                for (int i = 0; i < LD / 2; ++i) {
+                    const float4 mv = mrow[i];  // broadcast read: coordinates 2i, 2i+1 of both references
+                    // the exact chain in coordinate order, two references at a time (pad coordinates are 0 on both sides)
+                    const gh_f2 da = (gh_f2){q[2 * i], q[2 * i]} - (gh_f2){mv.x, mv.y};
+                    d2 = __builtin_elementwise_fma(da, da, d2);
+                    const gh_f2 db = (gh_f2){q[2 * i + 1], q[2 * i + 1]} - (gh_f2){mv.z, mv.w};
+                    d2 = __builtin_elementwise_fma(db, db, d2);
                 }
-                best = min(best, __float_as_uint(d2));
+                best = min(best, min(__float_as_uint(d2.x), __float_as_uint(d2.y)));
             }
             mn[gg] = best;
         }
