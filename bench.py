@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--workload", default="rr1m", choices=sorted(WORKLOADS))
     ap.add_argument("--sampler", default="device", choices=["device", "host"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sample-size", type=int, default=None, help="override the workload's number of sampled midpoints")
+    ap.add_argument("--knn", default="auto", choices=["auto", "scan", "grid"], help="KNN search (gh_params.knn_method)")
     ap.add_argument("--dist", action="store_true",
                     help="use the multi-GPU driver (RCCL collectives) even for one rank: rehearsal of the N>1 path")
     args = ap.parse_args()
@@ -127,6 +129,8 @@ def main():
     from graphem_rapids_amd import _native
     n, D, k, S, edges, pos = make_workload(args.workload)
     E = len(edges)
+    if args.sample_size:
+        S = min(args.sample_size, E)
 
     use_dist = world > 1 or args.dist
     if use_dist:
@@ -144,7 +148,7 @@ def main():
         barrier = dist.barrier
         eng = lay.engine.eng
     else:
-        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, device_id=local_rank)
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, device_id=local_rank, knn_method=args.knn)
         eng.set_positions(pos)
         stream = None
         if args.sampler == "host":  # ids drawn on the host before the timed region (parity-style stream)
@@ -191,7 +195,7 @@ def main():
         # Dominant kernel: the fused spring+scan kernel (the stand-alone scan when unfused).  It is bound by the
         # memory system: the spring phase gathers one position row per pull-list entry (2E random 16-byte rows),
         # and with no locality in the graph most of them miss the L2 (PMC traffic below).
-        dom = "spring_scan" if "spring_scan" in kern else "knn_scan"
+        dom = "spring_scan" if "spring_scan" in kern else "spring_mid" if "spring_mid" in kern else "knn_scan"
         scan_us = kern.get(dom, {}).get("avg_us")
         roofline = None
         knn_fp32 = None
@@ -232,7 +236,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "graph": WORKLOADS[args.workload][0], "n_vertices": n,
                        "n_edges": E, "n_components": D, "n_neighbors": k, "sample_size": S,
-                       "sampler": args.sampler, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else "")},
+                       "sampler": args.sampler, "knn": args.knn, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else "")},
             "roofline": roofline, "roofline_knn_fp32": knn_fp32, "roofline_iter_hbm": hbm, "kernels": kern,
         }
         if use_dist:  # rank 0's split of an iteration (HIP events on the engine's stream, second pass): where a scaling run loses its time

@@ -31,10 +31,11 @@ SYMBOLS = [
 class GhParams(ctypes.Structure):
     _fields_ = [("L_min", ctypes.c_float), ("k_attr", ctypes.c_float), ("k_inter", ctypes.c_float),
                 ("n_neighbors", ctypes.c_int32), ("sample_size", ctypes.c_int32), ("seed", ctypes.c_uint64),
-                ("reorder", ctypes.c_int32)]
+                ("reorder", ctypes.c_int32), ("knn_method", ctypes.c_int32)]
 
 
 REORDER = {"auto": 0, "off": 1, "bfs": 2}  # gh_params.reorder (include/graphem_hip.h GH_REORDER_*)
+KNN_METHOD = {"auto": 0, "scan": 1, "grid": 2}  # gh_params.knn_method (GH_KNN_*)
 
 
 class GhPartition(ctypes.Structure):
@@ -168,14 +169,14 @@ class Engine:
     """Thin RAII wrapper over a gh_handle."""
 
     def __init__(self, n, D, edges, L_min, k_attr, k_inter, n_neighbors, sample_size, seed=0, device_id=0,
-                 partition=None, reorder="auto"):
+                 partition=None, reorder="auto", knn_method="auto"):
         self.lib = load()
         self.handle = ctypes.c_void_p()
         self.n, self.D = int(n), int(D)
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
         self.E = edges.shape[0]
         prm = GhParams(float(L_min), float(k_attr), float(k_inter), int(n_neighbors), int(sample_size),
-                       int(seed) & 0xFFFFFFFFFFFFFFFF, REORDER[reorder])
+                       int(seed) & 0xFFFFFFFFFFFFFFFF, REORDER[reorder], KNN_METHOD[knn_method])
         part = None
         if partition is not None:
             vals = [int(x) for x in partition]  # (row_lo, row_hi, edge_lo, edge_hi[, edge_rule])

@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_terms, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -112,6 +112,9 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     h->prm = *params;
     h->k = params->n_neighbors; h->K = h->k + 1;
     h->S = std::min<int64_t>(params->sample_size, E);
+    if (h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID)   // AUTO (and anything unknown)
+        h->prm.knn_method = (D <= 3 && h->S >= 8192) ? GH_KNN_GRID : GH_KNN_SCAN;
+    if (const char *e = getenv("GRAPHEM_HIP_KNN")) h->prm.knn_method = atoi(e) == GH_KNN_GRID ? GH_KNN_GRID : GH_KNN_SCAN;  // A/B runs
     if (part) h->part = *part;
     else h->part = gh_partition{0, n, 0, E, GH_EDGES_RANGE};
     if (h->part.edge_rule == GH_EDGES_HASHED) h->part.edge_lo = h->part.edge_hi = 0;  // not used by this rule
@@ -376,6 +379,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         h->err = "upload of the graph failed";
         return bail(GH_ERR_HIP);
     }
+    if ((st = gh_grid_alloc(h)) != GH_OK) return bail(st);
     if (h->thr_M1 > 0) {  // endpoints of the threshold subset: every thr_stride-th own edge
         std::vector<int32_t> sub((size_t)h->thr_M1 * 2);
         for (int64_t j = 0; j < h->thr_M1; ++j) {
@@ -511,6 +515,12 @@ static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
         GH_HIP(hipMemsetAsync(h->d_tcount, 0, sizeof(int32_t), h->stream));
         return gh_launch_spring_mid(h);
     }
+    if (gh_grid_path(h)) {  // sub-quadratic search: thresholds, own midpoints to memory, grid build + cell search
+        GH_TRY(gh_knn_prepare(h));          // query records only: the thresholds come from the grid itself
+        GH_TRY(gh_launch_spring_mid(h));
+        GH_TRY(gh_grid_search(h));
+        return gh_knn_finish(h, true, fuse_intersect);
+    }
     if (h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused) {
         GH_TRY(gh_knn_prepare(h));
         GH_TRY(gh_knn_thresholds(h));
@@ -532,8 +542,9 @@ static gh_status step_merge(gh_engine *h, const uint64_t *gathered, int world) {
 // also runs the next iteration's KNN set-up, for the sample source expected then (gh_launch_normalise);
 // gh_knn_prepare falls back to its own kernel when the next step turns out different.
 static gh_status step_finish(gh_engine *h, int next_mode = -1, int32_t *next_ids = nullptr) {
-    const bool presetup = next_mode >= 0 && h->rows == h->n && !h->d_gbuf && h->fused_scan && gh_knn_scan_path(h) &&
-                          !h->force_unfused && h->S > 0 && h->k > 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
+    const bool presetup = next_mode >= 0 && h->rows == h->n && !h->d_gbuf && gh_knn_scan_path(h) &&
+                          ((h->fused_scan && !h->force_unfused) || gh_grid_path(h)) && h->S > 0 && h->k > 0 &&
+                          !getenv("GRAPHEM_HIP_NO_PRESETUP");
     GH_TRY(gh_launch_normalise(h, true, presetup, next_mode, next_ids));  // also zeroes what the intersection phase touched
     h->iter += 1;
     return GH_OK;

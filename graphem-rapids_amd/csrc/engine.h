@@ -125,6 +125,14 @@ struct gh_engine {
     uint64_t *d_merged = nullptr; // (S, K) keys merged over the ranks (world > 1)
     const uint64_t *d_keys_cur = nullptr;  // keys the intersection phase reads: d_partial or d_merged
 
+    // grid KNN (grid.hip; GH_KNN_GRID)
+    int grid_G = 0, grid_bits = 0;
+    int64_t grid_cells = 0;
+    size_t grid_temp_bytes = 0;
+    uint32_t *d_grid_u32 = nullptr;   // keys, rows, sorted keys, sorted rows, cell starts, sorted edge ids
+    void *d_grid_smid = nullptr;      // (own_count) float4 midpoints in cell order
+    void *d_grid_temp = nullptr;      // radix sort scratch
+
     // normalisation
     double *d_blockstats = nullptr; // (nblocks, 2, LD)
     int nblocks_update = 0;
@@ -161,6 +169,10 @@ gh_status gh_knn_thresholds(gh_engine *h);
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
 gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq, const float *d_ref, int64_t nref,
                                int D, int K, uint64_t *d_keys, std::string *err);
+// grid.hip
+bool gh_grid_path(const gh_engine *h);
+gh_status gh_grid_alloc(gh_engine *h);
+gh_status gh_grid_search(gh_engine *h);            // d_mid + tau -> candidate lists
 // fused.hip
 gh_status gh_radial_topk_device(gh_engine *h, int K, uint64_t *d_part, int nparts, int32_t *d_ids);
 bool gh_fused_uses_mfma(const gh_engine *h);       // the fused kernel's pre-filter runs on the matrix pipe

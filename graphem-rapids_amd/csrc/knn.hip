@@ -639,7 +639,7 @@ bool gh_knn_scan_path(const gh_engine *h) {
 gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint64_t iter) {
     if (h->thr_stride == 0) {  // fixed at the first use: d_gmin is sized from it
         const int64_t Mtot = own_edges(h);
-        const bool scan = gh_knn_scan_path(h);
+        const bool scan = gh_knn_scan_path(h) && !gh_grid_path(h);   // the grid search takes its thresholds from the grid
         h->thr_stride = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h)) : 1;
         h->thr_M1 = scan ? (Mtot + h->thr_stride - 1) / h->thr_stride : 0;
     }
@@ -654,8 +654,8 @@ unsigned gh_setup_blocks(const gh_setup_args &a) {
     return a.tiles > 0 ? (unsigned)a.tiles : (unsigned)((a.S + 255) / 256);
 }
 int64_t gh_gmin_floats(const gh_engine *h) {
-    if (!gh_knn_scan_path(h)) return 1;
     const gh_setup_args a = gh_make_setup_args(const_cast<gh_engine *>(h), 0, nullptr, 0);
+    if (a.tiles == 0) return 4;
     return h->S * a.Gpad + 4;
 }
 
@@ -837,3 +837,5 @@ gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq,
     if (e != hipSuccess) { *err = std::string("kernel launch: ") + hipGetErrorString(e); return GH_ERR_HIP; }
     return GH_OK;
 }
+
+#include "grid_core.h"

@@ -54,6 +54,7 @@ class GraphEmbedderHIP:
         *,
         sampler="auto",
         init="auto",
+        knn_method="auto",
     ):
         """Arguments as pt.py:51-104.  Extra keyword-only arguments:
 
@@ -61,6 +62,10 @@ class GraphEmbedderHIP:
             global CPU generator exactly as the reference's CPU backend does (pt.py:409);
             'device' uses the engine's on-GPU sampler (no host work in the loop);
             'auto' = 'torch' up to 2**20 edges, 'device' above.
+        knn_method : 'scan' (exact filtered brute-force scan fused with the spring phase), 'grid' (n_components <= 3:
+            exact search through a uniform grid over the midpoints rebuilt every iteration -- sub-quadratic, pays from
+            several thousand sampled midpoints on; the counterpart of the reference's cuVS indexes,
+            embedder_cuvs.py:255-313), or 'auto' = 'grid' when n_components <= 3 and sample_size >= 8192.
         init : 'laplacian' (scipy eigsh exactly as pt.py:337-379), 'laplacian_hip' (the same
             eigenvectors by thick-restart Lanczos on the GPU, spectral.py: 1.2 s at 100 K vertices where
             eigsh takes 29 s, 3.4 s at 1 M where it is impractical), 'random' (the reference's own
@@ -119,6 +124,9 @@ class GraphEmbedderHIP:
         if self.batch_size is None:
             self.batch_size = self.n  # the engine never chunks the query set
 
+        if knn_method not in _native.KNN_METHOD:
+            raise ValueError(f"Invalid knn_method: {knn_method}")
+        self.knn_method = knn_method
         if sampler not in ("auto", "torch", "device"):
             raise ValueError(f"Invalid sampler: {sampler}")
         if sampler == "auto":
@@ -130,7 +138,7 @@ class GraphEmbedderHIP:
         self._engine_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         self._engine = _native.Engine(
             self.n, n_components, self._edges_np, L_min, k_attr, k_inter, n_neighbors, self.sample_size,
-            seed=self._engine_seed, device_id=self.device.index)
+            seed=self._engine_seed, device_id=self.device.index, knn_method=knn_method)
         if self.verbose:
             self.logger.info("Initialized GraphEmbedderHIP on %s", self.device)
             self.logger.info("Graph: %d vertices, %d edges, %dD", self.n, self.n_edges, self.n_components)

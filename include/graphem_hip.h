@@ -47,7 +47,19 @@ typedef struct {
     int32_t sample_size;  /* pt.py:61, already min(sample_size, E) as pt.py:156 */
     uint64_t seed;        /* seed of the on-device sampler (used when no sample ids are passed) */
     int32_t reorder;      /* internal vertex order: GH_REORDER_AUTO / _OFF / _BFS (no reference counterpart) */
+    int32_t knn_method;   /* GH_KNN_AUTO / _SCAN / _GRID: how the exact KNN of the sampled midpoints is searched */
 } gh_params;
+
+/* KNN search (the reference's cdist + topk, pt.py:543-593; its cuVS backend reaches for IVF indexes,
+ * embedder_cuvs.py:255-313).  Every method returns the EXACT k+1 nearest midpoints, identical ids.
+ *   GH_KNN_SCAN  filtered brute-force scan fused with the spring phase: S * E pre-filter evaluations on the matrix
+ *                pipe, hidden under the spring phase's gathers up to a few thousand queries;
+ *   GH_KNN_GRID  n_components <= 3: a uniform grid over the midpoints rebuilt every iteration (O(E)), then per query
+ *                only the cells its threshold ball touches: sub-quadratic, pays from several thousand queries on;
+ *   GH_KNN_AUTO  SCAN, or GRID when n_components <= 3 and sample_size >= 8192. */
+#define GH_KNN_AUTO 0
+#define GH_KNN_SCAN 1
+#define GH_KNN_GRID 2
 
 /* Internal vertex order.  The spring phase gathers the position row of every neighbour; with
  * breadth-first vertex numbers a vertex sits next to its BFS siblings and close to its parent and
