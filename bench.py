@@ -85,9 +85,17 @@ def cpu_baseline(n, D, k, S, edges, pos, budget_s=24.0):
 
     omp = oracle.OmpStepper(n, edges)
     legs = {}
-    legs["port_omp"] = dict(timed(lambda p, s: omp.step(p, s, k), budget_s / 3), cores=oracle.num_threads(),
-                            what="oracle/graphem_oracle.c go_step_omp: every phase over all cores")
-    legs["port"] = dict(timed(lambda p, s: oracle.step(p, edges, s, k), budget_s / 3), cores=oracle.num_threads(),
+    all_threads = oracle.num_threads()
+    best_omp = None
+    for nt in sorted({all_threads, max(1, all_threads // 2), min(all_threads, 64), min(all_threads, 32)}, reverse=True):
+        oracle.set_threads(nt)   # memory-bound phases on a multi-socket host: the best team is not always the largest
+        leg = dict(timed(lambda p, s: omp.step(p, s, k), budget_s / 9), cores=nt,
+                   what="oracle/graphem_oracle.c go_step_omp: every phase OpenMP; best of several team sizes")
+        if best_omp is None or leg["value"] > best_omp["value"]:
+            best_omp = leg
+    oracle.set_threads(all_threads)
+    legs["port_omp"] = best_omp
+    legs["port"] = dict(timed(lambda p, s: oracle.step(p, edges, s, k), budget_s / 3), cores=all_threads,
                         what="oracle/graphem_oracle.c go_step: KNN phase OpenMP, other phases 1 thread")
     te = torch.from_numpy(edges.astype(np.int64))
 

@@ -113,7 +113,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     h->k = params->n_neighbors; h->K = h->k + 1;
     h->S = std::min<int64_t>(params->sample_size, E);
     if (h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID)   // AUTO (and anything unknown)
-        h->prm.knn_method = (D <= 3 && h->S >= 8192) ? GH_KNN_GRID : GH_KNN_SCAN;
+        h->prm.knn_method = (D <= 3 && h->S >= 12288) ? GH_KNN_GRID : GH_KNN_SCAN;
     if (const char *e = getenv("GRAPHEM_HIP_KNN")) h->prm.knn_method = atoi(e) == GH_KNN_GRID ? GH_KNN_GRID : GH_KNN_SCAN;  // A/B runs
     if (part) h->part = *part;
     else h->part = gh_partition{0, n, 0, E, GH_EDGES_RANGE};

@@ -169,15 +169,43 @@ class PartitionedLayout:
         # the loop in the C library over RCCL whenever the engine offers it (the product engine does)
         self.native = hasattr(self.engine, "comm_init_rccl") if native is None else bool(native)
         if self.native:
-            from . import _native
-            dev = self.engine.pos.device
-            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if self.rank == 0:
-                uid.copy_(torch.frombuffer(bytearray(_native.comm_unique_id()), dtype=torch.uint8))
-            if self.world > 1:
-                src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
-                dist.broadcast(uid, src=src, group=self.group)
-            self.engine.comm_init_rccl(self.world, self.rank, bytes(uid.cpu().numpy().tobytes()))
+            self.native = self._init_native_comm()
+
+    def _init_native_comm(self):
+        """Bootstraps the library's own RCCL communicator: rank 0's unique id goes to every rank through
+        torch.distributed.  Every step is agreed on by all ranks (a rank that cannot open librccl.so must not leave the
+        others waiting inside ncclCommInitRank); on failure all ranks fall back to the Python-driven loop together."""
+        from . import _native
+        dev = self.engine.pos.device
+        uid = torch.zeros(129, dtype=torch.uint8, device=dev)       # 128 bytes of id + 1 "rank 0 could make one"
+        if self.rank == 0:
+            try:
+                raw = _native.comm_unique_id()
+                uid[:128].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+                uid[128] = 1
+            except RuntimeError:
+                pass
+        if self.world > 1:
+            src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
+            dist.broadcast(uid, src=src, group=self.group)
+        host = uid.cpu().numpy()
+        if host[128] != 1:
+            return False
+        ok = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            self.engine.comm_init_rccl(self.world, self.rank, host[:128].tobytes())
+        except (RuntimeError, ValueError):
+            ok.zero_()
+        if self.world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 1:
+            return True
+        try:                                   # some rank failed: everybody back onto torch's stream and collectives
+            self.engine.eng.comm_destroy()
+        except (RuntimeError, ValueError, AttributeError):
+            pass
+        self.engine.eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        return False
 
     def set_positions(self, pos):
         self.engine.set_positions(np.ascontiguousarray(pos, dtype=np.float32))

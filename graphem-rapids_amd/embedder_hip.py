@@ -65,7 +65,7 @@ class GraphEmbedderHIP:
         knn_method : 'scan' (exact filtered brute-force scan fused with the spring phase), 'grid' (n_components <= 3:
             exact search through a uniform grid over the midpoints rebuilt every iteration -- sub-quadratic, pays from
             several thousand sampled midpoints on; the counterpart of the reference's cuVS indexes,
-            embedder_cuvs.py:255-313), or 'auto' = 'grid' when n_components <= 3 and sample_size >= 8192.
+            embedder_cuvs.py:255-313), or 'auto' = 'grid' when n_components <= 3 and sample_size >= 12288.
         init : 'laplacian' (scipy eigsh exactly as pt.py:337-379), 'laplacian_hip' (the same
             eigenvectors by thick-restart Lanczos on the GPU, spectral.py: 1.2 s at 100 K vertices where
             eigsh takes 29 s, 3.4 s at 1 M where it is impractical), 'random' (the reference's own

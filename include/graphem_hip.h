@@ -56,7 +56,7 @@ typedef struct {
  *                pipe, hidden under the spring phase's gathers up to a few thousand queries;
  *   GH_KNN_GRID  n_components <= 3: a uniform grid over the midpoints rebuilt every iteration (O(E)), then per query
  *                only the cells its threshold ball touches: sub-quadratic, pays from several thousand queries on;
- *   GH_KNN_AUTO  SCAN, or GRID when n_components <= 3 and sample_size >= 8192. */
+ *   GH_KNN_AUTO  SCAN, or GRID when n_components <= 3 and sample_size >= 12288. */
 #define GH_KNN_AUTO 0
 #define GH_KNN_SCAN 1
 #define GH_KNN_GRID 2

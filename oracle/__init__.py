@@ -54,6 +54,8 @@ def lib():
         L.go_column_sums_colmajor.restype = None
         L.go_run_layout.restype = i32
         L.go_num_threads.restype = i32
+        L.go_set_threads.argtypes = [i32]
+        L.go_set_threads.restype = None
         _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
         _i8p = np.ctypeslib.ndpointer(dtype=np.int8, flags="C_CONTIGUOUS")
         L.go_pull_lists.argtypes = [_i32p, i64, i64, _i64p, _i32p, _i8p]
@@ -196,6 +198,10 @@ class OmpStepper:
 
 def num_threads():
     return lib().go_num_threads()
+
+
+def set_threads(n):
+    lib().go_set_threads(int(n))
 
 
 def column_sums(x, colmajor=False):

@@ -493,6 +493,15 @@ int go_step_omp(float *pos, int64_t n, int D, const int32_t *edges, int64_t E, c
     return err;
 }
 
+/* bench.py tries a few team sizes for the all-cores leg: on a two-socket host fewer threads than cores can be faster */
+void go_set_threads(int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+}
+
 int go_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
