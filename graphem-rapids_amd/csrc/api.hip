@@ -182,7 +182,9 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     std::vector<int32_t> deg((size_t)n, 0);
     for (int64_t i = 0; i < 2 * E; ++i) deg[(size_t)edges[i]]++;
     bool has_long = false;
-    for (int64_t i = 0; i < n && !has_long; ++i) has_long = deg[(size_t)i] > GH_LONG_DEG;
+    h->long_deg = gh_long_degree(n, E);
+    const int long_deg = h->long_deg;
+    for (int64_t i = 0; i < n && !has_long; ++i) has_long = deg[(size_t)i] > long_deg;
     if (has_long && part && part->edge_rule != GH_EDGES_HASHED) has_long = false;  // range partitions: as before
     if (has_long && !part) h->part = gh_partition{0, n, 0, 0, GH_EDGES_HASHED};
 
@@ -198,7 +200,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     const bool hashed = h->part.edge_rule == GH_EDGES_HASHED;
     auto owner_is_v = [&](int64_t e) {
         if (has_long) {
-            const bool lu = deg[(size_t)edges[2 * e]] > GH_LONG_DEG, lv = deg[(size_t)edges[2 * e + 1]] > GH_LONG_DEG;
+            const bool lu = deg[(size_t)edges[2 * e]] > long_deg, lv = deg[(size_t)edges[2 * e + 1]] > long_deg;
             if (lu != lv) return lu;
         }
         uint32_t x = (uint32_t)e * 0x9E3779B1u;
@@ -257,7 +259,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
             long_ownptr.push_back(0);
             long_eptr.push_back(0);
             for (int64_t i = 0; i < h->rows; ++i) {
-                if (rowptr[(size_t)i + 1] - rowptr[(size_t)i] <= GH_LONG_DEG) continue;
+                if (rowptr[(size_t)i + 1] - rowptr[(size_t)i] <= long_deg) continue;
                 long_rows.push_back((int32_t)i);
                 long_eptr.push_back(long_eptr.back() + (rowptr[(size_t)i + 1] - rowptr[(size_t)i]));
                 for (int32_t j = rowptr[(size_t)i]; j < rowptr[(size_t)i + 1]; ++j)

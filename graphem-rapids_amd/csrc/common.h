@@ -170,11 +170,19 @@ __host__ __device__ inline bool gh_dim_templated(int D) {
 // endpoint is short (api.hip: the short endpoint owns it); the few they do own (hub-hub edges) are
 // listed apart so that their midpoints can still be emitted by the row's thread.
 #define GH_LONG_DEG 128
+// Small dense graphs (a SNAP social graph at 16 components: 4 K vertices of mean degree 44) leave a fused workgroup with
+// two dozen vertices for 256 threads, each walking its list two 64-byte rows at a time -- 40 us of one wave's serial
+// work.  There every row above GH_LONG_DEG_DENSE takes the long path (one thread per list entry, then the ordered sum).
+#define GH_LONG_DEG_DENSE 16
+__host__ inline int gh_long_degree(int64_t n, int64_t E) {
+    return (E <= (int64_t)1 << 20 && 2 * E >= 24 * n) ? GH_LONG_DEG_DENSE : GH_LONG_DEG;   // mean degree >= 24, <= 1M edges
+}
 struct gh_long_args {
     const int32_t *rows;    // local ids of the long own rows, ascending
     const int32_t *ownptr;  // (n + 1) offsets into ownadj
     const int32_t *ownadj;  // neighbours across the edges the long rows own, pull-list order
     int n;                  // number of long own rows (0: the graph has none)
+    int deg;                // rows with more neighbours than this are long (gh_long_degree)
 };
 
 // One row of the spring phase: short rows pull, long rows take the force spring_long_kernel left
@@ -184,7 +192,7 @@ __device__ __forceinline__ void spring_row(const float *__restrict__ pos, const 
                                            int end, int64_t self, const float *px, float L_min, float neg_k, float *F,
                                            float *__restrict__ mid, int64_t mid_row0, const gh_long_args &la,
                                            int i_local, const float *__restrict__ Fpre) {
-    if (la.n > 0 && end - beg > GH_LONG_DEG) {
+    if (la.n > 0 && end - beg > la.deg) {
         gh_load_row<LD>(Fpre, 0, F);
         if (WRITE_MID) {
             int lo = 0, hi = la.n - 1;
@@ -192,12 +200,21 @@ __device__ __forceinline__ void spring_row(const float *__restrict__ pos, const 
                 const int m = (lo + hi) >> 1;
                 if (la.rows[m] < i_local) lo = m + 1; else hi = m;
             }
-            for (int j = la.ownptr[lo]; j < la.ownptr[lo + 1]; ++j) {
-                float py[LD], mrow[LD];
-                gh_load_row<LD>(pos, la.ownadj[j], py);
+            constexpr int C = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;   // neighbour rows in flight, as in spring_pull
+            const int jend = la.ownptr[lo + 1];
+            for (int base = la.ownptr[lo]; base < jend; base += C) {
+                float py[C][LD];
 #pragma unroll
-                for (int d = 0; d < LD; ++d) mrow[d] = d < D ? (px[d] + py[d]) / 2.0f : 0.0f;
-                gh_store_row<LD>(mid, mid_row0++, mrow);
+                for (int j = 0; j < C; ++j) gh_load_row<LD>(pos, base + j < jend ? la.ownadj[base + j] : (int32_t)self, py[j]);
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    if (base + j < jend) {
+                        float mrow[LD];
+#pragma unroll
+                        for (int d = 0; d < LD; ++d) mrow[d] = d < D ? (px[d] + py[j][d]) / 2.0f : 0.0f;
+                        gh_store_row<LD>(mid, mid_row0++, mrow);
+                    }
+                }
             }
         }
         return;

@@ -64,6 +64,7 @@ struct gh_engine {
     int32_t *d_long_eptr = nullptr;   // (nlong + 1) prefix of their degrees
     float *d_long_terms = nullptr;    // (long_entries * D) force terms of their neighbours, component-major per row
     int nlong = 0;
+    int long_deg = 128;               // rows with more neighbours than this are long (common.h gh_long_degree)
     int64_t long_entries = 0;
     float *d_mid = nullptr;       // (own_count, LD) midpoints of the own edges, current iteration
     float *d_Fs = nullptr;        // (rows, LD) spring forces of the own rows

@@ -68,7 +68,9 @@ __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const 
                                            const int32_t *__restrict__ adj, const int32_t *__restrict__ first_edge,
                                            int v0, int v1, int fe0, int64_t row_lo, float L_min, float neg_k,
                                            float *__restrict__ Fs, float *__restrict__ out_new, float *mids,
-                                           double (&sx)[LD], double (&sxx)[LD], const gh_long_args &la) {
+                                           double (&sx)[LD], double (&sxx)[LD], const gh_long_args &la,
+                                           const float *__restrict__ Fpre = nullptr /* hub forces (the Fs array) */) {
+    if (!Fpre) Fpre = Fs;
 #pragma unroll
     for (int d = 0; d < LD; ++d) { sx[d] = 0.0; sxx[d] = 0.0; }
     for (int i = v0 + threadIdx.x; i < v1; i += NT) {
@@ -79,17 +81,17 @@ __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const 
         // common instantiation, where the extra path costs 8 VGPRs and with them a wave of occupancy
         if constexpr (LONG)
             spring_row<D, LD, true>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mids, first_edge[i] - fe0,
-                                    la, i, Fs + (int64_t)i * LD);
+                                    la, i, Fpre + (int64_t)i * LD);
         else
             spring_pull<D, LD, true>(pos, adj, rowptr[i], rowptr[i + 1], x, px, L_min, neg_k, F, mids, first_edge[i] - fe0);
-        gh_store_row<LD>(Fs, i, F);
+        if (Fs) gh_store_row<LD>(Fs, i, F);
 #pragma unroll
         for (int d = 0; d < LD; ++d) {
             nw[d] = px[d] + F[d];
             sx[d] += (double)nw[d];
             sxx[d] += (double)nw[d] * (double)nw[d];
         }
-        gh_store_row<LD>(out_new, i, nw);
+        if (out_new) gh_store_row<LD>(out_new, i, nw);
     }
 }
 
@@ -104,7 +106,7 @@ __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const dou
         if (lane == 0) { red[w * 2 * LD + d] = a; red[w * 2 * LD + LD + d] = b; }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * LD) {
+    if (threadIdx.x < 2 * LD && blockstats) {
         double v = red[threadIdx.x];
 #pragma unroll
         for (int ww = 1; ww < NT / 64; ++ww) v += red[ww * 2 * LD + threadIdx.x];
@@ -135,11 +137,15 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     if (threadIdx.x == 0) hcount = 0;
 
     // ---- phase A: spring forces, new0 = pos + Fs, midpoints of the owned edges to LDS
+    // (gridDim.y > 1: few, long workgroups -- small graphs with wide rows -- split the QUERIES over blockIdx.y; every
+    // slice redoes phase A for its tile, slice 0 alone stores its results)
     __shared__ double red[(NT / 64) * 2 * LD];
     {
         double sx[LD], sxx[LD];
-        gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx, la);
-        gh_block_stats<LD, NT>(sx, sxx, red, blockstats);  // contains the barrier that ends phase A
+        const bool store = blockIdx.y == 0;
+        gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, store ? Fs : nullptr,
+                                    store ? out_new : nullptr, mids, sx, sxx, la, Fs);
+        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr);  // contains the barrier that ends phase A
     }
 
     // ---- phase B: the tile becomes this workgroup's references
@@ -168,9 +174,11 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     __syncthreads();  // every thread has its references: the tile's LDS becomes the hit buffer
     uint64_t *hkey = reinterpret_cast<uint64_t *>(tile);
     int *hq = reinterpret_cast<int *>(hkey + HITBUF);
-    for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
-        const int nq = min(S - s_lo, GH_SCAN_QGROUP);
-        if (s_lo > 0) __syncthreads();  // the previous group's records are still being read
+    const int per = (S + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s_begin = (int)blockIdx.y * per, s_end = min(S, s_begin + per);
+    for (int s_lo = s_begin; s_lo < s_end; s_lo += GH_SCAN_QGROUP) {
+        const int nq = min(s_end - s_lo, GH_SCAN_QGROUP);
+        if (s_lo > s_begin) __syncthreads();  // the previous group's records are still being read
         gh_stage_queries<QS, (D <= 3 ? 3 : LD), NT>(qscan, qt, s_lo, nq, qsh, taush);
         __syncthreads();
         gh_scan_queries<D, R, HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt);
@@ -337,7 +345,15 @@ void launch_mfma(gh_engine *h) {
 
 template <int D, int LD, int R, int NT, bool LONG>
 void launch_l(gh_engine *h) {
-    spring_scan_kernel<D, LD, R, NT, LONG><<<dim3((unsigned)h->n_vblocks), dim3(NT), 0, h->stream>>>(
+    // few workgroups with a long packed-VALU scan each (wide rows on a small graph): the queries over up to 4 slices
+    unsigned ny = 1;
+    if (LD >= 8 && h->n_vblocks < 384) {
+        ny = (unsigned)(768 / (h->n_vblocks > 0 ? h->n_vblocks : 1));
+        if (ny > 4) ny = 4;
+        if (ny < 1) ny = 1;
+        if ((int64_t)ny > h->S) ny = 1;
+    }
+    spring_scan_kernel<D, LD, R, NT, LONG><<<dim3((unsigned)h->n_vblocks, ny), dim3(NT), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
         h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h));
 }

@@ -42,7 +42,19 @@ struct inter_args {
     float *scratch;
 };
 
-__device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi, const uint64_t *best) {
+// Whole workgroup; best[] in LDS, visible to all threads (the callers' extraction ends with a barrier).
+__device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi, const uint64_t *best, gh_pair_list *pl) {
+    if (ia.LD >= 8 && ia.LD <= 16 && ia.k <= 127 && blockDim.x % (4 * ia.LD) == 0) {   // wide rows: lanes = (role, coordinate)
+        const int32_t i = ia.sampled[qi];
+#define GH_WIDE_ONE(DD, LL)                                                                                              \
+    case DD:                                                                                                             \
+        if constexpr (LL >= 8) gh_intersect_query_wide<DD, LL>(ia.pos, ia.edges, i, best, ia.k, ia.k_inter, ia.acc, ia.tflag, \
+                                                              ia.touched, ia.tcount, pl);                               \
+        break;
+        switch (ia.D) { GH_FOR_EACH_DIM(GH_WIDE_ONE) default: break; }
+#undef GH_WIDE_ONE
+        return;
+    }
     // neighbour c of the query is key column c+1: column 0 is dropped blindly (pt.py:421)
     for (int c = threadIdx.x; c < ia.k; c += blockDim.x)
         gh_intersect_pair_any(ia.pos, ia.D, ia.LD, ia.edges, ia.sampled[qi], (int32_t)gh_key_id(best[c + 1]), ia.k_inter,
@@ -153,8 +165,39 @@ __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *o
 
 // K smallest of the c keys in src (LDS or global), by the smallest per-thread register count
 // that holds them: the cost of a round is proportional to the keys each thread rescans.
+// K smallest of c <= 2 * NT keys by counting: every key's rank among all of them (keys are unique), one pass over an
+// LDS copy.  The wave-minimum rounds above cost ~100 instructions per extracted key and run K times in a row: at
+// K = 33 (n_neighbors = 32) that was 8 us of a select launch; counting costs c/2 LDS reads whatever K is.
+template <int NT = 256>
+__device__ void block_rank_smallest(const uint64_t *src, int c, int K, uint64_t *out, uint64_t *stage /* >= 2 * NT keys */) {
+    uint64_t mine[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = j * NT + threadIdx.x;
+        mine[j] = i < c ? src[i] : GH_KEY_INF;
+        stage[i] = mine[j];
+    }
+    for (int i = c + threadIdx.x; i < K; i += NT) out[i] = GH_KEY_INF;   // fewer than K keys: the tail
+    __syncthreads();
+    int rank[2] = {0, 0};
+    const int c2 = (c + 1) & ~1;
+    for (int i = 0; i < c2; i += 2) {
+        const uint64_t a = stage[i], b = stage[i + 1];   // broadcast read of 16 bytes (slots past c hold GH_KEY_INF)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) rank[j] += (a < mine[j] ? 1 : 0) + (b < mine[j] ? 1 : 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (mine[j] != GH_KEY_INF && rank[j] < K) out[rank[j]] = mine[j];
+    __syncthreads();
+}
+
 template <int MAXNPT, int NT = 256>
 __device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64_t *out, uint64_t *red) {
+    if (K > 16 && c <= 2 * NT && 2 * NT <= (NT / 64) * GH_EXTRACT_MAX_K) {   // red holds (NT/64) * GH_EXTRACT_MAX_K keys
+        block_rank_smallest<NT>(src, c, K, out, red);
+        return;
+    }
     auto run = [&](auto npt_tag) {
         constexpr int NPT = decltype(npt_tag)::value;
         uint64_t keys[NPT];
@@ -253,7 +296,8 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(search_args a, in
     if (out_keys)
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
     if (tau_out && threadIdx.x == 0) tau_out[qi * a.QS] = best[K - 1] != GH_KEY_INF ? gh_key_d2(best[K - 1]) : INFINITY;
-    if (ia.pos) intersect_query(ia, qi, best);
+    __shared__ gh_pair_list pairs;
+    if (ia.pos) intersect_query(ia, qi, best, &pairs);
 }
 
 // The same selection for large K (> GH_EXTRACT_MAX_K): running threshold + LDS compaction +
@@ -492,7 +536,8 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     }
     if (final_level) {
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
-        if (ia.pos) intersect_query(ia, qi, best);
+        __shared__ gh_pair_list pairs;
+        if (ia.pos) intersect_query(ia, qi, best, &pairs);
     } else if (threadIdx.x == 0) {
         tau[qi * QS] = gh_key_d2(best[K - 1]);
     }
@@ -519,7 +564,8 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restri
     __syncthreads();
     block_sort(buf, n2);
     for (int c = threadIdx.x; c < K; c += blockDim.x) merged[qi * K + c] = buf[c];
-    if (ia.pos) intersect_query(ia, qi, buf);  // the k candidate pairs of this query, same launch (pt.py:638-774)
+    __shared__ gh_pair_list pairs;
+    if (ia.pos) intersect_query(ia, qi, buf, &pairs);  // the k candidate pairs of this query, same launch (pt.py:638-774)
 }
 
 template <int D, int R>

@@ -68,14 +68,21 @@ def edge_owner_is_second(edge_ids):
 LONG_DEG = 128  # csrc/common.h GH_LONG_DEG: rows with more neighbours are hubs
 
 
-def owned_edge_ids(edges, row_lo, row_hi):
+def long_degree(n, n_edges):
+    """csrc/common.h gh_long_degree: small dense graphs (<= 2**20 edges, mean degree >= 24) treat every row above 16
+    neighbours as a hub."""
+    return 16 if (n_edges <= (1 << 20) and 2 * n_edges >= 24 * n) else LONG_DEG
+
+
+def owned_edge_ids(edges, row_lo, row_hi, n=None):
     """Ids of the edges a rank with rows [row_lo, row_hi) owns under the hashed rule (vertex numbers as
     given: an engine that reorders vertices internally partitions its internal rows the same way).
     An edge between a hub and a short row belongs to the short row; otherwise the hash decides."""
     edges = np.asarray(edges).reshape(-1, 2)
     second = edge_owner_is_second(np.arange(len(edges)))
     if len(edges):
-        is_hub = np.bincount(edges.ravel()) > LONG_DEG
+        deg = np.bincount(edges.ravel())
+        is_hub = deg > long_degree(len(deg) if n is None else n, len(edges))
         hub_u, hub_v = is_hub[edges[:, 0]], is_hub[edges[:, 1]]
         if is_hub.any():
             second = np.where(hub_u != hub_v, hub_u, second)

@@ -28,6 +28,31 @@ __global__ __launch_bounds__(256) void plain(const float4 *__restrict__ pos, con
     out[i] = acc;
 }
 
+// The fused kernel's whole memory side without any arithmetic: own row, 8 neighbour gathers through a pull list with
+// ownership flags, two 16-byte rows written (Fs, new0), row pointer + first-edge reads, one 16-byte midpoint per owned
+// edge into LDS.  The fair ceiling for spring_scan's phase A.
+__global__ __launch_bounds__(256) void plain_full(const float4 *__restrict__ pos, const int *__restrict__ rowptr,
+                                                  const int *__restrict__ first_edge, const int *__restrict__ adj, int n,
+                                                  float4 *__restrict__ out1, float4 *__restrict__ out2) {
+    __shared__ float4 tile[1024];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 px = pos[i];
+    const int beg = rowptr[i], fe = first_edge[i];
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = pos[adj[beg + j] & 0x7FFFFFFF];
+    float4 acc = make_float4(0, 0, 0, 0);
+    int slot = (fe & 255) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        acc.x += v[j].x - px.x; acc.y += v[j].y - px.y; acc.z += v[j].z - px.z;
+        if (j & 1) tile[(slot++) & 1023] = make_float4(0.5f * (v[j].x + px.x), 0.5f * (v[j].y + px.y), 0.5f * (v[j].z + px.z), 0.f);
+    }
+    out1[i] = acc;
+    out2[i] = make_float4(px.x + acc.x, px.y + acc.y, px.z + acc.z, tile[threadIdx.x].x);
+}
+
 // rows of XCD g: slice g; thread (local block b, k) -> row r0 + (b + k*G)*256 + tid
 template <int T, bool ORDERED>
 __global__ __launch_bounds__(256) void sweep2(const float4 *__restrict__ pos, const int *__restrict__ adj,
@@ -107,6 +132,44 @@ __global__ __launch_bounds__(256) void sweep2(const float4 *__restrict__ pos, co
     for (int k = 0; k < T; ++k) if (row[k] >= 0) out[row[k]] = acc[k];
 }
 
+// sweep2 with one row per thread and the gathered rows staged through LDS at their LIST position (per-lane slot
+// address), summed in list order afterwards: the reference's summation order at the price of 128 bytes of LDS per thread.
+__global__ __launch_bounds__(256) void sweep2_lds(const float4 *__restrict__ pos, const int *__restrict__ adj,
+                                                  const unsigned *__restrict__ cnt, const unsigned *__restrict__ perm, int n,
+                                                  int slice_rows, int G, float4 *__restrict__ out) {
+    __shared__ float4 rows[8][256];
+    const int g = blockIdx.x % 8, local = blockIdx.x / 8;
+    const int r0 = g * slice_rows;
+    const int i = r0 + local * 256 + threadIdx.x;
+    const bool ok = i < r0 + slice_rows && i < n;
+    int cur = ok ? i * 8 : 0;
+    const unsigned c = ok ? cnt[i] : 0u;
+    const unsigned p = ok ? perm[i] : 0u;
+    // inverse of perm: slot s (arrival order) holds list position inv[s]
+    unsigned inv = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) inv |= (unsigned)j << (3 * ((p >> (3 * j)) & 7));
+    int slot = 0;
+    for (int t = 0; t < 8; ++t) {
+        const int left = (c >> (4 * t)) & 15u;
+        const int mx = __reduce_max_sync(0xFFFFFFFFFFFFFFFFull, left);
+        for (int j = 0; j < mx; ++j) {
+            if (j < left) {
+                const float4 v = pos[adj[cur]];
+                ++cur;
+                rows[(inv >> (3 * slot)) & 7][threadIdx.x] = v;
+                ++slot;
+            }
+        }
+    }
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float4 v = rows[j][threadIdx.x]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        out[i] = acc;
+    }
+}
+
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 1000000, deg = 8;
     const int slice_rows = (n + 7) / 8;
@@ -154,6 +217,15 @@ int main(int argc, char **argv) {
         CK(hipMemset(out, 0, (size_t)n * 16));
     };
     timeit("plain", [&] { plain<<<dim3((n + 255) / 256), dim3(256)>>>(pos, dadj, n, out); });
+    {
+        std::vector<int> rp((size_t)n + 1), fe((size_t)n + 1);
+        for (int i = 0; i <= n; ++i) { rp[i] = i * 8; fe[i] = i * 4; }
+        int *drp, *dfe; float4 *out2;
+        CK(hipMalloc(&drp, rp.size() * 4)); CK(hipMalloc(&dfe, fe.size() * 4)); CK(hipMalloc(&out2, (size_t)n * 16));
+        CK(hipMemcpy(drp, rp.data(), rp.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dfe, fe.data(), fe.size() * 4, hipMemcpyHostToDevice));
+        timeit("plain_full (fused kernel's memory side)", [&] { plain_full<<<dim3((n + 255) / 256), dim3(256)>>>(pos, drp, dfe, dadj, n, out, out2); });
+    }
     timeit("plain (slice-sorted lists)", [&] { plain<<<dim3((n + 255) / 256), dim3(256)>>>(pos, dadj2, n, out); });
     const int tiles = (slice_rows + 255) / 256;
 #define RUN(T, ORD)                                                                                                  \
@@ -161,6 +233,10 @@ int main(int argc, char **argv) {
         const int G = (tiles + T - 1) / T;                                                                           \
         char name[64]; snprintf(name, sizeof name, "sweep2 T=%d %s (%d WGs)", T, ORD ? "ordered" : "unordered", 8 * G); \
         timeit(name, [&] { sweep2<T, ORD><<<dim3(8 * G), dim3(256)>>>(pos, dadj2, dcnt, dperm, n, slice_rows, G, out); }); \
+    }
+    {
+        const int G = tiles;
+        timeit("sweep2 T=1 LDS-staged, list order", [&] { sweep2_lds<<<dim3(8 * G), dim3(256)>>>(pos, dadj2, dcnt, dperm, n, slice_rows, G, out); });
     }
     RUN(1, false) RUN(2, false) RUN(4, false) RUN(8, false)
     RUN(1, true) RUN(2, true) RUN(4, true)
