@@ -24,7 +24,7 @@ SYMBOLS = [
     "gh_spectral_last_error", "gh_gather_layout", "gh_gather_buffer_device", "gh_gather_slot_bytes",
     "gh_step_finish_gathered", "gh_vertex_order", "gh_positions_unpadded_device", "gh_radial_topk",
     "gh_comm_unique_id", "gh_comm_init_rccl", "gh_loopback_group_create", "gh_loopback_group_destroy",
-    "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error",
+    "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error", "gh_debug_stamps",
 ]
 
 
@@ -140,6 +140,8 @@ def load():
     L.gh_run_partitioned.restype = ctypes.c_int
     L.gh_comm_last_error.argtypes = []
     L.gh_comm_last_error.restype = ctypes.c_char_p
+    L.gh_debug_stamps.argtypes = [vp, vp, i64]
+    L.gh_debug_stamps.restype = ctypes.c_int
     L.gh_device_count.argtypes = []
     L.gh_device_count.restype = i32
     L.gh_version.argtypes = []

@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_terms, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -186,7 +186,11 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     const int long_deg = h->long_deg;
     for (int64_t i = 0; i < n && !has_long; ++i) has_long = deg[(size_t)i] > long_deg;
     if (has_long && part && part->edge_rule != GH_EDGES_HASHED) has_long = false;  // range partitions: as before
-    if (has_long && !part) h->part = gh_partition{0, n, 0, 0, GH_EDGES_HASHED};
+    // A whole-graph engine always takes the hashed rule: under "endpoint 0 owns" vertex i of a u < v edge list owns its
+    // edges to higher-numbered neighbours only -- 8 for the first vertices of an 8-regular graph, 0 for the last -- so the
+    // fused workgroups at the end of the vertex range held 1024 rows for a few hundred owned edges and took 31 us where the
+    // median workgroup took 18 (tools/stamp_probe.py, 100 K vertices): they were the length of the kernel.
+    if (!part) h->part = gh_partition{0, n, 0, 0, GH_EDGES_HASHED};
 
     // Pull lists of the own rows in the reference's summation order (pt.py:633-634):
     // first the edges where the vertex is endpoint 0, then those where it is endpoint 1,
@@ -319,6 +323,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     const size_t nLD = (size_t)n * h->LD, S = (size_t)h->S;
     gh_status st;
 #define GH_A(p, count, zero) if ((st = dev_alloc(h, &h->p, (count), (zero))) != GH_OK) return bail(st)
+#define GH_A2(p, count) if ((st = dev_alloc(h, &h->p, (count), true)) != GH_OK) return bail(st)
     GH_A(d_edges, (size_t)E * 2, false);
     GH_A(d_rowptr, (size_t)h->rows + 1, false);
     GH_A(d_adj, (size_t)h->adj_len, false);
@@ -382,6 +387,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         return bail(GH_ERR_HIP);
     }
     if ((st = gh_grid_alloc(h)) != GH_OK) return bail(st);
+    if (getenv("GRAPHEM_HIP_STAMPS")) GH_A2(d_stamps, (size_t)std::max(h->n_vblocks, 1) * 8);
     if (h->thr_M1 > 0) {  // endpoints of the threshold subset: every thr_stride-th own edge
         std::vector<int32_t> sub((size_t)h->thr_M1 * 2);
         for (int64_t j = 0; j < h->thr_M1; ++j) {
@@ -793,6 +799,17 @@ extern "C" gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, do
     if (name) *name = h->timers[(size_t)i].name.c_str();
     if (total_ms) *total_ms = h->timers[(size_t)i].total_ms;
     if (launches) *launches = h->timers[(size_t)i].launches;
+    return GH_OK;
+}
+
+// Diagnostic builds of a run (GRAPHEM_HIP_STAMPS set at gh_create): wall-clock stamps (100 MHz) of the last fused
+// launch, 8 per workgroup: start, after the spring phase, after its barrier, scan operands ready, scan done, hits flushed.
+extern "C" gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64_t count) {
+    GH_TRY(check_handle(h));
+    if (!h->d_stamps) { h->err = "GRAPHEM_HIP_STAMPS was not set when the engine was created"; return GH_ERR_INVALID; }
+    const int64_t have = (int64_t)std::max(h->n_vblocks, 1) * 8;
+    GH_HIP(hipStreamSynchronize(h->stream));
+    GH_HIP(hipMemcpy(out, h->d_stamps, sizeof(unsigned long long) * (size_t)std::min(count, have), hipMemcpyDeviceToHost));
     return GH_OK;
 }
 

@@ -121,8 +121,11 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
     const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
     float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
-    const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, gh_long_args la) {
+    const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, gh_long_args la,
+    unsigned long long *__restrict__ stamps /* diagnostic builds of a run only (GRAPHEM_HIP_STAMPS): 8 per workgroup */) {
     constexpr int TILE = NT * R;
+#define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+    GH_STAMP(0);
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     constexpr int HITBUF = TILE * LD * 4 / 16;  // hit records reuse the midpoint tile's LDS
     __shared__ float4 tile[TILE * LD / 4];
@@ -145,8 +148,10 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
         const bool store = blockIdx.y == 0;
         gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, store ? Fs : nullptr,
                                     store ? out_new : nullptr, mids, sx, sxx, la, Fs);
+        GH_STAMP(1);
         gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr);  // contains the barrier that ends phase A
     }
+    GH_STAMP(2);
 
     // ---- phase B: the tile becomes this workgroup's references
     gh_f2 m[R / 2][D], c0[R / 2];
@@ -172,6 +177,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
         }
     }
     __syncthreads();  // every thread has its references: the tile's LDS becomes the hit buffer
+    GH_STAMP(3);
     uint64_t *hkey = reinterpret_cast<uint64_t *>(tile);
     int *hq = reinterpret_cast<int *>(hkey + HITBUF);
     const int per = (S + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -184,7 +190,9 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
         gh_scan_queries<D, R, HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt);
     }
     __syncthreads();
+    GH_STAMP(4);
     gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+    GH_STAMP(5);
 }
 
 // MFMA form of phase B (D <= 3, 256 threads, tiles of 256*R edges): the pre-filter of scan_core.h
@@ -201,8 +209,10 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
     float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
     const gh_h8 *__restrict__ qA, const int32_t *__restrict__ qexact, int S, uint64_t *__restrict__ cand,
-    int32_t *__restrict__ cnt, gh_long_args la) {
+    int32_t *__restrict__ cnt, gh_long_args la, unsigned long long *__restrict__ stamps) {
     constexpr int LD = 4, NT = 256, TILE = NT * R, NB = 2 * R, HITBUF = 512;
+    GH_STAMP(0);
+    if (stamps && threadIdx.x == 0) { stamps[(int64_t)blockIdx.x * 8 + 6] = vblock[blockIdx.x + 1] - vblock[blockIdx.x]; stamps[(int64_t)blockIdx.x * 8 + 7] = first_edge[vblock[blockIdx.x + 1]] - first_edge[vblock[blockIdx.x]]; }
     static_assert(D <= 3, "one 16-deep contraction holds three split coordinates");
     __shared__ float4 tile[TILE];                    // fp32 midpoints of the owned edges (x, y, z, 0)
     __shared__ gh_h8 qa[GH_SCAN_QGROUP * 2];         // A rows: [query][half]
@@ -223,8 +233,10 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     {
         double sx[LD], sxx[LD];
         gh_phase_a<D, LD, NT, true>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx, la);
+        GH_STAMP(1);
         gh_block_stats<LD, NT>(sx, sxx, red, blockstats);  // contains the barrier that ends phase A
     }
+    GH_STAMP(2);
 
     // B operands of this wave's NB column blocks; a reference outside the f16 range never passes the
     // MFMA filter and is scanned exactly by its lane (half 0) below
@@ -259,6 +271,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     };
     for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
     // (visible to every thread after the staging barrier of the first query group)
+    GH_STAMP(3);
 
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
@@ -332,7 +345,10 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
         }
     }
     __syncthreads();
+    GH_STAMP(4);
     gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+    GH_STAMP(5);
+#undef GH_STAMP
 }
 
 template <int D, int R>
@@ -340,7 +356,7 @@ void launch_mfma(gh_engine *h) {
     spring_scan_mfma_kernel<D, R><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min,
         -h->prm.k_attr, h->d_Fs, h->d_new, h->d_blockstats, h->d_q, reinterpret_cast<const gh_h8 *>(h->d_qA),
-        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h));
+        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h), h->d_stamps);
 }
 
 template <int D, int LD, int R, int NT, bool LONG>
@@ -355,7 +371,7 @@ void launch_l(gh_engine *h) {
     }
     spring_scan_kernel<D, LD, R, NT, LONG><<<dim3((unsigned)h->n_vblocks, ny), dim3(NT), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
-        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h));
+        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h), h->d_stamps);
 }
 
 template <int D, int LD, int R, int NT>

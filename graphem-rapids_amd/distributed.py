@@ -196,7 +196,18 @@ class PartitionedLayout:
             src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
             dist.broadcast(uid, src=src, group=self.group)
         host = uid.cpu().numpy()
+        # every rank must be able to open RCCL and make an id of its own BEFORE anybody enters the collective
+        # ncclCommInitRank (a rank that fails there would leave the others waiting inside it)
+        ready = torch.ones(1, dtype=torch.int32, device=dev)
+        try:
+            _native.comm_unique_id()
+        except RuntimeError:
+            ready.zero_()
         if host[128] != 1:
+            ready.zero_()
+        if self.world > 1:
+            dist.all_reduce(ready, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ready.item()) != 1:
             return False
         ok = torch.ones(1, dtype=torch.int32, device=dev)
         try:

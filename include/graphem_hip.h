@@ -211,6 +211,10 @@ gh_status gh_timing_reset(gh_handle h);
 int32_t gh_timing_count(gh_handle h);
 gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, double *total_ms, int64_t *launches);
 
+/* Diagnostic runs only (environment GRAPHEM_HIP_STAMPS set at gh_create): 8 wall-clock stamps (100 MHz) per workgroup
+ * of the last fused spring+scan launch (tools/stamp_probe.py).  Blocking. */
+gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64_t count);
+
 /* Diagnostics of the last KNN search: per query, the candidate-list length the last subset
  * level and the final level saw, and whether the exact fallback had to redo the query
  * (any of the three (S,) host pointers may be NULL).  Blocking. */

@@ -78,3 +78,71 @@ def test_grid_path_is_taken_and_runs_a_layout():
     assert out.shape == (n, 3) and np.isfinite(out).all()
     with pytest.raises(ValueError):
         gra.create_graphem(gra.edges_to_adjacency(n, edges), n_components=3, backend="hip", verbose=False, knn_method="ivf")
+
+
+def test_grid_knn_on_row_partitions_and_auto_choice():
+    """The grid indexes the OWN edges of a rank, like the scan: three row-partitioned engines in the native loop
+    (loopback collectives, one thread each) with knn_method='grid' must reproduce the single engine; and AUTO picks the
+    grid from 12288 sampled midpoints on."""
+    import threading
+    from graphem_rapids_amd import _native
+    from graphem_rapids_amd.distributed import partition_rows
+    n, D, k, S, world = 90001, 3, 10, 1024, 3
+    edges = _graph(n - 1, 8, seed=6)
+    rng = np.random.default_rng(9)
+    pos = np.vstack([rng.standard_normal((n - 1, D)).astype(np.float32), np.zeros((1, D), np.float32)])
+    stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(3)]).astype(np.int32)
+    single = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=4, knn_method="scan")
+    single.set_positions(pos)
+    single.run(3, stream)
+    ref = single.get_positions()
+    single.close()
+    lib = _native.load()
+    group = lib.gh_loopback_group_create(world)
+    engines = []
+    for r in range(world):
+        chunk, lo, hi = partition_rows(n, world, r)
+        e = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=4, partition=(lo, hi, 0, 0, _native.EDGES_HASHED),
+                           knn_method="grid")
+        e.gather_layout(world, r, chunk)
+        e.comm_init_loopback(group, r)
+        e.set_positions(pos)
+        engines.append(e)
+    errors = []
+
+    def work(e):
+        try:
+            e.timing_enable(True)
+            e.run_partitioned(3, stream)
+            e.sync()
+        except Exception as exc:  # pylint: disable=broad-exception-caught
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(e,)) for e in engines]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    outs = [e.get_positions() for e in engines]
+    assert all("grid_build" in e.timings() for e in engines)
+    for e in engines:
+        e.comm_destroy()
+        e.close()
+    lib.gh_loopback_group_destroy(group)
+    assert np.abs(outs[0] - ref).max() <= 2e-6
+    assert all(np.array_equal(o, outs[0]) for o in outs[1:])
+    # AUTO
+    big = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, 16384, seed=1)
+    big.set_positions(pos)
+    big.timing_enable(True)
+    big.run(1)
+    big.sync()
+    assert "grid_build" in big.timings()
+    big.close()
+    small = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, 256, seed=1)
+    small.set_positions(pos)
+    small.timing_enable(True)
+    small.run(1)
+    small.sync()
+    assert "spring_scan" in small.timings() and "grid_build" not in small.timings()
+    small.close()

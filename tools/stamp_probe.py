@@ -1,0 +1,34 @@
+"""Where a fused spring+scan workgroup spends its time: wall-clock stamps (100 MHz) written by thread 0 at the phase
+boundaries of the last launch (diagnostic: GRAPHEM_HIP_STAMPS).  Usage: python tools/stamp_probe.py [workload]"""
+import ctypes, os, sys
+os.environ["GRAPHEM_HIP_STAMPS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, bench
+from graphem_rapids_amd import _native
+wl = sys.argv[1] if len(sys.argv) > 1 else "rr1m"
+n, D, k, S, edges, pos = bench.make_workload(wl)
+eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S)
+eng.set_positions(pos)
+eng.run(8)
+eng.sync()
+buf = np.zeros(1 << 22, dtype=np.uint64)
+st = eng.lib.gh_debug_stamps(eng.handle, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
+assert st == 0
+t = buf.reshape(-1, 8)
+t = t[t[:, 0] > 0].astype(np.int64)
+t0 = t[:, 0].min()
+names = ["spring phase (gathers)", "block sums + barrier", "scan operands", "scan over all queries", "flush hits"]
+print(wl, "workgroups", len(t), "kernel span %.1f us" % ((t[:, 5].max() - t0) / 100.0))
+for i, nm in enumerate(names):
+    d = (t[:, i + 1] - t[:, i]) / 100.0
+    print("  %-26s median %6.2f us   p90 %6.2f   max %6.2f   sum/CU %.1f us" % (nm, np.median(d), np.quantile(d, 0.9), d.max(), d.sum() / 256))
+life = (t[:, 5] - t[:, 0]) / 100.0
+print("  workgroup lifetime median %.2f us, p90 %.2f; start times: p10 %.1f p50 %.1f p90 %.1f us" % (
+    np.median(life), np.quantile(life, 0.9), *[(np.quantile(t[:, 0], q) - t0) / 100.0 for q in (0.1, 0.5, 0.9)]))
+idx = np.argsort(-life)[:5]
+full = buf.reshape(-1, 8)
+rows = np.nonzero(full[:, 0] > 0)[0]
+for i in idx:
+    print("  slowest: workgroup", int(rows[i]), "lifetime %.1f us, phases" % life[i], [round(float(x), 2) for x in (t[i, 1:6] - t[i, 0:5]) / 100.0],
+          "start %.1f us" % ((t[i, 0] - t0) / 100.0), "rows", int(t[i, 6]), "owned edges", int(t[i, 7]))
+print("  rows per workgroup: median", np.median(t[:, 6]), "max", t[:, 6].max(), "; owned edges median", np.median(t[:, 7]))
