@@ -228,6 +228,26 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const int fe0 = first_edge[v0];
     const int nedges = first_edge[v1] - fe0;
     if (threadIdx.x == 0) { hcount = 0; nbad = 0; }
+    // Nothing below depends on the spring phase: the first query group's operand rows, the tile's edge ids and the length
+    // of the exact-query list are fetched now, under phase A's gathers, instead of between the phases (measured neutral at
+    // 100 K and 1 M vertices, tools/stamp_probe.py: the scan's 8 us per workgroup there are its ~70 divergent hits, not its
+    // staging).
+    auto stage_queries = [&](int s_lo, int nq) {
+        const int q = threadIdx.x;  // one query per thread: 32 B of A row, 16 B of exact record
+        if (q < nq) {
+            qa[2 * q] = qA[2 * (s_lo + q)];
+            qa[2 * q + 1] = qA[2 * (s_lo + q) + 1];
+            qrec[q] = reinterpret_cast<const float4 *>(qt)[s_lo + q];
+        } else {  // padding row: never passes
+            const _Float16 z = (_Float16)0.0f;
+            qa[2 * q] = (gh_h8){z, z, z, z, z, z, z, z};
+            qa[2 * q + 1] = (gh_h8){z, z, z, z, (_Float16)GH_MF_NEVER, z, z, z};
+            qrec[q] = make_float4(0.f, 0.f, 0.f, -1.f);
+        }
+    };
+    stage_queries(0, min(S, GH_SCAN_QGROUP));
+    for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
+    const int nex = qexact[0];
 
     __shared__ double red[(NT / 64) * 2 * LD];
     {
@@ -269,27 +289,15 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
             else gh_append_candidate(cand, cnt, s_lo + s, gh_key(d2, id));
         }
     };
-    for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
-    // (visible to every thread after the staging barrier of the first query group)
     GH_STAMP(3);
 
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
-        if (s_lo > 0) __syncthreads();  // the previous group's rows are still being read
-        {
-            const int q = threadIdx.x;  // one query per thread: 32 B of A row, 16 B of exact record
-            if (q < nq) {
-                qa[2 * q] = qA[2 * (s_lo + q)];
-                qa[2 * q + 1] = qA[2 * (s_lo + q) + 1];
-                qrec[q] = reinterpret_cast<const float4 *>(qt)[s_lo + q];
-            } else {  // padding row: never passes
-                const _Float16 z = (_Float16)0.0f;
-                qa[2 * q] = (gh_h8){z, z, z, z, z, z, z, z};
-                qa[2 * q + 1] = (gh_h8){z, z, z, z, (_Float16)GH_MF_NEVER, z, z, z};
-                qrec[q] = make_float4(0.f, 0.f, 0.f, -1.f);
-            }
+        if (s_lo > 0) {
+            __syncthreads();  // the previous group's rows are still being read
+            stage_queries(s_lo, nq);
         }
-        __syncthreads();
+        __syncthreads();   // staged rows, edge ids, the list of out-of-range references: visible to every thread
         const int nqb = (nq + 31) / 32;
         const gh_f16x zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int qb = 0; qb < nqb; ++qb) {
@@ -328,7 +336,6 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
             }
         }
         // outside the f16 range: exact scan of this group's listed queries over the whole tile ...
-        const int nex = qexact[0];
         for (int x = 0; x < nex; ++x) {
             const int s = qexact[1 + x] - s_lo;
             if (s < 0 || s >= nq) continue;
