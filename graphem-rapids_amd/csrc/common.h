@@ -183,7 +183,29 @@ struct gh_long_args {
     const int32_t *ownadj;  // neighbours across the edges the long rows own, pull-list order
     int n;                  // number of long own rows (0: the graph has none)
     int deg;                // rows with more neighbours than this are long (gh_long_degree)
+    // fused kernels: the midpoints of the edges long rows own are made by the whole workgroup, one owned edge per thread
+    // (gh_long_midpoints), not by the row's thread walking its list
+    const uint8_t *own_long;   // per owned-edge slot: its owner row is long; null: the row's thread emits them (unfused kernels)
+    const int32_t *own_eids;   // ids of the owned edges in slot order
+    const int32_t *edges;      // (E, 2)
 };
+
+// Midpoints of the tile's owned edges whose owner row is long -> mid rows (slot j of the tile = owned edge fe0 + j).
+// (p_u + p_v) / 2 is the same number whichever endpoint owns the edge.
+template <int D, int LD, int NT>
+__device__ __forceinline__ void gh_long_midpoints(const float *__restrict__ pos, const gh_long_args &la, int fe0, int nedges,
+                                                  float *__restrict__ mid) {
+    for (int j = threadIdx.x; j < nedges; j += NT) {
+        if (!la.own_long[fe0 + j]) continue;
+        const int2 uv = reinterpret_cast<const int2 *>(la.edges)[la.own_eids[fe0 + j]];
+        float pu[LD], pv[LD], mrow[LD];
+        gh_load_row<LD>(pos, uv.x, pu);
+        gh_load_row<LD>(pos, uv.y, pv);
+#pragma unroll
+        for (int d = 0; d < LD; ++d) mrow[d] = d < D ? (pu[d] + pv[d]) / 2.0f : 0.0f;
+        gh_store_row<LD>(mid, j, mrow);
+    }
+}
 
 // One row of the spring phase: short rows pull, long rows take the force spring_long_kernel left
 // in Fpre and only emit the midpoints of the edges they own.
@@ -194,7 +216,7 @@ __device__ __forceinline__ void spring_row(const float *__restrict__ pos, const 
                                            int i_local, const float *__restrict__ Fpre) {
     if (la.n > 0 && end - beg > la.deg) {
         gh_load_row<LD>(Fpre, 0, F);
-        if (WRITE_MID) {
+        if (WRITE_MID && !la.own_long) {
             int lo = 0, hi = la.n - 1;
             while (lo < hi) {  // la.rows holds i_local
                 const int m = (lo + hi) >> 1;

@@ -62,6 +62,7 @@ struct gh_engine {
     int32_t *d_long_ownptr = nullptr; // their owned (hub-hub) edges: offsets ...
     int32_t *d_long_ownadj = nullptr; // ... and neighbours
     int32_t *d_long_eptr = nullptr;   // (nlong + 1) prefix of their degrees
+    uint8_t *d_own_long = nullptr;    // (own_count) owned-edge slots whose owner row is long (common.h gh_long_midpoints)
     float *d_long_terms = nullptr;    // (long_entries * D) force terms of their neighbours, component-major per row
     int nlong = 0;
     int long_deg = 128;               // rows with more neighbours than this are long (common.h gh_long_degree)
@@ -194,7 +195,7 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup = f
                               int32_t *next_ids = nullptr);
 gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode = -1);
 struct gh_long_args;
-gh_long_args gh_make_long_args(const gh_engine *h);                 // common.h
+gh_long_args gh_make_long_args(const gh_engine *h, bool coop_mid = false);   // common.h; coop_mid: fused kernels
 gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0);  // spring forces of the hub rows  // gathered slots of every rank -> all n rows of d_pos
 gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD);
 gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD);

@@ -598,9 +598,11 @@ gh_status launch_spring(gh_engine *h, float *outF, int64_t f_row0) {
 
 static bool spring_is_templated_d(int D) { return gh_dim_templated(D); }
 
-gh_long_args gh_make_long_args(const gh_engine *h) {
-    if (h->nlong == 0 || !spring_is_templated_d(h->D)) return gh_long_args{nullptr, nullptr, nullptr, 0, h->long_deg};
-    return gh_long_args{h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->nlong, h->long_deg};
+gh_long_args gh_make_long_args(const gh_engine *h, bool coop_mid) {
+    if (h->nlong == 0 || !spring_is_templated_d(h->D)) return gh_long_args{nullptr, nullptr, nullptr, 0, h->long_deg, nullptr, nullptr, nullptr};
+    const bool coop = coop_mid && h->d_own_long && h->d_own_eids;
+    return gh_long_args{h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->nlong, h->long_deg,
+                        coop ? h->d_own_long : nullptr, h->d_own_eids, h->d_edges};
 }
 
 // Spring forces of the long own rows -> outF rows (i + f_row0); no-op for graphs without hubs.

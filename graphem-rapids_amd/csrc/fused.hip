@@ -66,7 +66,7 @@ namespace {
 template <int D, int LD, int NT, bool LONG>
 __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const int32_t *__restrict__ rowptr,
                                            const int32_t *__restrict__ adj, const int32_t *__restrict__ first_edge,
-                                           int v0, int v1, int fe0, int64_t row_lo, float L_min, float neg_k,
+                                           int v0, int v1, int fe0, int nedges, int64_t row_lo, float L_min, float neg_k,
                                            float *__restrict__ Fs, float *__restrict__ out_new, float *mids,
                                            double (&sx)[LD], double (&sxx)[LD], const gh_long_args &la,
                                            const float *__restrict__ Fpre = nullptr /* hub forces (the Fs array) */) {
@@ -93,6 +93,8 @@ __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const 
         }
         if (out_new) gh_store_row<LD>(out_new, i, nw);
     }
+    if constexpr (LONG)
+        if (la.n > 0 && la.own_long) gh_long_midpoints<D, LD, NT>(pos, la, fe0, nedges, mids);
 }
 
 // Workgroup reduction of the per-thread column sums -> blockstats[entry][blockIdx.x], entry < 2*LD (fixed order).
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     {
         double sx[LD], sxx[LD];
         const bool store = blockIdx.y == 0;
-        gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, store ? Fs : nullptr,
+        gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, store ? Fs : nullptr,
                                     store ? out_new : nullptr, mids, sx, sxx, la, Fs);
         GH_STAMP(1);
         gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr);  // contains the barrier that ends phase A
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     __shared__ double red[(NT / 64) * 2 * LD];
     {
         double sx[LD], sxx[LD];
-        gh_phase_a<D, LD, NT, true>(pos, rowptr, adj, first_edge, v0, v1, fe0, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx, la);
+        gh_phase_a<D, LD, NT, true>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx, la);
         GH_STAMP(1);
         gh_block_stats<LD, NT>(sx, sxx, red, blockstats);  // contains the barrier that ends phase A
     }
@@ -363,7 +365,7 @@ void launch_mfma(gh_engine *h) {
     spring_scan_mfma_kernel<D, R><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min,
         -h->prm.k_attr, h->d_Fs, h->d_new, h->d_blockstats, h->d_q, reinterpret_cast<const gh_h8 *>(h->d_qA),
-        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h), h->d_stamps);
+        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), h->d_stamps);
 }
 
 template <int D, int LD, int R, int NT, bool LONG>
@@ -378,7 +380,7 @@ void launch_l(gh_engine *h) {
     }
     spring_scan_kernel<D, LD, R, NT, LONG><<<dim3((unsigned)h->n_vblocks, ny), dim3(NT), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
-        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h), h->d_stamps);
+        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), h->d_stamps);
 }
 
 template <int D, int LD, int R, int NT>

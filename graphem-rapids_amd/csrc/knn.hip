@@ -447,8 +447,13 @@ __global__ __launch_bounds__(64) void knn_tau_kernel(const uint32_t *__restrict_
             v[j] = min(v[j], x);
         }
     }
+    // K-th smallest of the group minima AS A MULTISET: a round takes the smallest remaining value and all its copies at
+    // once, counting them.  (Retiring the copies without counting made tau the K-th DISTINCT value: on a collapsed layout
+    // -- a hub that has flown off holds the variance, thousands of midpoints coincide to the last bit -- that let
+    // 12 000 candidates per query through instead of 300 and sent 8 queries per iteration to the exact fallback.)
     uint32_t kth = 0x7F800000u;
-    for (int r = 0; r < K; ++r) {
+    int need = K;
+    while (need > 0) {
         uint32_t m = v[0];
 #pragma unroll
         for (int j = 1; j < NV; ++j) m = min(m, v[j]);
@@ -457,8 +462,17 @@ __global__ __launch_bounds__(64) void knn_tau_kernel(const uint32_t *__restrict_
                 min((uint32_t)__builtin_amdgcn_readlane((int)m, 32), (uint32_t)__builtin_amdgcn_readlane((int)m, 48)));
         kth = m;
         if (m == 0x7F800000u) break;  // fewer than K occupied groups: tau = inf, the candidate lists overflow, exact fallback
+        int mine = 0;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) v[j] = v[j] == m ? 0x7F800000u : v[j];
+        for (int j = 0; j < NV; ++j) {
+            mine += v[j] == m ? 1 : 0;
+            v[j] = v[j] == m ? 0x7F800000u : v[j];
+        }
+        for (int t = 1;; ++t) {   // copies over the wave: one ballot per multiplicity level (almost always a single one)
+            const unsigned long long b = __ballot(mine >= t);
+            if (!b) break;
+            need -= __popcll(b);
+        }
     }
     const float tau = __uint_as_float(kth);
     float qs[16];

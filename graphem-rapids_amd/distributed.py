@@ -77,7 +77,8 @@ def long_degree(n, n_edges):
 def owned_edge_ids(edges, row_lo, row_hi, n=None):
     """Ids of the edges a rank with rows [row_lo, row_hi) owns under the hashed rule (vertex numbers as
     given: an engine that reorders vertices internally partitions its internal rows the same way).
-    An edge between a hub and a short row belongs to the short row; otherwise the hash decides."""
+    An edge between a hub and a short row belongs to the short row, one between two hubs of different degree to the
+    smaller hub; otherwise the hash decides."""
     edges = np.asarray(edges).reshape(-1, 2)
     second = edge_owner_is_second(np.arange(len(edges)))
     if len(edges):
@@ -85,6 +86,8 @@ def owned_edge_ids(edges, row_lo, row_hi, n=None):
         is_hub = deg > long_degree(len(deg) if n is None else n, len(edges))
         hub_u, hub_v = is_hub[edges[:, 0]], is_hub[edges[:, 1]]
         if is_hub.any():
+            du, dv = deg[edges[:, 0]], deg[edges[:, 1]]
+            second = np.where(hub_u & hub_v & (du != dv), du > dv, second)   # two hubs: the smaller one owns the edge
             second = np.where(hub_u != hub_v, hub_u, second)
     owner = np.where(second, edges[:, 1], edges[:, 0])
     return np.nonzero((owner >= row_lo) & (owner < row_hi))[0]
