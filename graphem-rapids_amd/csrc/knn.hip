@@ -44,12 +44,12 @@ struct inter_args {
 
 // Whole workgroup; best[] in LDS, visible to all threads (the callers' extraction ends with a barrier).
 __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi, const uint64_t *best, gh_pair_list *pl) {
-    if (ia.LD >= 8 && ia.LD <= 16 && ia.k <= 127 && blockDim.x % (4 * ia.LD) == 0) {   // wide rows: lanes = (role, coordinate)
+    if (ia.LD <= 16 && ia.k <= 127 && blockDim.x % (4 * ia.LD) == 0 && ia.D >= 2 && ia.D <= 16) {   // lanes = (role, coordinate)
         const int32_t i = ia.sampled[qi];
 #define GH_WIDE_ONE(DD, LL)                                                                                              \
     case DD:                                                                                                             \
-        if constexpr (LL >= 8) gh_intersect_query_wide<DD, LL>(ia.pos, ia.edges, i, best, ia.k, ia.k_inter, ia.acc, ia.tflag, \
-                                                              ia.touched, ia.tcount, pl);                               \
+        gh_intersect_query_wide<DD, LL>(ia.pos, ia.edges, i, best, ia.k, ia.k_inter, ia.acc, ia.tflag, ia.touched,     \
+                                        ia.tcount, pl);                                                                  \
         break;
         switch (ia.D) { GH_FOR_EACH_DIM(GH_WIDE_ONE) default: break; }
 #undef GH_WIDE_ONE
@@ -538,6 +538,11 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
         if (threadIdx.x == 0) stats[qi - S] = ((dred[0] + dred[1]) + dred[2]) + dred[3];
         return;
     }
+    // the first 1024 list slots are fetched before the list's length is known (the list is allocated whole: slots past the
+    // end hold stale keys, masked below): one memory round trip instead of two in front of the extraction
+    uint64_t pre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pre[j] = cand[qi * GH_CAND_CAP + j * 256 + threadIdx.x];
     const int c = cnt[qi * GH_CNT_STRIDE];
     __syncthreads();
     if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; }
@@ -545,6 +550,10 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
         if (!final_level) return;  // tau keeps its previous (still valid, looser) value
         if (threadIdx.x == 0) ovf[qi] = 1;
         block_search_query(fb, qi, K, qs, best, red);
+    } else if (c <= 1024 && !(K > 16 && c <= 512)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[j] = j * 256 + (int)threadIdx.x < c ? pre[j] : GH_KEY_INF;
+        block_extract_smallest<4>(pre, K, best, red);
     } else {
         block_extract_adaptive<NPT>(cand + qi * GH_CAND_CAP, c, K, best, red);
     }
