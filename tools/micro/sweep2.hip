@@ -170,6 +170,47 @@ __global__ __launch_bounds__(256) void sweep2_lds(const float4 *__restrict__ pos
     }
 }
 
+// The fused kernel's phase-A geometry: a 256-thread workgroup holds only 128 rows (512 owned edges per tile, 4 per row),
+// threads 128..255 idle in this phase; own row, two outputs, midpoints to LDS.  Variant 0: all 8 gathers at once in list
+// order (today's kernel); variant 1: slice-sorted list walked window by window, XCD g owning slice g, sums in arrival
+// order (what a relaxed summation order would allow).
+template <int SWEEP>
+__global__ __launch_bounds__(256) void phase_a_like(const float4 *__restrict__ pos, const int *__restrict__ adj,
+                                                    const unsigned *__restrict__ cnt, int n, int slice_rows, int G,
+                                                    float4 *__restrict__ out1, float4 *__restrict__ out2) {
+    __shared__ float4 tile[512];
+    const int g = blockIdx.x % 8, local = blockIdx.x / 8;
+    const int i = SWEEP ? g * slice_rows + local * 128 + (int)threadIdx.x : (int)blockIdx.x * 128 + (int)threadIdx.x;
+    const bool ok = threadIdx.x < 128 && i < n && (!SWEEP || i < (g + 1) * slice_rows);
+    if (!ok) return;
+    const float4 px = pos[i];
+    float4 acc = make_float4(0, 0, 0, 0);
+    int slot = threadIdx.x * 4;
+    if (SWEEP) {
+        const unsigned c = cnt[i];
+        int cur = i * 8, seen = 0;
+        for (int t = 0; t < 8; ++t) {
+            const int left = (c >> (4 * t)) & 15u;
+            for (int j = 0; j < left; ++j) {
+                const float4 v = pos[adj[cur++]];
+                acc.x += v.x - px.x; acc.y += v.y - px.y; acc.z += v.z - px.z;
+                if (seen++ & 1) tile[(slot++) & 511] = make_float4(0.5f * (v.x + px.x), 0.5f * (v.y + px.y), 0.5f * (v.z + px.z), 0.f);
+            }
+        }
+    } else {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pos[adj[i * 8 + j]];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc.x += v[j].x - px.x; acc.y += v[j].y - px.y; acc.z += v[j].z - px.z;
+            if (j & 1) tile[(slot++) & 511] = make_float4(0.5f * (v[j].x + px.x), 0.5f * (v[j].y + px.y), 0.5f * (v[j].z + px.z), 0.f);
+        }
+    }
+    out1[i] = acc;
+    out2[i] = make_float4(px.x + acc.x, px.y + acc.y, px.z + acc.z, tile[threadIdx.x].x);
+}
+
 int main(int argc, char **argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 1000000, deg = 8;
     const int slice_rows = (n + 7) / 8;
@@ -225,6 +266,13 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(drp, rp.data(), rp.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dfe, fe.data(), fe.size() * 4, hipMemcpyHostToDevice));
         timeit("plain_full (fused kernel's memory side)", [&] { plain_full<<<dim3((n + 255) / 256), dim3(256)>>>(pos, drp, dfe, dadj, n, out, out2); });
+    }
+    {
+        float4 *out2; CK(hipMalloc(&out2, (size_t)n * 16));
+        const int G0 = (n + 127) / 128;
+        timeit("phase-A-like, list order, 8 at once", [&] { phase_a_like<0><<<dim3(G0), dim3(256)>>>(pos, dadj, dcnt, n, slice_rows, 0, out, out2); });
+        const int G1 = (slice_rows + 127) / 128;
+        timeit("phase-A-like, slice sweep, arrival order", [&] { phase_a_like<1><<<dim3(8 * G1), dim3(256)>>>(pos, dadj2, dcnt, n, slice_rows, G1, out, out2); });
     }
     timeit("plain (slice-sorted lists)", [&] { plain<<<dim3((n + 255) / 256), dim3(256)>>>(pos, dadj2, n, out); });
     const int tiles = (slice_rows + 255) / 256;
