@@ -400,7 +400,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         return bail(GH_ERR_HIP);
     }
     if ((st = gh_grid_alloc(h)) != GH_OK) return bail(st);
-    if (getenv("GRAPHEM_HIP_STAMPS")) GH_A2(d_stamps, (size_t)std::max(h->n_vblocks, 1) * 8);
+    if (getenv("GRAPHEM_HIP_STAMPS")) GH_A2(d_stamps, ((size_t)std::max(h->n_vblocks, 1) + GH_STAMP_EXTRA) * 8);
     if (h->thr_M1 > 0) {  // endpoints of the threshold subset: every thr_stride-th own edge
         std::vector<int32_t> sub((size_t)h->thr_M1 * 2);
         for (int64_t j = 0; j < h->thr_M1; ++j) {
@@ -816,11 +816,13 @@ extern "C" gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, do
 }
 
 // Diagnostic builds of a run (GRAPHEM_HIP_STAMPS set at gh_create): wall-clock stamps (100 MHz) of the last fused
-// launch, 8 per workgroup: start, after the spring phase, after its barrier, scan operands ready, scan done, hits flushed.
+// launch, 8 per workgroup: start, after the spring phase, after its barrier, scan operands ready, scan done, hits flushed;
+// after those n_vblocks records, GH_STAMP_EXTRA records of the last normalise launch's first workgroups (set-up
+// workgroups first): start, mean / std known, [tile staged], end, -, -, 1 = set-up / 2 = normalising.
 extern "C" gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64_t count) {
     GH_TRY(check_handle(h));
     if (!h->d_stamps) { h->err = "GRAPHEM_HIP_STAMPS was not set when the engine was created"; return GH_ERR_INVALID; }
-    const int64_t have = (int64_t)std::max(h->n_vblocks, 1) * 8;
+    const int64_t have = ((int64_t)std::max(h->n_vblocks, 1) + GH_STAMP_EXTRA) * 8;
     GH_HIP(hipStreamSynchronize(h->stream));
     GH_HIP(hipMemcpy(out, h->d_stamps, sizeof(unsigned long long) * (size_t)std::min(count, have), hipMemcpyDeviceToHost));
     return GH_OK;

@@ -142,6 +142,7 @@ struct gh_engine {
                                     // summed elementwise over the ranks by the caller when partitioned
 
     // timing
+#define GH_STAMP_EXTRA 8192
     unsigned long long *d_stamps = nullptr;   // GRAPHEM_HIP_STAMPS: (n_vblocks, 8) wall-clock stamps of the last fused launch
     bool timing = false;
     std::vector<gh_timer_slot> timers;

@@ -330,7 +330,12 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
                                                        int32_t *__restrict__ tflag,
                                                        const int32_t *__restrict__ touched,
                                                        const int32_t *__restrict__ tcount, int nfix, int g_norm,
-                                                       int n_setup, gh_setup_args sa, int32_t *__restrict__ qexact) {
+                                                       int n_setup, gh_setup_args sa, int32_t *__restrict__ qexact,
+                                                       unsigned long long *__restrict__ stamps /* diagnostic, or null */) {
+    if (stamps && (blockIdx.x >= GH_STAMP_EXTRA)) stamps = nullptr;
+    if (stamps) stamps += (int64_t)blockIdx.x * 8;
+#define GH_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+    GH_STAMP(0);
     // the set-up workgroups come FIRST in the grid: their chains of dependent gathers start at once and
     // run under the streaming of the others
     __shared__ __align__(16) unsigned char setup_lds[GH_SETUP_LDS_BYTES];
@@ -347,14 +352,21 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
             if (d == 0) tflag[x] = 0;
         }
     }
-    extern __shared__ float ms[];  // mean[LD], std[LD]
+    extern __shared__ float ms[];  // mean[LD], std[LD], then the (2 + 2 nfix, LD) statistics rows as doubles
+    // all statistics rows with one load per thread and round, then summed from LDS in the fixed order: a thread adding
+    // its column's 2 nfix corrections straight from memory waited for them one after the other (LD = 16: 64 loads, 7.6 us
+    // before any workgroup of this launch knew mean and std -- tools/stamp_probe.py)
+    double *srow = reinterpret_cast<double *>(ms + 2 * LD);
+    for (int t = threadIdx.x; t < (2 + 2 * nfix) * LD; t += blockDim.x) srow[t] = stats[t];
+    __syncthreads();
     for (int d = threadIdx.x; d < LD; d += blockDim.x) {
         float mean = 0.0f, sd = 1.0f;
         if (d < D) {
-            double sum = stats[d], sq = stats[LD + d];
+            double sum = srow[d], sq = srow[LD + d];
+#pragma unroll 8
             for (int b = 0; b < nfix; ++b) {  // corrections of the touched rows (zero when unused)
-                sum += stats[(2 + 2 * b) * LD + d];
-                sq += stats[(3 + 2 * b) * LD + d];
+                sum += srow[(2 + 2 * b) * LD + d];
+                sq += srow[(3 + 2 * b) * LD + d];
             }
             const double m = sum / (double)n;
             double var = (sq - sum * m) / (double)(n - 1);
@@ -366,13 +378,16 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
         ms[LD + d] = sd;
     }
     __syncthreads();
+    GH_STAMP(1);
+    if (stamps && threadIdx.x == 0) stamps[6] = setup_block ? 1 : 2;
     if (setup_block) {
         const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         if (t == 0) qexact[0] = 0;
         // position of vertex v, component d < D, exactly as the normalising threads below compute it
         auto getp = [=](int64_t v, int d) { return (nw[v * LD + d] - ms[d]) / ms[LD + d]; };
-        if (sa.tiles > 0) gh_setup_block_any(sa, (int)blockIdx.x, getp, setup_lds);
+        if (sa.tiles > 0) gh_setup_block_any(sa, (int)blockIdx.x, getp, setup_lds, stamps);
         else gh_setup_item(sa, t, getp);
+        GH_STAMP(3);
         return;
     }
     // 16 bytes per thread and step (LD is a multiple of 4, rows are 16-byte aligned)
@@ -389,6 +404,8 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
         o.w = d0 + 3 < D ? (v.w - ms[d0 + 3]) / ms[LD + d0 + 3] : 0.0f;
         dst[t] = o;
     }
+    GH_STAMP(3);
+#undef GH_STAMP
 }
 
 // The same normalisation for ALL n rows from the gathered slots of every rank (one-collective
@@ -778,10 +795,11 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
         sa = gh_make_setup_args(h, next_mode, next_mode == 0 ? next_ids : h->d_sampled, h->iter + 1);
         extra = gh_setup_blocks(sa);
     }
-    normalise_kernel<<<dim3(grid + extra), dim3(256), sizeof(float) * 2 * h->LD, h->stream>>>(
+    const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * (size_t)(2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
+    normalise_kernel<<<dim3(grid + extra), dim3(256), smem, h->stream>>>(
         h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos,
         with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount, gh_fix_blocks(h->LD), (int)grid,
-        (int)extra, sa, h->d_qexact);
+        (int)extra, sa, h->d_qexact, h->d_stamps ? h->d_stamps + (int64_t)std::max(h->n_vblocks, 1) * 8 : nullptr);
     GH_LAUNCH_CHECK();
     if (presetup) {
         h->presetup_valid = true;

@@ -371,9 +371,18 @@ void launch_mfma(gh_engine *h) {
 template <int D, int LD, int R, int NT, bool LONG>
 void launch_l(gh_engine *h) {
     // few workgroups with a long packed-VALU scan each (wide rows on a small graph): the queries over up to 4 slices
+    // -- as many as still run all at once: a second round of workgroups costs a whole workgroup lifetime (C5 shape,
+    // D = 16: 179 VGPRs -> 2 workgroups per CU; 177 tiles x 4 slices ran as 512 + 196, 53 us; x 2 slices 354 at once)
     unsigned ny = 1;
     if (LD >= 8 && h->n_vblocks < 384) {
-        ny = (unsigned)(768 / (h->n_vblocks > 0 ? h->n_vblocks : 1));
+        static int resident = 0;  // per instantiation
+        if (resident == 0) {
+            int occ = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spring_scan_kernel<D, LD, R, NT, LONG>, NT, 0) != hipSuccess) occ = 1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
+            resident = (occ > 0 ? occ : 1) * (cus > 0 ? cus : 256);
+        }
+        ny = (unsigned)(resident / (h->n_vblocks > 0 ? h->n_vblocks : 1));
         if (ny > 4) ny = 4;
         if (ny < 1) ny = 1;
         if ((int64_t)ny > h->S) ny = 1;

@@ -86,7 +86,8 @@ __device__ __forceinline__ uint32_t gh_row_min_u32(uint32_t v) {
 // LDS-read / DPP chains per wave, 40 us.)  Workgroup 0 also does the per-query set-up items.
 #define GH_SETUP_LDS_BYTES (GH_THR_TILE * 16 * 4)
 template <int LD, class P>
-__device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, P getp, unsigned char *lds) {
+__device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, P getp, unsigned char *lds,
+                                               unsigned long long *stamps = nullptr /* diagnostic */) {
     // the tile in LDS as PAIRS of subset edges, component-interleaved: pair p, coordinate d -> (m_2p[d], m_2p+1[d]),
     // so that the distance chain of two references runs on packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32)
     gh_f2 *rsh = reinterpret_cast<gh_f2 *>(lds);     // [GH_THR_TILE / 2][LD]
@@ -123,6 +124,7 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
         for (int d = 0; d < LD; ++d) slot[2 * d] = m[d];
     }
     __syncthreads();
+    if (stamps && t == 0) stamps[2] = wall_clock64();
     for (int64_t s0 = 0; s0 < a.S; s0 += 256) {
         const int64_t s = s0 + t;
         if (s >= a.S) continue;   // no barrier below
@@ -176,8 +178,9 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
 
 // Runtime row stride -> the instantiation (the scan path has LD in {4, 8, 16}).
 template <class P>
-__device__ __forceinline__ void gh_setup_block_any(const gh_setup_args &a, int blk, P getp, unsigned char *lds) {
-    if (a.LD == 4) gh_setup_block<4>(a, blk, getp, lds);
-    else if (a.LD == 8) gh_setup_block<8>(a, blk, getp, lds);
-    else gh_setup_block<16>(a, blk, getp, lds);
+__device__ __forceinline__ void gh_setup_block_any(const gh_setup_args &a, int blk, P getp, unsigned char *lds,
+                                                   unsigned long long *stamps = nullptr) {
+    if (a.LD == 4) gh_setup_block<4>(a, blk, getp, lds, stamps);
+    else if (a.LD == 8) gh_setup_block<8>(a, blk, getp, lds, stamps);
+    else gh_setup_block<16>(a, blk, getp, lds, stamps);
 }

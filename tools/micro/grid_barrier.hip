@@ -1,0 +1,114 @@
+// Micro-benchmark (round 2): what one grid-wide barrier costs inside a resident (cooperatively launched) kernel on
+// MI355X, against the launch boundary it would replace.  Decides whether a persistent kernel for small graphs
+// (five dependent launches per iteration, 60+ us for ~15 us of work) is worth building.
+//
+//   barrier   G workgroups x 256 threads; per round every workgroup writes `bytes` of its own slot, passes the
+//             barrier (thread 0: agent-scope release add on one counter, relaxed spin, acquire fence), then reads
+//             the slot of workgroup (b + 97) % G and checks it holds this round's value (so the measured barrier
+//             really publishes across XCDs).
+//   launches  the same write / check as two kernels per round on one stream.
+// Usage: grid_barrier [rounds]
+#include <hip/hip_runtime.h>
+#include <hip/hip_cooperative_groups.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ __forceinline__ bool grid_barrier(unsigned *ctr, unsigned target, unsigned *fail) {
+    __syncthreads();
+    bool ok = true;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) { ok = false; break; }   // never hang the box: give up after ~0.1 s
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);   // agent scope by default for device code
+        if (!ok) atomicAdd(fail, 1u);
+    }
+    __syncthreads();
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void barrier_kernel(unsigned *ctr, unsigned *fail, float *buf, int words, int rounds,
+                                                      unsigned *bad) {
+    const int G = gridDim.x, b = blockIdx.x;
+    unsigned wrong = 0;
+    for (int r = 0; r < rounds; ++r) {
+        float *mine = buf + (size_t)b * words;
+        for (int i = threadIdx.x; i < words; i += 256) mine[i] = (float)(r + 1);
+        if (!grid_barrier(ctr, (unsigned)(2 * r + 1) * G, fail)) return;
+        const float *other = buf + (size_t)((b + 97) % G) * words;
+        for (int i = threadIdx.x; i < words; i += 256) wrong += (other[i] != (float)(r + 1));
+        if (!grid_barrier(ctr, (unsigned)(2 * r + 2) * G, fail)) return;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
+__global__ __launch_bounds__(256) void write_kernel(float *buf, int words, int r) {
+    float *mine = buf + (size_t)blockIdx.x * words;
+    for (int i = threadIdx.x; i < words; i += 256) mine[i] = (float)(r + 1);
+}
+__global__ __launch_bounds__(256) void check_kernel(const float *buf, int words, int r, unsigned *bad) {
+    const float *other = buf + (size_t)((blockIdx.x + 97) % gridDim.x) * words;
+    unsigned wrong = 0;
+    for (int i = threadIdx.x; i < words; i += 256) wrong += (other[i] != (float)(r + 1));
+    if (wrong) atomicAdd(bad, wrong);
+}
+
+int main(int argc, char **argv) {
+    const int rounds = argc > 1 ? atoi(argv[1]) : 200;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("%s: %d CUs\n", prop.name, prop.multiProcessorCount);
+    unsigned *d_ctr, *d_fail, *d_bad;
+    float *d_buf;
+    CK(hipMalloc(&d_ctr, 4)); CK(hipMalloc(&d_fail, 4)); CK(hipMalloc(&d_bad, 4));
+    CK(hipMalloc(&d_buf, 64u << 20));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, barrier_kernel, 256, 0));
+    printf("barrier_kernel: %d workgroups per CU resident\n", occ);
+    for (int G : {256, 512, 1024}) {
+        if (G > occ * prop.multiProcessorCount) continue;
+        for (int words : {64, 1024, 4096}) {     // 256 B, 4 KB, 16 KB per workgroup and phase
+            CK(hipMemsetAsync(d_ctr, 0, 4, st)); CK(hipMemsetAsync(d_fail, 0, 4, st)); CK(hipMemsetAsync(d_bad, 0, 4, st));
+            float ms[2];
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipMemsetAsync(d_ctr, 0, 4, st));
+                int w = words, rr = rounds;
+                void *args[] = {&d_ctr, &d_fail, &d_buf, &w, &rr, &d_bad};
+                CK(hipEventRecord(e0, st));
+                CK(hipLaunchCooperativeKernel(reinterpret_cast<void *>(barrier_kernel), dim3(G), dim3(256), args, 0, st));
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                CK(hipEventElapsedTime(&ms[rep], e0, e1));
+            }
+            unsigned fail = 0, bad = 0;
+            CK(hipMemcpy(&fail, d_fail, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+            // the same as launches
+            CK(hipMemsetAsync(d_bad, 0, 4, st));
+            float msl = 0;
+            for (int rep = 0; rep < 2; ++rep) {
+                CK(hipEventRecord(e0, st));
+                for (int r = 0; r < rounds; ++r) {
+                    write_kernel<<<G, 256, 0, st>>>(d_buf, words, r);
+                    check_kernel<<<G, 256, 0, st>>>(d_buf, words, r, d_bad);
+                }
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                CK(hipEventElapsedTime(&msl, e0, e1));
+            }
+            unsigned bad2 = 0;
+            CK(hipMemcpy(&bad2, d_bad, 4, hipMemcpyDeviceToHost));
+            printf("G=%4d  %5d B/wg/phase: barrier %.2f us per phase (timeouts %u, stale reads %u)   launch %.2f us per phase (stale %u)\n",
+                   G, words * 4, 1e3 * ms[1] / (2 * rounds), fail, bad, 1e3 * msl / (2 * rounds), bad2);
+        }
+    }
+    return 0;
+}

@@ -1,5 +1,6 @@
-"""Where a fused spring+scan workgroup spends its time: wall-clock stamps (100 MHz) written by thread 0 at the phase
-boundaries of the last launch (diagnostic: GRAPHEM_HIP_STAMPS).  Usage: python tools/stamp_probe.py [workload]"""
+"""Where a fused spring+scan workgroup -- and the workgroups of the normalise launch after it -- spend their time:
+wall-clock stamps (100 MHz) written by thread 0 at the phase boundaries of the last launch (diagnostic:
+GRAPHEM_HIP_STAMPS).  Usage: python tools/stamp_probe.py [workload]"""
 import ctypes, os, sys
 os.environ["GRAPHEM_HIP_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,9 +12,14 @@ eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S)
 eng.set_positions(pos)
 eng.run(8)
 eng.sync()
-buf = np.zeros(1 << 22, dtype=np.uint64)
+EXTRA = 8192   # records of the normalise launch after the fused kernel's (engine.h GH_STAMP_EXTRA)
+buf = np.full(1 << 22, np.iinfo(np.uint64).max, dtype=np.uint64)
 st = eng.lib.gh_debug_stamps(eng.handle, buf.ctypes.data_as(ctypes.c_void_p), buf.size)
 assert st == 0
+have = int(np.nonzero(buf != np.iinfo(np.uint64).max)[0].max()) // 8 + 1
+nvb = have - EXTRA
+norm = buf[nvb * 8:have * 8].reshape(-1, 8).astype(np.int64)
+buf = buf[:nvb * 8]
 t = buf.reshape(-1, 8)
 t = t[t[:, 0] > 0].astype(np.int64)
 t0 = t[:, 0].min()
@@ -32,3 +38,19 @@ for i in idx:
     print("  slowest: workgroup", int(rows[i]), "lifetime %.1f us, phases" % life[i], [round(float(x), 2) for x in (t[i, 1:6] - t[i, 0:5]) / 100.0],
           "start %.1f us" % ((t[i, 0] - t0) / 100.0), "rows", int(t[i, 6]), "owned edges", int(t[i, 7]))
 print("  rows per workgroup: median", np.median(t[:, 6]), "max", t[:, 6].max(), "; owned edges median", np.median(t[:, 7]))
+
+
+# ---- the normalise launch that followed: set-up workgroups (next iteration's queries and group minima) first
+for kind, nm in ((1, "set-up"), (2, "normalising")):
+    w = norm[norm[:, 6] == kind]
+    if len(w) == 0:
+        continue
+    z = norm[norm[:, 0] > 0][:, 0].min()
+    print("normalise launch, %d %s workgroups (of the first %d): start p50 %.1f us after the first, span to last end %.1f us" % (
+        len(w), nm, EXTRA, (np.median(w[:, 0]) - z) / 100.0, (w[:, 3].max() - z) / 100.0))
+    print("  mean/std known after     median %6.2f us  max %6.2f" % (np.median(w[:, 1] - w[:, 0]) / 100.0, (w[:, 1] - w[:, 0]).max() / 100.0))
+    if kind == 1 and (w[:, 2] > 0).any():
+        print("  queries + tile staged    median %6.2f us  max %6.2f" % (np.median(w[:, 2] - w[:, 1]) / 100.0, (w[:, 2] - w[:, 1]).max() / 100.0))
+        print("  distances, group minima  median %6.2f us  max %6.2f" % (np.median(w[:, 3] - w[:, 2]) / 100.0, (w[:, 3] - w[:, 2]).max() / 100.0))
+    else:
+        print("  rest                     median %6.2f us  max %6.2f" % (np.median(w[:, 3] - w[:, 1]) / 100.0, (w[:, 3] - w[:, 1]).max() / 100.0))
