@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -400,6 +400,15 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         return bail(GH_ERR_HIP);
     }
     if ((st = gh_grid_alloc(h)) != GH_OK) return bail(st);
+    GH_A2(d_tau_flag, 1);
+    GH_A2(d_wait_failed, 1);
+    // Thresholds by the first workgroups of the fused launch (tau_core.h) where that launch is a single round of
+    // workgroups or little more: there the iteration is a chain of launch latencies and this removes one (100 K vertices:
+    // 64.9 -> 60.6 us).  A large graph gains nothing (1 M vertices: 175.7 -> 176.7 us, the first round of workgroups waits
+    // ~3 us for producers that share their CUs with gathers) and keeps the launch of its own.
+    // GRAPHEM_HIP_TAU_SEPARATE=1 / 0 forces either form.
+    h->tau_embedded = h->n_vblocks <= 2048;
+    if (const char *e = getenv("GRAPHEM_HIP_TAU_SEPARATE")) h->tau_embedded = atoi(e) == 0;
     if (getenv("GRAPHEM_HIP_STAMPS")) GH_A2(d_stamps, ((size_t)std::max(h->n_vblocks, 1) + GH_STAMP_EXTRA) * 8);
     if (h->thr_M1 > 0) {  // endpoints of the threshold subset: every thr_stride-th own edge
         std::vector<int32_t> sub((size_t)h->thr_M1 * 2);
@@ -456,9 +465,25 @@ static gh_status download_padded(gh_engine *h, const float *d_src, float *host) 
     return GH_OK;
 }
 
+// A workgroup of a fused launch gave up waiting for that launch's thresholds (tau_core.h): whatever was computed since
+// is not to be trusted.  Cannot happen while workgroups are started in index order; checked where the host synchronises.
+static gh_status check_device_waits(gh_engine *h) {
+    if (!h->tau_embedded || !h->d_wait_failed) return GH_OK;
+    int32_t failed = 0;
+    GH_HIP(hipMemcpyAsync(&failed, h->d_wait_failed, sizeof(failed), hipMemcpyDeviceToHost, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    if (failed) {
+        h->err = "a workgroup of the fused spring+scan launch timed out waiting for the thresholds of its own launch; "
+                 "results since the last check are invalid (set GRAPHEM_HIP_TAU_SEPARATE=1 and report this)";
+        return GH_ERR_RUNTIME;
+    }
+    return GH_OK;
+}
+
 extern "C" gh_status gh_get_positions(gh_handle h, float *pos) {
     GH_TRY(check_handle(h));
     if (!pos) { h->err = "positions is NULL"; return GH_ERR_INVALID; }
+    GH_TRY(check_device_waits(h));
     return download_padded(h, h->d_pos, pos);
 }
 
@@ -544,7 +569,7 @@ static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
     }
     if (h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused) {
         GH_TRY(gh_knn_prepare(h));
-        GH_TRY(gh_knn_thresholds(h));
+        if (!h->tau_embedded) GH_TRY(gh_knn_thresholds(h));   // else: the first workgroups of the fused launch (tau_core.h)
         GH_TRY(gh_launch_spring_scan(h));
         return gh_knn_finish(h, false, fuse_intersect);
     }
@@ -627,7 +652,7 @@ extern "C" gh_status gh_sync(gh_handle h) {
     GH_TRY(check_handle(h));
     GH_HIP(hipStreamSynchronize(h->stream));
     resolve_timers(h);
-    return GH_OK;
+    return check_device_waits(h);
 }
 
 // ---- multi-GPU split step ----------------------------------------------------------

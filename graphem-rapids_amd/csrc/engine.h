@@ -142,6 +142,12 @@ struct gh_engine {
                                     // summed elementwise over the ranks by the caller when partitioned
 
     // timing
+    // thresholds inside the fused launch (tau_core.h)
+    bool tau_embedded = false;
+    unsigned *d_tau_flag = nullptr;      // queries published so far (wraps)
+    unsigned tau_epoch = 0;              // value of *d_tau_flag after the last launch issued
+    int32_t *d_wait_failed = nullptr;    // a consumer gave up waiting: reported by gh_sync / gh_get_positions
+
 #define GH_STAMP_EXTRA 8192
     unsigned long long *d_stamps = nullptr;   // GRAPHEM_HIP_STAMPS: (n_vblocks, 8) wall-clock stamps of the last fused launch
     bool timing = false;
@@ -170,6 +176,8 @@ unsigned gh_setup_blocks(const gh_setup_args &a);
 int64_t gh_gmin_floats(const gh_engine *h);   // size of d_gmin
 gh_status gh_knn_prepare(gh_engine *h);
 gh_status gh_knn_thresholds(gh_engine *h);
+struct gh_tau_args;
+gh_tau_args gh_make_tau_args(gh_engine *h);  // tau_core.h
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
 gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq, const float *d_ref, int64_t nref,
                                int D, int K, uint64_t *d_keys, std::string *err);

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "engine.h"
 #include "scan_core.h"
+#include "tau_core.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -100,7 +101,7 @@ __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const 
 // Workgroup reduction of the per-thread column sums -> blockstats[entry][blockIdx.x], entry < 2*LD (fixed order).
 template <int LD, int NT>
 __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const double (&sxx)[LD], double *red /* [NT/64][2*LD] */,
-                                               double *__restrict__ blockstats) {
+                                               double *__restrict__ blockstats, int bx, int nbx) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int d = 0; d < LD; ++d) {
@@ -112,7 +113,7 @@ __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const dou
         double v = red[threadIdx.x];
 #pragma unroll
         for (int ww = 1; ww < NT / 64; ++ww) v += red[ww * 2 * LD + threadIdx.x];
-        blockstats[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = v;  // [entry][workgroup]: the reducers read contiguously
+        blockstats[(int64_t)threadIdx.x * nbx + bx] = v;  // [entry][workgroup]: the reducers read contiguously
     }
 }
 
@@ -124,9 +125,16 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
     float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
     const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, gh_long_args la,
+    gh_tau_args ta /* nblocks > 0: the first workgroups of the grid compute the thresholds (tau_core.h) */,
     unsigned long long *__restrict__ stamps /* diagnostic builds of a run only (GRAPHEM_HIP_STAMPS): 8 per workgroup */) {
     constexpr int TILE = NT * R;
-#define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+    if ((int)blockIdx.x < ta.nblocks) {
+        if (blockIdx.y == 0) gh_tau_produce<NT>(ta);
+        return;
+    }
+    const bool coh = ta.nblocks > 0;
+    const int bx = (int)blockIdx.x - ta.nblocks, nbx = (int)gridDim.x - ta.nblocks;
+#define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + (k)] = wall_clock64(); } while (0)
     GH_STAMP(0);
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     constexpr int HITBUF = TILE * LD * 4 / 16;  // hit records reuse the midpoint tile's LDS
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     __shared__ int hcount;
     float *mids = reinterpret_cast<float *>(tile);
 
-    const int v0 = vblock[blockIdx.x], v1 = vblock[blockIdx.x + 1];
+    const int v0 = vblock[bx], v1 = vblock[bx + 1];
     const int fe0 = first_edge[v0];
     const int nedges = first_edge[v1] - fe0;
     if (threadIdx.x == 0) hcount = 0;
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
         gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, store ? Fs : nullptr,
                                     store ? out_new : nullptr, mids, sx, sxx, la, Fs);
         GH_STAMP(1);
-        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr);  // contains the barrier that ends phase A
+        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr, bx, nbx);  // contains the barrier that ends phase A
     }
     GH_STAMP(2);
 
@@ -178,6 +186,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
             else m[r / 2][d].x = mv[d];
         }
     }
+    if (ta.nblocks > 0 && threadIdx.x == 0) gh_tau_wait(ta);  // thresholds of this launch: out by now, as a rule
     __syncthreads();  // every thread has its references: the tile's LDS becomes the hit buffer
     GH_STAMP(3);
     uint64_t *hkey = reinterpret_cast<uint64_t *>(tile);
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     for (int s_lo = s_begin; s_lo < s_end; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(s_end - s_lo, GH_SCAN_QGROUP);
         if (s_lo > s_begin) __syncthreads();  // the previous group's records are still being read
-        gh_stage_queries<QS, (D <= 3 ? 3 : LD), NT>(qscan, qt, s_lo, nq, qsh, taush);
+        gh_stage_queries<QS, (D <= 3 ? 3 : LD), NT>(qscan, qt, s_lo, nq, qsh, taush, coh);
         __syncthreads();
         gh_scan_queries<D, R, HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt);
     }
@@ -211,10 +220,16 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
     float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
     const gh_h8 *__restrict__ qA, const int32_t *__restrict__ qexact, int S, uint64_t *__restrict__ cand,
-    int32_t *__restrict__ cnt, gh_long_args la, unsigned long long *__restrict__ stamps) {
+    int32_t *__restrict__ cnt, gh_long_args la, gh_tau_args ta, unsigned long long *__restrict__ stamps) {
     constexpr int LD = 4, NT = 256, TILE = NT * R, NB = 2 * R, HITBUF = 512;
+    if ((int)blockIdx.x < ta.nblocks) {  // thresholds of this launch (tau_core.h); diagnostic stamps: the last records of the buffer
+        gh_tau_produce<NT>(ta, stamps ? stamps + ((int64_t)gridDim.x - 2 * ta.nblocks + GH_STAMP_EXTRA + blockIdx.x) * 8 : nullptr);
+        return;
+    }
+    const bool coh = ta.nblocks > 0;
+    const int bx = (int)blockIdx.x - ta.nblocks, nbx = (int)gridDim.x - ta.nblocks;
     GH_STAMP(0);
-    if (stamps && threadIdx.x == 0) { stamps[(int64_t)blockIdx.x * 8 + 6] = vblock[blockIdx.x + 1] - vblock[blockIdx.x]; stamps[(int64_t)blockIdx.x * 8 + 7] = first_edge[vblock[blockIdx.x + 1]] - first_edge[vblock[blockIdx.x]]; }
+    if (stamps && threadIdx.x == 0) { stamps[(int64_t)bx * 8 + 6] = vblock[bx + 1] - vblock[bx]; stamps[(int64_t)bx * 8 + 7] = first_edge[vblock[bx + 1]] - first_edge[vblock[bx]]; }
     static_assert(D <= 3, "one 16-deep contraction holds three split coordinates");
     __shared__ float4 tile[TILE];                    // fp32 midpoints of the owned edges (x, y, z, 0)
     __shared__ gh_h8 qa[GH_SCAN_QGROUP * 2];         // A rows: [query][half]
@@ -226,20 +241,22 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     __shared__ int hcount, nbad;
     float *mids = reinterpret_cast<float *>(tile);
 
-    const int v0 = vblock[blockIdx.x], v1 = vblock[blockIdx.x + 1];
+    const int v0 = vblock[bx], v1 = vblock[bx + 1];
     const int fe0 = first_edge[v0];
     const int nedges = first_edge[v1] - fe0;
     if (threadIdx.x == 0) { hcount = 0; nbad = 0; }
-    // Nothing below depends on the spring phase: the first query group's operand rows, the tile's edge ids and the length
-    // of the exact-query list are fetched now, under phase A's gathers, instead of between the phases (measured neutral at
-    // 100 K and 1 M vertices, tools/stamp_probe.py: the scan's 8 us per workgroup there are its ~70 divergent hits, not its
-    // staging).
+    // The tile's edge ids do not depend on the spring phase: fetched now, under its gathers.  (So were the first query
+    // group's operand rows while the thresholds had a launch of their own -- measured neutral at 100 K and 1 M vertices,
+    // tools/stamp_probe.py: the scan's 8 us per workgroup there are its ~70 divergent hits, not its staging.)
     auto stage_queries = [&](int s_lo, int nq) {
         const int q = threadIdx.x;  // one query per thread: 32 B of A row, 16 B of exact record
         if (q < nq) {
-            qa[2 * q] = qA[2 * (s_lo + q)];
-            qa[2 * q + 1] = qA[2 * (s_lo + q) + 1];
-            qrec[q] = reinterpret_cast<const float4 *>(qt)[s_lo + q];
+            const float4 *arow = reinterpret_cast<const float4 *>(qA + 2 * (s_lo + q));
+            float4 a0, a1, rec;
+            gh_ld_f4x3(arow, arow + 1, reinterpret_cast<const float4 *>(qt) + s_lo + q, coh, a0, a1, rec);
+            reinterpret_cast<float4 *>(qa)[2 * q] = a0;
+            reinterpret_cast<float4 *>(qa)[2 * q + 1] = a1;
+            qrec[q] = rec;
         } else {  // padding row: never passes
             const _Float16 z = (_Float16)0.0f;
             qa[2 * q] = (gh_h8){z, z, z, z, z, z, z, z};
@@ -247,16 +264,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
             qrec[q] = make_float4(0.f, 0.f, 0.f, -1.f);
         }
     };
-    stage_queries(0, min(S, GH_SCAN_QGROUP));
     for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
-    const int nex = qexact[0];
 
     __shared__ double red[(NT / 64) * 2 * LD];
     {
         double sx[LD], sxx[LD];
         gh_phase_a<D, LD, NT, true>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx, la);
         GH_STAMP(1);
-        gh_block_stats<LD, NT>(sx, sxx, red, blockstats);  // contains the barrier that ends phase A
+        gh_block_stats<LD, NT>(sx, sxx, red, blockstats, bx, nbx);  // contains the barrier that ends phase A
     }
     GH_STAMP(2);
 
@@ -291,14 +306,19 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
             else gh_append_candidate(cand, cnt, s_lo + s, gh_key(d2, id));
         }
     };
+    if (ta.nblocks > 0) {  // thresholds of this launch: out by now, as a rule
+        if (stamps && threadIdx.x == 0) stamps[(int64_t)bx * 8 + 6] = wall_clock64();
+        if (threadIdx.x == 0) gh_tau_wait(ta);
+        if (stamps && threadIdx.x == 0) stamps[(int64_t)bx * 8 + 7] = wall_clock64();
+        __syncthreads();
+    }
+    const int nex = (int)gh_ld_u32(qexact, coh);
     GH_STAMP(3);
 
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
-        if (s_lo > 0) {
-            __syncthreads();  // the previous group's rows are still being read
-            stage_queries(s_lo, nq);
-        }
+        if (s_lo > 0) __syncthreads();  // the previous group's rows are still being read
+        stage_queries(s_lo, nq);
         __syncthreads();   // staged rows, edge ids, the list of out-of-range references: visible to every thread
         const int nqb = (nq + 31) / 32;
         const gh_f16x zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -339,7 +359,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
         }
         // outside the f16 range: exact scan of this group's listed queries over the whole tile ...
         for (int x = 0; x < nex; ++x) {
-            const int s = qexact[1 + x] - s_lo;
+            const int s = (int)gh_ld_u32(qexact + 1 + x, coh) - s_lo;
             if (s < 0 || s >= nq) continue;
             for (int j = threadIdx.x; j < nedges; j += NT) park(s_lo, s, j);
         }
@@ -360,12 +380,27 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
 #undef GH_STAMP
 }
 
+// The thresholds of this iteration: computed by the first workgroups of the fused launch itself (h->tau_embedded), or
+// already in place (knn_tau_kernel ran; nblocks = 0).
+gh_tau_args fused_tau_args(gh_engine *h, int nt) {
+    gh_tau_args ta{};
+    if (!h->tau_embedded) return ta;
+    ta = gh_make_tau_args(h);
+    h->tau_epoch += (unsigned)h->S;
+    ta.flag = h->d_tau_flag;
+    ta.target = h->tau_epoch;
+    ta.nblocks = gh_tau_blocks((int)h->S, nt);
+    ta.wait_failed = h->d_wait_failed;
+    return ta;
+}
+
 template <int D, int R>
 void launch_mfma(gh_engine *h) {
-    spring_scan_mfma_kernel<D, R><<<dim3((unsigned)h->n_vblocks), dim3(256), 0, h->stream>>>(
+    const gh_tau_args ta = fused_tau_args(h, 256);
+    spring_scan_mfma_kernel<D, R><<<dim3((unsigned)(h->n_vblocks + ta.nblocks)), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min,
         -h->prm.k_attr, h->d_Fs, h->d_new, h->d_blockstats, h->d_q, reinterpret_cast<const gh_h8 *>(h->d_qA),
-        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), h->d_stamps);
+        h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta, h->d_stamps);
 }
 
 template <int D, int LD, int R, int NT, bool LONG>
@@ -387,9 +422,11 @@ void launch_l(gh_engine *h) {
         if (ny < 1) ny = 1;
         if ((int64_t)ny > h->S) ny = 1;
     }
-    spring_scan_kernel<D, LD, R, NT, LONG><<<dim3((unsigned)h->n_vblocks, ny), dim3(NT), 0, h->stream>>>(
+    const gh_tau_args ta = fused_tau_args(h, NT);
+    spring_scan_kernel<D, LD, R, NT, LONG><<<dim3((unsigned)(h->n_vblocks + ta.nblocks), ny), dim3(NT), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
-        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), h->d_stamps);
+        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta,
+        h->d_stamps);
 }
 
 template <int D, int LD, int R, int NT>

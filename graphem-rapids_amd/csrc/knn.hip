@@ -21,6 +21,7 @@
 #include "engine.h"
 #include "scan_core.h"
 #include "setup_core.h"
+#include "tau_core.h"
 #include "intersect_core.h"
 
 #include <math.h>
@@ -420,87 +421,8 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
     gh_flush_hits<GH_SCAN_HITBUF>(hkey, hq, &hcount, cand, cnt);
 }
 
-// tau of one query = the K-th smallest of its G group minima (setup_core.h): an upper bound of its
-// K-th smallest distance over ALL own edges.  One wave per query: the minima sit NV per lane in
-// registers (more than 64 * NV groups: folded by min, which only makes groups coarser), K rounds of a
-// wave-wide minimum retire the smallest value each (equal values retire together: the bound can only
-// get looser).  Then the pre-filter records of the scan (scan_core.h).
-template <int NV>
-__global__ __launch_bounds__(64) void knn_tau_kernel(const uint32_t *__restrict__ gmin, int64_t G, int64_t Gpad, int D,
-                                                    float *__restrict__ qt, float *__restrict__ qscan, int QS, int QT,
-                                                    int K, _Float16 *__restrict__ qA, int32_t *__restrict__ qexact,
-                                                    int32_t *__restrict__ tcount_reset) {
-    // set-up done inside the previous normalise launch: the touched-list counter is reset here instead
-    if (tcount_reset && blockIdx.x == 0 && threadIdx.x == 0) *tcount_reset = 0;
-    const int64_t qi = blockIdx.x;
-    const int lane = threadIdx.x;
-    const uint32_t *row = gmin + qi * Gpad;
-    const float qcoord = lane < D ? qt[qi * QS + lane] : 0.0f;  // lane d holds coordinate d (issued with the loads below)
-    uint32_t v[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) v[j] = 0x7F800000u;
-    for (int64_t base = 0; base < G; base += 64 * NV) {
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int64_t i = base + j * 64 + lane;
-            const uint32_t x = i < G ? row[i] : 0x7F800000u;
-            v[j] = min(v[j], x);
-        }
-    }
-    // K-th smallest of the group minima AS A MULTISET: a round takes the smallest remaining value and all its copies at
-    // once, counting them.  (Retiring the copies without counting made tau the K-th DISTINCT value: on a collapsed layout
-    // -- a hub that has flown off holds the variance, thousands of midpoints coincide to the last bit -- that let
-    // 12 000 candidates per query through instead of 300 and sent 8 queries per iteration to the exact fallback.)
-    uint32_t kth = 0x7F800000u;
-    int need = K;
-    while (need > 0) {
-        uint32_t m = v[0];
-#pragma unroll
-        for (int j = 1; j < NV; ++j) m = min(m, v[j]);
-        m = gh_row_min_u32(m);
-        m = min(min((uint32_t)__builtin_amdgcn_readlane((int)m, 0), (uint32_t)__builtin_amdgcn_readlane((int)m, 16)),
-                min((uint32_t)__builtin_amdgcn_readlane((int)m, 32), (uint32_t)__builtin_amdgcn_readlane((int)m, 48)));
-        kth = m;
-        if (m == 0x7F800000u) break;  // fewer than K occupied groups: tau = inf, the candidate lists overflow, exact fallback
-        int mine = 0;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            mine += v[j] == m ? 1 : 0;
-            v[j] = v[j] == m ? 0x7F800000u : v[j];
-        }
-        for (int t = 1;; ++t) {   // copies over the wave: one ballot per multiplicity level (almost always a single one)
-            const unsigned long long b = __ballot(mine >= t);
-            if (!b) break;
-            need -= __popcll(b);
-        }
-    }
-    const float tau = __uint_as_float(kth);
-    float qs[16];
-    float qn = 0.0f;
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {   // every lane gets all coordinates (coordinates past D are 0: fma(0, 0, s) == s)
-        qs[d] = __shfl(qcoord, d, 64);
-        qn = fmaf(qs[d], qs[d], qn);
-    }
-    // scan record of the pre-filter (scan_core.h): (-2q, t),  t = tau - |q|^2 + eps*(2|q|^2 + tau)
-    if (lane < QS) qscan[qi * QS + lane] = lane < D ? -2.0f * qcoord : 0.0f;
-    if (lane == 0) {
-        qt[qi * QS + QT] = tau;
-        const float eps = gh_filter_eps(D);
-        // + 1e-30: a must-pass value is then strictly negative even when every magnitude is 0 (the
-        // MFMA form of the filter tests sign bits)
-        qscan[qi * QS + QT] = fmaf(eps, fmaf(2.0f, qn, tau), tau - qn) + 1e-30f;
-    }
-    if (qA && D <= 3) {  // operand row of the MFMA form of the filter (scan_core.h): lane k stores element k
-        _Float16 rowh[16];
-        const bool ok = gh_mf_query_row(qs, D, tau, rowh);
-        if (lane == 0 && !ok) qexact[1 + atomicAdd(&qexact[0], 1)] = (int32_t)qi;
-        _Float16 mine = rowh[0];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) mine = lane == k ? rowh[k] : mine;
-        if (lane < 16) qA[qi * 16 + lane] = mine;
-    }
-}
+// Thresholds as a launch of their own (tau_core.h): one wave per query.
+__global__ __launch_bounds__(64) void knn_tau_kernel(gh_tau_args a) { gh_tau_query_any(a, blockIdx.x, threadIdx.x); }
 
 // One workgroup per query: K smallest of the candidate list; final -> K best keys (and the
 // intersection phase of the query when ia is set), else tighten tau.  A final list that overflowed
@@ -744,20 +666,29 @@ gh_status gh_knn_prepare(gh_engine *h) {
     return GH_OK;
 }
 
+// Arguments of the threshold computation (tau_core.h) for this iteration.
+gh_tau_args gh_make_tau_args(gh_engine *h) {
+    const gh_setup_args a = gh_make_setup_args(h, 0, h->d_sampled_cur, h->iter);
+    gh_tau_args t{};
+    t.gmin = reinterpret_cast<const uint32_t *>(h->d_gmin);
+    t.Gpad = a.Gpad;
+    t.D = h->D;
+    t.QS = gh_qs(h->D, h->LD);
+    t.QT = gh_qtau(h->D, h->LD);
+    t.K = h->K;
+    t.S = (int)h->S;
+    t.qt = h->d_q;
+    t.qscan = h->d_qscan;
+    t.qA = reinterpret_cast<_Float16 *>(h->d_qA);
+    t.qexact = h->d_qexact;
+    t.tcount_reset = h->tcount_reset_pending ? h->d_tcount : nullptr;
+    return t;
+}
+
 // tau of every query from the group minima the set-up left in d_gmin.  Needs gh_knn_scan_path(h).
 gh_status gh_knn_thresholds(gh_engine *h) {
-    const gh_setup_args a = gh_make_setup_args(h, 0, h->d_sampled_cur, h->iter);
-    const int QS = gh_qs(h->D, h->LD), QT = gh_qtau(h->D, h->LD);
     gh_scope t(h, "knn_tau");
-#define GH_TAU(NVv)                                                                                                        \
-    knn_tau_kernel<NVv><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(                                                  \
-        reinterpret_cast<const uint32_t *>(h->d_gmin), a.Gpad, a.Gpad, h->D, h->d_q, h->d_qscan, QS, QT, h->K,              \
-        reinterpret_cast<_Float16 *>(h->d_qA), h->d_qexact, h->tcount_reset_pending ? h->d_tcount : nullptr)
-    // registers per lane for the group minima: the selection rounds rescan them all
-    if (a.Gpad <= 64 * 8) GH_TAU(8);
-    else if (a.Gpad <= 64 * 16) GH_TAU(16);
-    else GH_TAU(32);
-#undef GH_TAU
+    knn_tau_kernel<<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(gh_make_tau_args(h));
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

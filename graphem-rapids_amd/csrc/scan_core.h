@@ -18,16 +18,41 @@ __device__ __forceinline__ void gh_append_candidate(uint64_t *__restrict__ cand,
     if (p < GH_CAND_CAP) cand[(int64_t)sg * GH_CAND_CAP + p] = key;
 }
 
+// Loads of values another workgroup of the SAME launch produced and released (tau_core.h: thresholds inside the fused
+// launch): coherent = agent-scope atomic loads (global_load ... sc1), served past whatever stale copy an L1 or this XCD's
+// L2 holds; otherwise plain loads.
+__device__ __forceinline__ uint32_t gh_ld_u32(const void *p, bool coherent) {
+    return coherent ? __hip_atomic_load(static_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                    : *static_cast<const uint32_t *>(p);
+}
+__device__ __forceinline__ float gh_ld_f32(const float *p, bool coherent) { return __uint_as_float(gh_ld_u32(p, coherent)); }
+// 16 bytes with ONE request (sc1 loads are L2-served at the plain rate when 16 bytes wide; a dword sc1 load costs a
+// whole L2 request for 4 bytes -- the first version staged the queries that way and the fused kernel went from 127 to
+// 169 us).  The wait sits in the same statement: the compiler does not track the counter of a load it cannot see.
+__device__ __forceinline__ float4 gh_ld_f4(const float4 *p, bool coherent) {
+    if (!coherent) return *p;
+    float4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gh_ld_f4x3(const float4 *p0, const float4 *p1, const float4 *p2, bool coherent, float4 &a,
+                                           float4 &b, float4 &c) {
+    if (!coherent) { a = *p0; b = *p1; c = *p2; return; }
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+
 // Stage nq query records (plus one spare for the prefetch) of the group starting at s_lo.
 // taush gets the exact thresholds tau of the same queries (element QT of the records qt): the
 // rare exact path of the scan then needs no global load.
 template <int QS, int QT, int NT = 256>
 __device__ __forceinline__ void gh_stage_queries(const float *__restrict__ qscan, const float *__restrict__ qt,
-                                                 int s_lo, int nq, float4 *qsh, float *taush) {
+                                                 int s_lo, int nq, float4 *qsh, float *taush, bool coherent = false) {
     const float4 *src = reinterpret_cast<const float4 *>(qscan) + (int64_t)s_lo * (QS / 4);
     for (int i = threadIdx.x; i < (nq + 1) * (QS / 4); i += NT)
-        qsh[i] = i < nq * (QS / 4) ? src[i] : make_float4(0.f, 0.f, 0.f, -1.f);
-    for (int i = threadIdx.x; i < nq; i += NT) taush[i] = qt[(int64_t)(s_lo + i) * QS + QT];
+        qsh[i] = i < nq * (QS / 4) ? gh_ld_f4(src + i, coherent) : make_float4(0.f, 0.f, 0.f, -1.f);
+    for (int i = threadIdx.x; i < nq; i += NT) taush[i] = gh_ld_f32(qt + (int64_t)(s_lo + i) * QS + QT, coherent);
 }
 
 // Relative slack of the pre-filter below.  |filter value - exact fma-chain dist2| is bounded by
@@ -168,19 +193,26 @@ __device__ __forceinline__ void gh_split3(float x, _Float16 &h, _Float16 &m, _Fl
 // A-operand row of one query (16 halfs; lanes 0-31 of a wave read elements 0..7, lanes 32-63
 // elements 8..15).  q: D <= 3 coordinates (missing ones 0).  Returns false (and a never-pass row)
 // when the query is outside the f16 range: the caller must put it on the exact list.
-__device__ __forceinline__ bool gh_mf_query_row(const float *q, int D, float tau, _Float16 *row) {
+__device__ __forceinline__ bool gh_mf_query_row(const float *q /* 3 coordinates, those past D are 0 */, int D, float tau,
+                                                _Float16 *row) {
+    // always three rounds with constant indices (a zero coordinate contributes zeros everywhere: fma(0, 0, s) == s,
+    // split(0) = (0, 0)); with a run-time trip count `row` is indexed dynamically and the compiler moves it to LDS
+    (void)D;
     bool ok = tau <= GH_MF_TAU_MAX;  // false for inf / NaN too
     float qn = 0.0f;
-    for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
         ok = ok && fabsf(q[d]) <= GH_MF_RANGE;
         qn = fmaf(q[d], q[d], qn);
     }
+#pragma unroll
     for (int k = 0; k < 16; ++k) row[k] = (_Float16)0.0f;
     if (!ok) {
         row[12] = (_Float16)GH_MF_NEVER;
         return false;
     }
-    for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
         _Float16 h, l;
         gh_split2(-2.0f * q[d], h, l);
         row[3 * d] = h; row[3 * d + 1] = h; row[3 * d + 2] = l;

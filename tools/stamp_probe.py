@@ -31,14 +31,14 @@ for i, nm in enumerate(names):
 life = (t[:, 5] - t[:, 0]) / 100.0
 print("  workgroup lifetime median %.2f us, p90 %.2f; start times: p10 %.1f p50 %.1f p90 %.1f us" % (
     np.median(life), np.quantile(life, 0.9), *[(np.quantile(t[:, 0], q) - t0) / 100.0 for q in (0.1, 0.5, 0.9)]))
+embedded = len(t) > 0 and int(np.median(t[:, 6])) > (1 << 20)   # slots 6, 7: wait for this launch's thresholds (else rows, owned edges)
 idx = np.argsort(-life)[:5]
-full = buf.reshape(-1, 8)
-rows = np.nonzero(full[:, 0] > 0)[0]
 for i in idx:
-    print("  slowest: workgroup", int(rows[i]), "lifetime %.1f us, phases" % life[i], [round(float(x), 2) for x in (t[i, 1:6] - t[i, 0:5]) / 100.0],
-          "start %.1f us" % ((t[i, 0] - t0) / 100.0), "rows", int(t[i, 6]), "owned edges", int(t[i, 7]))
-print("  rows per workgroup: median", np.median(t[:, 6]), "max", t[:, 6].max(), "; owned edges median", np.median(t[:, 7]))
-
+    print("  slowest: workgroup", int(np.nonzero(buf.reshape(-1, 8)[:, 0] > 0)[0][i]), "lifetime %.1f us, phases" % life[i],
+          [round(float(x), 2) for x in (t[i, 1:6] - t[i, 0:5]) / 100.0], "start %.1f us" % ((t[i, 0] - t0) / 100.0),
+          "" if embedded else "rows %d owned edges %d" % (int(t[i, 6]), int(t[i, 7])))
+if not embedded:
+    print("  rows per workgroup: median", np.median(t[:, 6]), "max", t[:, 6].max(), "; owned edges median", np.median(t[:, 7]))
 
 # ---- the normalise launch that followed: set-up workgroups (next iteration's queries and group minima) first
 for kind, nm in ((1, "set-up"), (2, "normalising")):
@@ -54,3 +54,17 @@ for kind, nm in ((1, "set-up"), (2, "normalising")):
         print("  distances, group minima  median %6.2f us  max %6.2f" % (np.median(w[:, 3] - w[:, 2]) / 100.0, (w[:, 3] - w[:, 2]).max() / 100.0))
     else:
         print("  rest                     median %6.2f us  max %6.2f" % (np.median(w[:, 3] - w[:, 1]) / 100.0, (w[:, 3] - w[:, 1]).max() / 100.0))
+
+# ---- thresholds inside the fused launch (tau_core.h): the producers' stamps sit in the last records of the buffer
+prod = norm[-64:]
+prod = prod[prod[:, 0] > 0]
+if len(prod):
+    names2 = ["group minima loaded", "K-th smallest", "records stored (issued)", "stores acknowledged", "counter moved"]
+    print("threshold producers: %d workgroups, start %.1f us after the first workgroup, counter complete at %.1f us" % (
+        len(prod), (prod[:, 0].min() - t0) / 100.0, (prod[:, 5].max() - t0) / 100.0))
+    for i, nm in enumerate(names2):
+        d = (prod[:, i + 1] - prod[:, i]) / 100.0
+        print("  %-26s median %6.2f us   max %6.2f" % (nm, np.median(d), d.max()))
+    w = (t[:, 7] - t[:, 6]) / 100.0
+    print("  consumers: waited median %.2f us, max %.2f, %d of %d workgroups more than 1 us; wait began %.1f us (median) after the first workgroup" % (
+        np.median(w), w.max(), int((w > 1.0).sum()), len(w), (np.median(t[:, 6]) - t0) / 100.0))
