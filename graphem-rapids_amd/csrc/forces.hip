@@ -324,6 +324,10 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
 // mean / std from them.  Writes rows [row_lo, row_lo+rows) of pos.
 // The workgroups past g_norm (single-rank steps only, rows == n) run the NEXT iteration's KNN set-up
 // (setup_core.h) from the un-normalised rows: one launch and its dependent loads off the iteration.
+// LDT: the row stride as a compile-time constant for the set-up part (4, 8, 16; 0 = any stride, no tiles): one kernel for
+// all strides carried the 16-wide set-up's 127 VGPRs -- 4 workgroups per CU, so that at 1 M vertices half of the 2048
+// streaming workgroups queued behind the first 1024 (tools/stamp_probe.py: median start 8 us into the launch).
+template <int LDT>
 __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict__ nw, int64_t rows, int64_t row_lo,
                                                        int D, int LD, int64_t n, const double *__restrict__ stats,
                                                        float *__restrict__ pos, double *__restrict__ acc,
@@ -385,8 +389,12 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
         if (t == 0) qexact[0] = 0;
         // position of vertex v, component d < D, exactly as the normalising threads below compute it
         auto getp = [=](int64_t v, int d) { return (nw[v * LD + d] - ms[d]) / ms[LD + d]; };
-        if (sa.tiles > 0) gh_setup_block_any(sa, (int)blockIdx.x, getp, setup_lds, stamps);
-        else gh_setup_item(sa, t, getp);
+        if constexpr (LDT > 0) {
+            if (sa.tiles > 0) gh_setup_block<LDT>(sa, (int)blockIdx.x, getp, setup_lds, stamps);
+            else gh_setup_item(sa, t, getp);
+        } else {
+            gh_setup_item(sa, t, getp);
+        }
         GH_STAMP(3);
         return;
     }
@@ -394,16 +402,29 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
     const int64_t total4 = rows * LD / 4;
     const float4 *src = reinterpret_cast<const float4 *>(nw);
     float4 *dst = reinterpret_cast<float4 *>(pos + row_lo * LD);
-    for (int64_t t = nb * (int64_t)blockDim.x + threadIdx.x; t < total4; t += (int64_t)g_norm * blockDim.x) {
+    // four elements per thread and round, all four loads issued before the first division.  (Measured neutral for the
+    // launch as a whole: at 1 M vertices the streaming workgroups are done after 13 us, the set-up workgroups after 17 --
+    // 10 us of that are their two levels of cold random loads, edge -> rows, and holding the streaming back by 3.4 us
+    // did not shorten them: tools/stamp_probe.py.)
+    const int64_t step = (int64_t)g_norm * blockDim.x;
+    auto norm4 = [&](int64_t t, const float4 &v) {
         const int d0 = (int)((t * 4) % LD);
-        const float4 v = src[t];
         float4 o;
         o.x = d0 + 0 < D ? (v.x - ms[d0 + 0]) / ms[LD + d0 + 0] : 0.0f;
         o.y = d0 + 1 < D ? (v.y - ms[d0 + 1]) / ms[LD + d0 + 1] : 0.0f;
         o.z = d0 + 2 < D ? (v.z - ms[d0 + 2]) / ms[LD + d0 + 2] : 0.0f;
         o.w = d0 + 3 < D ? (v.w - ms[d0 + 3]) / ms[LD + d0 + 3] : 0.0f;
         dst[t] = o;
+    };
+    int64_t t = nb * (int64_t)blockDim.x + threadIdx.x;
+    for (; t + 3 * step < total4; t += 4 * step) {
+        const float4 v0 = src[t], v1 = src[t + step], v2 = src[t + 2 * step], v3 = src[t + 3 * step];
+        norm4(t, v0);
+        norm4(t + step, v1);
+        norm4(t + 2 * step, v2);
+        norm4(t + 3 * step, v3);
     }
+    for (; t < total4; t += step) norm4(t, src[t]);
     GH_STAMP(3);
 #undef GH_STAMP
 }
@@ -411,6 +432,7 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
 // The same normalisation for ALL n rows from the gathered slots of every rank (one-collective
 // finish, include/graphem_hip.h): slot r = [chunk rows of new positions | that rank's statistics].
 // The per-rank statistics are added in rank order, so every rank derives the same mean / std.
+template <int LDT>
 __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned char *__restrict__ gbuf, int64_t slot,
                                                                 int64_t chunk, int world, int D, int LD, int64_t n,
                                                                 int nfix, float *__restrict__ pos,
@@ -469,8 +491,12 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
             const float *rowsrc = reinterpret_cast<const float *>(gbuf + r * slot);
             return (rowsrc[(v - r * chunk) * LD + d] - ms[d]) / ms[LD + d];
         };
-        if (sa.tiles > 0) gh_setup_block_any(sa, (int)blockIdx.x, getp, setup_lds);
-        else gh_setup_item(sa, t, getp);
+        if constexpr (LDT > 0) {
+            if (sa.tiles > 0) gh_setup_block<LDT>(sa, (int)blockIdx.x, getp, setup_lds);
+            else gh_setup_item(sa, t, getp);
+        } else {
+            gh_setup_item(sa, t, getp);
+        }
         return;
     }
     const int64_t total4 = n * LD / 4;  // 16 bytes per thread and step
@@ -787,8 +813,10 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
     if (h->rows == 0) return with_cleanup ? gh_launch_inter_cleanup(h) : GH_OK;
     gh_scope t(h, "normalise");
     const int64_t total = h->rows * h->LD / 4;  // float4 elements
-    unsigned grid = grid_for(total, 256);
-    if (grid > 2048) grid = 2048;
+    unsigned grid = grid_for(total, 1024);  // four elements per thread and round (normalise_kernel)
+    unsigned cap = 2048;
+    if (const char *e = getenv("GRAPHEM_HIP_NORM_GRID")) cap = (unsigned)std::max(64, atoi(e));
+    if (grid > cap) grid = cap;
     gh_setup_args sa{};
     unsigned extra = 0;
     if (presetup) {
@@ -796,10 +824,19 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
         extra = gh_setup_blocks(sa);
     }
     const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * (size_t)(2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
-    normalise_kernel<<<dim3(grid + extra), dim3(256), smem, h->stream>>>(
-        h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos,
-        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount, gh_fix_blocks(h->LD), (int)grid,
-        (int)extra, sa, h->d_qexact, h->d_stamps ? h->d_stamps + (int64_t)std::max(h->n_vblocks, 1) * 8 : nullptr);
+#define GH_NORM(LL)                                                                                         \
+    normalise_kernel<LL><<<dim3(grid + extra), dim3(256), smem, h->stream>>>(                                    \
+        h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats, h->d_pos,                              \
+        with_cleanup ? h->d_acc : nullptr, h->d_tflag, h->d_touched, h->d_tcount, gh_fix_blocks(h->LD), (int)grid, \
+        (int)extra, sa, h->d_qexact, h->d_stamps ? h->d_stamps + (int64_t)std::max(h->n_vblocks, 1) * 8 : nullptr)
+    if (h->LD == 4) GH_NORM(4);
+    else if (h->LD == 8) GH_NORM(8);
+    else if (h->LD == 16) GH_NORM(16);
+    else {
+        if (sa.tiles > 0) { h->err = "KNN set-up tiles need a row stride of 4, 8 or 16"; return GH_ERR_RUNTIME; }
+        GH_NORM(0);
+    }
+#undef GH_NORM
     GH_LAUNCH_CHECK();
     if (presetup) {
         h->presetup_valid = true;
@@ -825,9 +862,18 @@ gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
         extra = gh_setup_blocks(sa);
     }
     const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * h->LD * (size_t)h->g_world;
-    normalise_gathered_kernel<<<dim3(grid + extra), dim3(256), smem, h->stream>>>(
-        h->d_gbuf, h->g_slot, h->g_chunk, h->g_world, h->D, h->LD, h->n, gh_fix_blocks(h->LD), h->d_pos, h->d_acc,
-        h->d_tflag, h->d_touched, h->d_tcount, (int)grid, (int)extra, sa, h->d_qexact);
+#define GH_NORMG(LL)                                                                                              \
+    normalise_gathered_kernel<LL><<<dim3(grid + extra), dim3(256), smem, h->stream>>>(                                   \
+        h->d_gbuf, h->g_slot, h->g_chunk, h->g_world, h->D, h->LD, h->n, gh_fix_blocks(h->LD), h->d_pos, h->d_acc,         \
+        h->d_tflag, h->d_touched, h->d_tcount, (int)grid, (int)extra, sa, h->d_qexact)
+    if (h->LD == 4) GH_NORMG(4);
+    else if (h->LD == 8) GH_NORMG(8);
+    else if (h->LD == 16) GH_NORMG(16);
+    else {
+        if (sa.tiles > 0) { h->err = "KNN set-up tiles need a row stride of 4, 8 or 16"; return GH_ERR_RUNTIME; }
+        GH_NORMG(0);
+    }
+#undef GH_NORMG
     GH_LAUNCH_CHECK();
     if (presetup) {
         h->presetup_valid = true;

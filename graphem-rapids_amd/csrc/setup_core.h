@@ -143,7 +143,7 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
         uint32_t *dst = reinterpret_cast<uint32_t *>(a.gmin) + s * a.Gpad + (int64_t)blk * GH_THR_GROUPS;
         // a few pairs in flight per lane only: fully unrolled, the compiler hoists every LDS read of the tile
         // (512 registers and scratch spills, which also cost the normalising workgroups of the same kernel their occupancy)
-        constexpr int UNR = LD == 4 ? 8 : LD == 8 ? 4 : 2;
+        constexpr int UNR = LD == 4 ? 4 : LD == 8 ? 4 : 2;  // (LD = 4: 8 in flight ran the distance loop ~1 us faster, at 90 VGPRs for the whole normalise launch instead of 58)
         uint32_t mn[GH_THR_GROUPS];
 #pragma unroll
         for (int gg = 0; gg < GH_THR_GROUPS; ++gg) {

@@ -48,6 +48,8 @@ for kind, nm in ((1, "set-up"), (2, "normalising")):
     z = norm[norm[:, 0] > 0][:, 0].min()
     print("normalise launch, %d %s workgroups (of the first %d): start p50 %.1f us after the first, span to last end %.1f us" % (
         len(w), nm, EXTRA, (np.median(w[:, 0]) - z) / 100.0, (w[:, 3].max() - z) / 100.0))
+    print("  end times: p10 %.1f p50 %.1f p90 %.1f p99 %.1f us; start times p90 %.1f max %.1f us" % (
+        *[(np.quantile(w[:, 3], q) - z) / 100.0 for q in (0.1, 0.5, 0.9, 0.99)], (np.quantile(w[:, 0], 0.9) - z) / 100.0, (w[:, 0].max() - z) / 100.0))
     print("  mean/std known after     median %6.2f us  max %6.2f" % (np.median(w[:, 1] - w[:, 0]) / 100.0, (w[:, 1] - w[:, 0]).max() / 100.0))
     if kind == 1 and (w[:, 2] > 0).any():
         print("  queries + tile staged    median %6.2f us  max %6.2f" % (np.median(w[:, 2] - w[:, 1]) / 100.0, (w[:, 2] - w[:, 1]).max() / 100.0))
