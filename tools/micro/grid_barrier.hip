@@ -6,7 +6,7 @@
 //             barrier (thread 0: agent-scope release add on one counter, relaxed spin, acquire fence), then reads
 //             the slot of workgroup (b + 97) % G and checks it holds this round's value (so the measured barrier
 //             really publishes across XCDs).
-//   launches  the same write / check as two kernels per round on one stream.
+//   launches  the same write / check as two kernels per round on one stream; "graph": that chain captured and replayed.
 //   flag      the protocol of the thresholds inside the fused launch (fused.hip): the FIRST P workgroups produce (write-through
 //             sc1 stores, s_waitcnt vmcnt(0), one add on a counter) and leave; every other workgroup first reads
 //             the producers' slots (stale copies now sit in its L1 / L2), does ~5 us of other work, then polls the
@@ -149,6 +149,30 @@ int main(int argc, char **argv) {
             printf("G=%4d  %5d B/wg/phase: barrier %.2f us per phase (timeouts %u, stale reads %u)   launch %.2f us per phase (stale %u)\n",
                    G, words * 4, 1e3 * ms[1] / (2 * rounds), fail, bad, 1e3 * msl / (2 * rounds), bad2);
         }
+    }
+    // ---- the same chain of dependent launches replayed from a hipGraph
+    for (int G : {256, 1024}) {
+        const int words = 1024;
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        for (int r = 0; r < rounds; ++r) {
+            write_kernel<<<G, 256, 0, st>>>(d_buf, words, r);
+            check_kernel<<<G, 256, 0, st>>>(d_buf, words, r, d_bad);
+        }
+        CK(hipStreamEndCapture(st, &graph));
+        CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0, st));
+            CK(hipGraphLaunch(exec, st));
+            CK(hipEventRecord(e1, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        printf("graph: G=%d, %d launches replayed: %.2f us per launch\n", G, 2 * rounds, 1e3 * ms / (2 * rounds));
+        CK(hipGraphExecDestroy(exec));
+        CK(hipGraphDestroy(graph));
     }
     // ---- producer / consumer flag inside one launch
     for (int G : {1024, 8192}) {
