@@ -566,6 +566,40 @@ def test_fused_scan_knn_is_exact(form, n, D, deg, outliers, monkeypatch):
     assert np.array_equal(d2, want)
 
 
+@pytest.mark.parametrize("n,D,k,S,outliers", [
+    (50000, 3, 10, 256, False),    # MFMA form, 391 tiles
+    (50000, 3, 10, 1100, True),    # several query groups, queries outside the f16 range (the exact-query list)
+    (30000, 2, 15, 300, False),
+    (20000, 4, 10, 256, False),    # packed-VALU form, stride 4
+    (12000, 8, 12, 64, False),
+    (10000, 16, 32, 256, False),   # C5 shape: query slices over blockIdx.y
+    (700000, 3, 10, 256, False),   # forced inside a launch of many rounds of workgroups (the default there is the separate kernel)
+])
+def test_thresholds_inside_the_fused_launch_equal_the_separate_kernel(n, D, k, S, outliers, monkeypatch):
+    """The thresholds of the filtered scan are computed either by knn_tau_kernel or by the first workgroups of the fused
+    spring+scan launch itself, handed to the other workgroups through a counter (csrc/tau_core.h).  Both forms must
+    give the same keys, bit for bit, and the same positions after a run that uses the device sampler."""
+    from graphem_rapids_amd import _native
+    edges, pos, sampled = _random_case(n, D, 8, k, S, seed=77)
+    if outliers:
+        far = np.random.default_rng(3).permutation(n)[: n // 100]
+        pos[far] *= np.float32(300.0)
+        sampled[:8] = np.nonzero(np.isin(edges[:, 0], far))[0][:8]
+    keys, out = {}, {}
+    for separate in ("1", "0"):
+        monkeypatch.setenv("GRAPHEM_HIP_TAU_SEPARATE", separate)
+        keys[separate] = _fused_step_keys(n, D, edges, pos, sampled, k)
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=5)
+        eng.set_positions(pos)
+        eng.run(6)
+        out[separate] = eng.get_positions()
+        eng.close()
+    assert np.array_equal(keys["0"], keys["1"])
+    ids = (keys["0"] & 0xFFFFFFFF).astype(np.int32)
+    assert np.array_equal(ids[:, 1:], oracle.knn_midpoints(pos, edges, sampled, k))
+    assert np.abs(out["0"] - out["1"]).max() <= 1e-6
+
+
 @pytest.mark.parametrize("reorder", ["off", "bfs"])
 def test_skewed_degrees_hubs(reorder):
     """A graph with hubs (degrees 20000, 2000, 600 on top of a sparse random graph): one row owns more
