@@ -195,7 +195,16 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     const int s_begin = (int)blockIdx.y * per, s_end = min(S, s_begin + per);
     for (int s_lo = s_begin; s_lo < s_end; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(s_end - s_lo, GH_SCAN_QGROUP);
-        if (s_lo > s_begin) __syncthreads();  // the previous group's records are still being read
+        if (s_lo > s_begin) {
+            __syncthreads();  // the previous group's records are still being read
+            // many query groups: the parked hits leave before the buffer fills (the subset stride then need not shrink
+            // with the number of queries to keep a workgroup's hits of ALL groups under the buffer size)
+            if (hcount >= HITBUF / 4) {
+                gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+                __syncthreads();
+                if (threadIdx.x == 0) hcount = 0;
+            }
+        }
         gh_stage_queries<QS, (D <= 3 ? 3 : LD), NT>(qscan, qt, s_lo, nq, qsh, taush, coh);
         __syncthreads();
         gh_scan_queries<D, R, HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt);
@@ -317,7 +326,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
 
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
-        if (s_lo > 0) __syncthreads();  // the previous group's rows are still being read
+        if (s_lo > 0) {
+            __syncthreads();  // the previous group's rows are still being read
+            if (hcount >= HITBUF / 4) {  // many query groups: the parked hits leave before the buffer fills
+                gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+                __syncthreads();
+                if (threadIdx.x == 0) hcount = 0;
+            }
+        }
         stage_queries(s_lo, nq);
         __syncthreads();   // staged rows, edge ids, the list of out-of-range references: visible to every thread
         const int nqb = (nq + 31) / 32;

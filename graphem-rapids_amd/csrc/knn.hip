@@ -579,7 +579,7 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
 // selection.  Measured optimum (rr1m, M = 4M, S*K = 2816): 64 (178 us per iteration; 40: 182, 100: 181); M = 400K: 20.
 // That is sqrt(c * M / (S*K)) with c = 3 for the MFMA form of the scan (its hits cost less than half as much as the
 // packed-VALU form's, whose balance sits lower).  Bounds: the list holds GH_CAND_CAP candidates (mean K*stride kept
-// <= 4096), a workgroup parks its hits in LDS (mean S*K*stride*tile/M kept near 300 for a buffer of >= 1024), and the
+// <= 4096), a workgroup parks its hits in LDS (mean min(S,256)*K*stride*tile/M per query group kept near 300 for a buffer of >= 512), and the
 // subset must keep well over K groups of GH_THR_GSIZE rows.
 int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile, bool mfma) {
     if (const char *e = getenv("GRAPHEM_HIP_SUBSET_STRIDE")) {  // tuning override
@@ -593,7 +593,8 @@ int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile, bool mfma) {
     const int64_t by_list = 4096 / K;
     if (r > by_list) r = by_list;
     if (r > 256) r = 256;
-    const int64_t by_hits = (int64_t)(300.0 * (double)Mtot / ((double)S * K * tile));
+    // (per query GROUP: the fused kernels empty the buffer between groups once it is a quarter full)
+    const int64_t by_hits = (int64_t)(300.0 * (double)Mtot / ((double)(S < 256 ? S : 256) * K * tile));
     if (r > by_hits) r = by_hits;
     if (r < 2) r = 2;
     while (r > 2 && Mtot / r < 8 * (int64_t)K * GH_THR_GSIZE) r /= 2;  // at least 8 K groups: tau stays close to the subset's K-th smallest
