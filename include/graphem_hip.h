@@ -63,7 +63,8 @@ typedef struct {
 
 /* Internal vertex order.  The spring phase gathers the position row of every neighbour; with
  * breadth-first vertex numbers a vertex sits next to its BFS siblings and close to its parent and
- * children, so more of those gathers hit the L2.  Purely internal: vertex arrays cross the API in
+ * children, so more of those gathers hit the L2; within blocks of 16384 such numbers the rows are put in
+ * order of falling degree (the lanes of a wave walk their lists in lock-step).  Purely internal: vertex arrays cross the API in
  * the caller's order, edge ids are unchanged and every summation keeps the reference's order, so
  * results do not depend on it.  AUTO = BFS when the position array outgrows an L2 (n * row bytes >
  * 3 MB) and the partition (if any) uses GH_EDGES_HASHED.  gh_positions_device() exposes the
