@@ -30,6 +30,8 @@ WORKLOADS = {
     "rr4m": ("rr", 4_000_000, 8, 3, 10, 256),      # BASELINE configs[3] (meant for 8 GPUs)
     "snap16": ("er", 4039, 0.0108, 16, 32, 256),   # BASELINE configs[4] shape (facebook_combined size), D=16 k=32
     "rr20k": ("rr", 20_000, 8, 3, 10, 256),        # quick self-test
+    "rr1m_d6": ("rr", 1_000_000, 8, 6, 10, 256),   # wide rows at scale (8-float rows)
+    "rr1m_d12": ("rr", 1_000_000, 8, 12, 10, 256), # (16-float rows, 32-deep contraction)
 }
 HBM_PEAK = 8.0e12       # B/s  (MI355X_MICROARCH.md: HBM3E peak, spec)
 FP32_PEAK = 157.3e12    # FLOP/s (fp32 vector peak = dense fp32 MFMA peak)
@@ -122,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-size", type=int, default=None, help="override the workload's number of sampled midpoints")
     ap.add_argument("--knn", default="auto", choices=["auto", "scan", "grid"], help="KNN search (gh_params.knn_method)")
+    ap.add_argument("--dim", type=int, default=None, help="override the workload's number of components (experiments)")
     ap.add_argument("--dist", action="store_true",
                     help="use the multi-GPU driver (RCCL collectives) even for one rank: rehearsal of the N>1 path")
     args = ap.parse_args()
@@ -136,6 +139,9 @@ def main():
 
     from graphem_rapids_amd import _native
     n, D, k, S, edges, pos = make_workload(args.workload)
+    if args.dim:
+        D = args.dim
+        pos = (np.random.default_rng(0).standard_normal((n, D)) * 0.1).astype(np.float32)
     E = len(edges)
     if args.sample_size:
         S = min(args.sample_size, E)

@@ -36,14 +36,16 @@
 // D = 4 and the LD = 8 / 16 kernels always use it).
 static bool fused_mfma(int LD, int D, int64_t S) {
     (void)S;
-    if (LD != 4 || D > 3) return false;
+    if (D == 4 || D > 16 || (LD != 4 && LD != 8 && LD != 16)) return false;   // D <= 3: split form; 5..16: wide form (scan_core.h)
     if (const char *e = getenv("GRAPHEM_HIP_MFMA")) return atoi(e) != 0;
     return true;
 }
+static int fused_mfma_kb(int LD, int D, int64_t S) { return !fused_mfma(LD, D, S) ? -1 : D <= 3 ? 0 : D <= 10 ? 1 : 2; }
 static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int *r) {
     *nt = 256;
     *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
     if (LD <= 4 && (own_edges < 1500000 || fused_mfma(LD, D, S))) *r = 2;  // MFMA form: 95 VGPRs / 27 KB instead of 115 / 37
+    if (LD > 4 && fused_mfma(LD, D, S)) *r = 2;  // wide MFMA form: tiles of 512 (the fp32 tile stays in LDS for the exact checks)
     if (LD <= 4 && own_edges < 400000 && !fused_mfma(LD, D, S)) *nt = 128;  // the MFMA form needs 256 threads
     const char *e = getenv("GRAPHEM_HIP_FUSED_CFG");
     if (e && LD <= 4) {
@@ -52,6 +54,7 @@ static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int 
     }
 }
 bool gh_fused_uses_mfma(const gh_engine *h) { return h->fused_scan && fused_mfma(h->LD, h->D, h->S); }
+int gh_fused_mfma_kb(const gh_engine *h) { return h->fused_scan ? fused_mfma_kb(h->LD, h->D, h->S) : -1; }
 int gh_fused_tile(const gh_engine *h) {
     int nt, r;
     fused_cfg(h->LD, h->D, h->S, h->own_count, &nt, &r);
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
     unsigned long long *__restrict__ stamps /* diagnostic builds of a run only (GRAPHEM_HIP_STAMPS): 8 per workgroup */) {
     constexpr int TILE = NT * R;
     if ((int)blockIdx.x < ta.nblocks) {
-        if (blockIdx.y == 0) gh_tau_produce<NT>(ta);
+        if (blockIdx.y == 0) gh_tau_produce<NT, -1>(ta);
         return;
     }
     const bool coh = ta.nblocks > 0;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     int32_t *__restrict__ cnt, gh_long_args la, gh_tau_args ta, unsigned long long *__restrict__ stamps) {
     constexpr int LD = 4, NT = 256, TILE = NT * R, NB = 2 * R, HITBUF = 512;
     if ((int)blockIdx.x < ta.nblocks) {  // thresholds of this launch (tau_core.h); diagnostic stamps: the last records of the buffer
-        gh_tau_produce<NT>(ta, stamps ? stamps + ((int64_t)gridDim.x - 2 * ta.nblocks + GH_STAMP_EXTRA + blockIdx.x) * 8 : nullptr);
+        gh_tau_produce<NT, 0>(ta, stamps ? stamps + ((int64_t)gridDim.x - 2 * ta.nblocks + GH_STAMP_EXTRA + blockIdx.x) * 8 : nullptr);
         return;
     }
     const bool coh = ta.nblocks > 0;
@@ -396,6 +399,193 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
 #undef GH_STAMP
 }
 
+// Wide rows (5 <= D <= 16) with the pre-filter on the matrix pipe (scan_core.h "Wide rows"): phase A as in
+// spring_scan_kernel, phase B as in spring_scan_mfma_kernel with 16 * KB deep contractions -- each wave owns 4 column
+// blocks of 32 references whose f16 operands stay in registers, the queries stream past as A operands from LDS, a lane
+// owns one reference column and 16 query rows of every 32x32 result; the fp32 tile and query records stay in LDS for
+// the exact re-check of the few pairs that pass.  Tile = 512 owned edges, 256 threads.
+// Packed fp32 VALU needs D/2 instructions per pair and lane; this form one (two) matrix instructions per 1024 pairs plus
+// the same ~10 VALU instructions to test them.
+template <int D, int LD, bool LONG>
+__global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
+    const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
+    const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
+    const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
+    float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
+    const float *__restrict__ qscan, const gh_h8 *__restrict__ qA, const int32_t *__restrict__ qexact, int S,
+    uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, gh_long_args la, gh_tau_args ta,
+    unsigned long long *__restrict__ stamps) {
+    constexpr int NT = 256, R = 2, TILE = NT * R, NB = 2 * R, HITBUF = 512;
+    constexpr int KB = D <= 10 ? 1 : 2;
+    constexpr int QS = LD + 4, QT = LD;
+    if ((int)blockIdx.x < ta.nblocks) {
+        if (blockIdx.y == 0) gh_tau_produce<NT, KB>(ta, stamps ? stamps + ((int64_t)gridDim.x - 2 * ta.nblocks + GH_STAMP_EXTRA + blockIdx.x) * 8 : nullptr);
+        return;
+    }
+    const bool coh = ta.nblocks > 0;
+    const int bx = (int)blockIdx.x - ta.nblocks, nbx = (int)gridDim.x - ta.nblocks;
+#define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + (k)] = wall_clock64(); } while (0)
+    GH_STAMP(0);
+    __shared__ float4 tile[TILE * LD / 4];                 // fp32 midpoints of the owned edges
+    __shared__ gh_h8 qa[GH_SCAN_QGROUP * KB * 2];          // A rows: [query][block of 16][half]
+    __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)]; // (-2q, t) records: the exact re-check takes q from them
+    __shared__ float taush[GH_SCAN_QGROUP];
+    __shared__ uint64_t hkey[HITBUF];
+    __shared__ int hq[HITBUF];
+    __shared__ uint16_t badlist[TILE];
+    __shared__ uint32_t ids[TILE];
+    __shared__ int hcount, nbad;
+    float *mids = reinterpret_cast<float *>(tile);
+
+    const int v0 = vblock[bx], v1 = vblock[bx + 1];
+    const int fe0 = first_edge[v0];
+    const int nedges = first_edge[v1] - fe0;
+    if (threadIdx.x == 0) { hcount = 0; nbad = 0; }
+    for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
+
+    // ---- phase A (every query slice redoes it for its tile, slice 0 alone stores its results)
+    __shared__ double red[(NT / 64) * 2 * LD];
+    {
+        double sx[LD], sxx[LD];
+        const bool store = blockIdx.y == 0;
+        gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, store ? Fs : nullptr,
+                                    store ? out_new : nullptr, mids, sx, sxx, la, Fs);
+        GH_STAMP(1);
+        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr, bx, nbx);  // contains the barrier that ends phase A
+    }
+    GH_STAMP(2);
+
+    // ---- phase B: operands of this wave's column blocks
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = lane & 31, hsel = lane >> 5;
+    gh_h8 B[NB][KB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = w * (64 * R) + b * 32 + col;
+        float mv[LD];
+        gh_load_row<LD>(mids, j < nedges ? j : 0, mv);
+        if (!gh_mfw_ref_col<D, KB>(mv, j < nedges, hsel, B[b]) && hsel == 0) badlist[atomicAdd(&nbad, 1)] = (uint16_t)j;
+    }
+
+    auto park = [&](int s_lo, int s, int j) {  // exact decision on pair (query s of the group, reference j)
+        const float *qv = reinterpret_cast<const float *>(qsh) + s * QS;   // (-2q_0 .. -2q_{D-1}, .., t)
+        float mv[LD];
+        gh_load_row<LD>(mids, j, mv);
+        float d2 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float df = -0.5f * qv[d] - mv[d];   // the record holds -2q: exact both ways
+            d2 = fmaf(df, df, d2);
+        }
+        if (d2 <= taush[s]) {
+            const uint32_t id = ids[j];
+            const int p = atomicAdd(&hcount, 1);
+            if (p < HITBUF) { hkey[p] = gh_key(d2, id); hq[p] = s_lo + s; }
+            else gh_append_candidate(cand, cnt, s_lo + s, gh_key(d2, id));
+        }
+    };
+    if (stamps && ta.nblocks > 0 && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + 6] = wall_clock64();
+    if (ta.nblocks > 0 && threadIdx.x == 0) gh_tau_wait(ta);  // thresholds of this launch: out by now, as a rule
+    if (stamps && ta.nblocks > 0 && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + 7] = wall_clock64();
+    __syncthreads();
+    const int nex = (int)gh_ld_u32(qexact, coh);
+    GH_STAMP(3);
+
+    const int per = (S + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s_begin = (int)blockIdx.y * per, s_end = min(S, s_begin + per);
+    const gh_f16x zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s_lo = s_begin; s_lo < s_end; s_lo += GH_SCAN_QGROUP) {
+        const int nq = min(s_end - s_lo, GH_SCAN_QGROUP);
+        if (s_lo > s_begin) {
+            __syncthreads();  // the previous group's rows are still being read
+            if (hcount >= HITBUF / 4) {  // many query groups: the parked hits leave before the buffer fills
+                gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+                __syncthreads();
+                if (threadIdx.x == 0) hcount = 0;
+            }
+        }
+        gh_stage_queries<QS, QT, NT>(qscan, qt, s_lo, nq, qsh, taush, coh);
+        {
+            const int q = threadIdx.x;  // one query per thread: 32 * KB bytes of A row
+            float4 *dst = reinterpret_cast<float4 *>(qa) + q * (2 * KB);
+            if (q < nq) {
+                const float4 *src = reinterpret_cast<const float4 *>(qA) + (int64_t)(s_lo + q) * (2 * KB);
+#pragma unroll
+                for (int i = 0; i < 2 * KB; ++i) dst[i] = gh_ld_f4(src + i, coh);
+            } else {  // padding row: never passes
+                _Float16 row[16 * KB];
+#pragma unroll
+                for (int k = 0; k < 16 * KB; ++k) row[k] = (_Float16)0.0f;
+                row[gh_mfw<KB>::base + 3] = (_Float16)GH_MF_NEVER;
+#pragma unroll
+                for (int i = 0; i < 2 * KB; ++i) {
+                    gh_h8 hv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hv[e] = row[i * 8 + e];
+                    reinterpret_cast<gh_h8 *>(dst)[i] = hv;
+                }
+            }
+        }
+        __syncthreads();   // staged rows, edge ids, the list of out-of-range references: visible to every thread
+        const int nqb = (nq + 31) / 32;
+        for (int qb = 0; qb < nqb; ++qb) {
+            gh_h8 a[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a[kb] = qa[((qb * 32 + col) * KB + kb) * 2 + hsel];
+            auto tile_of = [&](int b) {
+                gh_f16x f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], B[b][0], zero, 0, 0, 0);
+                if constexpr (KB == 2) f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], B[b][1], f, 0, 0, 0);
+                return f;
+            };
+            gh_f16x f = tile_of(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                gh_f16x fn = zero;
+                if (b + 1 < NB) fn = tile_of(b + 1);   // in the matrix pipe while block b is tested
+                int mn = min(__float_as_int(f[0]), __float_as_int(f[1]));
+#pragma unroll
+                for (int i = 2; i < 16; ++i) mn = min(mn, __float_as_int(f[i]));
+                asm volatile("" : "+v"(mn));
+                if (mn <= 0) {  // rare: result row (i&3) + 8(i>>2) + 4*half, column = this lane's reference
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m = __builtin_amdgcn_alignbit(m, __float_as_uint(f[i]), 31);
+                    const int j = w * (64 * R) + b * 32 + col;
+                    if (j < nedges) {
+                        while (m) {
+                            const int bit = 31 - __builtin_clz(m);
+                            m &= ~(1u << bit);
+                            const int i = 15 - bit;
+                            const int s = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
+                            if (s < nq) park(s_lo, s, j);
+                        }
+                    }
+                }
+                f = fn;
+            }
+        }
+        // outside the f16 range: exact scan of this group's listed queries over the whole tile ...
+        for (int x = 0; x < nex; ++x) {
+            const int s = (int)gh_ld_u32(qexact + 1 + x, coh) - s_lo;
+            if (s < 0 || s >= nq) continue;
+            for (int j = threadIdx.x; j < nedges; j += NT) park(s_lo, s, j);
+        }
+        // ... and of the tile's out-of-range references against every query of the group
+        const int nb_ = nbad;
+        for (int p = threadIdx.x; p < nb_ * nq; p += NT) {
+            const int s = p % nq;
+            const gh_h8 tv = qa[(s * KB + (gh_mfw<KB>::base + 3) / 16) * 2 + ((gh_mfw<KB>::base + 3) % 16) / 8];
+            if ((float)tv[(gh_mfw<KB>::base + 3) % 8] == GH_MF_NEVER) continue;  // a listed query: the loop above has done this pair
+            park(s_lo, s, badlist[p / nq]);
+        }
+    }
+    __syncthreads();
+    GH_STAMP(4);
+    gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+    GH_STAMP(5);
+#undef GH_STAMP
+}
+
 // The thresholds of this iteration: computed by the first workgroups of the fused launch itself (h->tau_embedded), or
 // already in place (knn_tau_kernel ran; nblocks = 0).
 gh_tau_args fused_tau_args(gh_engine *h, int nt) {
@@ -445,6 +635,35 @@ void launch_l(gh_engine *h) {
         h->d_stamps);
 }
 
+template <int D, int LD, bool LONG>
+void launch_mfmaw_l(gh_engine *h) {
+    // few workgroups (a small graph with wide rows): the queries in slices over blockIdx.y, as many as still run all at once
+    unsigned ny = 1;
+    if (h->n_vblocks < 384) {
+        static int resident = 0;  // per instantiation
+        if (resident == 0) {
+            int occ = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spring_scan_mfmaw_kernel<D, LD, LONG>, 256, 0) != hipSuccess) occ = 1;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
+            resident = (occ > 0 ? occ : 1) * (cus > 0 ? cus : 256);
+        }
+        ny = (unsigned)(resident / (h->n_vblocks > 0 ? h->n_vblocks : 1));
+        if (ny > 4) ny = 4;
+        if (ny < 1) ny = 1;
+        if ((int64_t)ny * 64 > h->S) ny = 1;
+    }
+    const gh_tau_args ta = fused_tau_args(h, 256);
+    spring_scan_mfmaw_kernel<D, LD, LONG><<<dim3((unsigned)(h->n_vblocks + ta.nblocks), ny), dim3(256), 0, h->stream>>>(
+        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
+        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, reinterpret_cast<const gh_h8 *>(h->d_qA), h->d_qexact, (int)h->S,
+        h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta, h->d_stamps);
+}
+template <int D, int LD>
+void launch_mfmaw(gh_engine *h) {
+    if (gh_make_long_args(h).n > 0) launch_mfmaw_l<D, LD, true>(h);
+    else launch_mfmaw_l<D, LD, false>(h);
+}
+
 template <int D, int LD, int R, int NT>
 void launch(gh_engine *h) {
     if (gh_make_long_args(h).n > 0) launch_l<D, LD, R, NT, true>(h);
@@ -465,7 +684,22 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
         case 3: launch<3, 4, RR, NTT>(h); break;              \
         default: launch<4, 4, RR, NTT>(h); break;             \
     }
-    if (fused_mfma(h->LD, h->D, h->S) && nt == 256) {
+    if (fused_mfma(h->LD, h->D, h->S) && h->D > 4) {
+        switch (h->D) {
+            case 5: launch_mfmaw<5, 8>(h); break;
+            case 6: launch_mfmaw<6, 8>(h); break;
+            case 7: launch_mfmaw<7, 8>(h); break;
+            case 8: launch_mfmaw<8, 8>(h); break;
+            case 9: launch_mfmaw<9, 16>(h); break;
+            case 10: launch_mfmaw<10, 16>(h); break;
+            case 11: launch_mfmaw<11, 16>(h); break;
+            case 12: launch_mfmaw<12, 16>(h); break;
+            case 13: launch_mfmaw<13, 16>(h); break;
+            case 14: launch_mfmaw<14, 16>(h); break;
+            case 15: launch_mfmaw<15, 16>(h); break;
+            default: launch_mfmaw<16, 16>(h); break;
+        }
+    } else if (fused_mfma(h->LD, h->D, h->S) && nt == 256) {
         if (r == 8) { if (h->D == 2) launch_mfma<2, 8>(h); else launch_mfma<3, 8>(h); }
         else if (r == 4) { if (h->D == 2) launch_mfma<2, 4>(h); else launch_mfma<3, 4>(h); }
         else { if (h->D == 2) launch_mfma<2, 2>(h); else launch_mfma<3, 2>(h); }

@@ -421,8 +421,10 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
     gh_flush_hits<GH_SCAN_HITBUF>(hkey, hq, &hcount, cand, cnt);
 }
 
-// Thresholds as a launch of their own (tau_core.h): one wave per query.
-__global__ __launch_bounds__(64) void knn_tau_kernel(gh_tau_args a) { gh_tau_query_any(a, blockIdx.x, threadIdx.x); }
+// Thresholds as a launch of their own (tau_core.h): one wave per query; one small kernel per register count and row form
+// (the code runs once per CU from a cold instruction cache: what is not executed must not be in the way).
+template <int NV, int FORM>
+__global__ __launch_bounds__(64) void knn_tau_kernel(gh_tau_args a) { gh_tau_query_any<FORM, NV>(a, blockIdx.x, threadIdx.x); }
 
 // One workgroup per query: K smallest of the candidate list; final -> K best keys (and the
 // intersection phase of the query when ia is set), else tighten tau.  A final list that overflowed
@@ -681,6 +683,7 @@ gh_tau_args gh_make_tau_args(gh_engine *h) {
     t.qt = h->d_q;
     t.qscan = h->d_qscan;
     t.qA = reinterpret_cast<_Float16 *>(h->d_qA);
+    t.qA_kb = gh_fused_mfma_kb(h);   // -1: no MFMA form in use
     t.qexact = h->d_qexact;
     t.tcount_reset = h->tcount_reset_pending ? h->d_tcount : nullptr;
     return t;
@@ -689,7 +692,17 @@ gh_tau_args gh_make_tau_args(gh_engine *h) {
 // tau of every query from the group minima the set-up left in d_gmin.  Needs gh_knn_scan_path(h).
 gh_status gh_knn_thresholds(gh_engine *h) {
     gh_scope t(h, "knn_tau");
-    knn_tau_kernel<<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(gh_make_tau_args(h));
+    const gh_tau_args a = gh_make_tau_args(h);
+    const int nv = gh_tau_nv_host(a.Gpad);
+#define GH_TAU_FORM(NVv)                                                                            \
+    switch (a.qA_kb) {                                                                              \
+        case 0: knn_tau_kernel<NVv, 0><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a); break;  \
+        case 1: knn_tau_kernel<NVv, 1><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a); break;  \
+        case 2: knn_tau_kernel<NVv, 2><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a); break;  \
+        default: knn_tau_kernel<NVv, -1><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a); break; \
+    }
+    if (nv == 8) { GH_TAU_FORM(8) } else if (nv == 16) { GH_TAU_FORM(16) } else { GH_TAU_FORM(32) }
+#undef GH_TAU_FORM
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

@@ -255,3 +255,91 @@ __device__ __forceinline__ bool gh_mf_ref_col(const float *mv, bool valid, int h
     }
     return true;
 }
+
+// ---------------------------------------------------------------------------------
+// Wide rows (5 <= D <= 16) on the matrix pipe: the same test F = C0_j - 2 q_s . m_j - T_s <= 0 with every
+// coordinate as ONE f16 piece.  Contraction of 16 * KB (KB = 1 for D <= 10, else 2):
+//     k = 0 .. D-1:            f16(-2 q_d) * f16(m_d)
+//     k = base .. base+2:      1 * (C0_h, C0_m, C0_l)           base = 10 (KB = 1) / 16 (KB = 2)
+//     k = base+3 .. base+5:    (-T_h, -T_m, -T_l) * 1
+// Products of two f16 are exact in the fp32 accumulator; what is lost is the low part of every coordinate:
+//     |a m - f16(a) f16(m)| <= |a| |m - f16(m)| + |a - f16(a)| |f16(m)|,   |x - f16(x)| <= max(2^-11 |x|, 2^-25)
+// (2^-25: half the spacing of f16 subnormals), summed over the coordinates with a = -2q:
+//     <= 2^-10 (1 + 2^-11) (|q|^2 + |m|^2) + 2^-25 (2 |q|_1 + |m|_1) (1 + 2^-11),
+// plus the <= 32 roundings of the accumulation, <= 2^-19 (|q|^2 + 2 |m|^2 + tau), plus the three-piece splits of C0 and
+// T (2^-33 relative, 2^-25 absolute).  Covered with margin by
+//     C0 = |m|^2 (1 - eps) - 2^-24 |m|_1,      T = tau - |q|^2 + eps (|q|^2 + tau) + 2^-23 |q|_1 + 2^-20,
+// eps = 1.25 * 2^-10 (needed: 2^-10 (1 + 2^-11) + 2^-18 = 0.98e-3 on the norms, 2^-18 on tau); the norms are the fp32
+// fma chains (relative error <= 17 * 2^-24, far inside the margin) and the decision is finally taken on the exact chain
+// of the difference form, as in the other forms.  Looser than the split form of D <= 3 by design: a pair passes when its
+// squared distance is within ~2 eps (|q|^2 + |m|^2) of tau -- in 16 dimensions that is 0.04 against thresholds of
+// several units; at D = 6 on a million vertices it lets ~3x the necessary pairs through to the exact check.
+// f16 range: |coordinate| <= GH_MF_RANGE, |m|^2 and |q|^2 <= GH_MFW_NORM_MAX, tau <= GH_MF_TAU_MAX; anything outside is
+// marked never-pass and handled exactly by the caller, as in the split form.
+#define GH_MFW_EPS 1.220703125e-3f
+#define GH_MFW_NORM_MAX 49000.0f
+template <int KB> struct gh_mfw { static constexpr int base = KB == 1 ? 10 : 16; static constexpr int K = 16 * KB; };
+
+// A-operand row of one query: 16 * KB halfs.  q: 16 coordinates (those past D are 0).  false: outside the f16 range
+// (a never-pass row; the caller puts the query on the exact list).
+template <int KB>
+__device__ __forceinline__ bool gh_mfw_query_row(const float *q, float tau, _Float16 *row) {
+    constexpr int base = gh_mfw<KB>::base, ND = KB == 1 ? 10 : 16;
+    bool ok = tau <= GH_MF_TAU_MAX;  // false for inf / NaN too
+    float qn = 0.0f, l1 = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        ok = ok && fabsf(q[d]) <= GH_MF_RANGE;
+        qn = fmaf(q[d], q[d], qn);
+        l1 += fabsf(q[d]);
+    }
+    ok = ok && qn <= GH_MFW_NORM_MAX;
+#pragma unroll
+    for (int k = 0; k < 16 * KB; ++k) row[k] = (_Float16)0.0f;
+    if (!ok) {
+        row[base + 3] = (_Float16)GH_MF_NEVER;
+        return false;
+    }
+#pragma unroll
+    for (int d = 0; d < ND; ++d) row[d] = (_Float16)(-2.0f * q[d]);
+    row[base] = row[base + 1] = row[base + 2] = (_Float16)1.0f;
+    const float T = (tau - qn) + (GH_MFW_EPS * (qn + tau) + (1.1920928955078125e-07f * l1 + GH_MF_ABS));
+    gh_split3(-T, row[base + 3], row[base + 4], row[base + 5]);
+    return true;
+}
+
+// B-operand column of one reference: for each of the KB blocks of 16 the 8 halfs of lane half hsel.
+// mv: LD >= D floats (pad 0).  valid = false: padding slot.  false: a real reference outside the f16 range (never passes
+// here; the caller scans it exactly).
+template <int D, int KB>
+__device__ __forceinline__ bool gh_mfw_ref_col(const float *mv, bool valid, int hsel, gh_h8 (&col)[KB]) {
+    constexpr int base = gh_mfw<KB>::base;
+    static_assert(D <= (KB == 1 ? 10 : 16), "contraction too short for this dimension");
+    bool ok = true;
+    float c0 = 0.0f, l1 = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        ok = ok && fabsf(mv[d]) <= GH_MF_RANGE;
+        c0 = fmaf(mv[d], mv[d], c0);
+        l1 += fabsf(mv[d]);
+    }
+    ok = ok && c0 <= GH_MFW_NORM_MAX;
+    _Float16 row[16 * KB];
+#pragma unroll
+    for (int k = 0; k < 16 * KB; ++k) row[k] = (_Float16)0.0f;
+    row[base + 3] = row[base + 4] = row[base + 5] = (_Float16)1.0f;   // also on a never-pass column: a never-pass row then yields NEVER, not 0
+    if (!valid || !ok) {
+        row[base] = (_Float16)GH_MF_NEVER;   // C0_h: beats every in-range -T
+    } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) row[d] = (_Float16)mv[d];
+        const float c = fmaf(-GH_MFW_EPS, c0, c0) - 5.9604644775390625e-08f * l1;
+        gh_split3(c, row[base], row[base + 1], row[base + 2]);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) col[kb][i] = hsel ? row[kb * 16 + 8 + i] : row[kb * 16 + i];
+    }
+    return ok || !valid;
+}

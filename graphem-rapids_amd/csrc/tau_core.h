@@ -13,7 +13,8 @@ struct gh_tau_args {
     int64_t Gpad;
     int D, QS, QT, K, S;
     float *qt, *qscan;        // query records (coordinates, tau) and pre-filter records (-2q, t)
-    _Float16 *qA;             // operand rows of the MFMA form of the filter, or null
+    _Float16 *qA;             // operand rows of the MFMA forms of the filter, or null
+    int qA_kb;                // host side: which row form knn_tau_kernel writes (-1 none, 0 split form of D <= 3, 1 / 2 wide form)
     int32_t *qexact;          // [0] = count, then the queries outside the f16 range of that filter
     int32_t *tcount_reset;    // the touched-list counter to reset (set-up ran inside the previous normalise launch), or null
     // -- inside the fused launch only
@@ -23,21 +24,45 @@ struct gh_tau_args {
     int32_t *wait_failed;     // set when a consumer gave up waiting (cannot happen while workgroups start in index order)
 };
 
+// Operand row of the wide MFMA form (the layout and the bounds of scan_core.h gh_mfw_query_row, which states them): 16 * KB
+// halfs, lane k < 8 * KB stores elements 2k, 2k+1.  Every lane builds just its own two elements -- lane d holds
+// coordinate d, the norms come from the caller's loop: this code runs once per CU from a cold instruction cache, and a
+// row built in full by every lane (400 instructions) took longer to fetch than to execute.
+template <int KB, class ST>
+__device__ __forceinline__ void gh_tau_wide_row(const gh_tau_args &a, int64_t qi, int lane, float qcoord, float qn, float l1,
+                                                float tau, ST st) {
+    constexpr int base = gh_mfw<KB>::base, ND = KB == 1 ? 10 : 16;
+    const bool in_range = __ballot(fabsf(qcoord) > GH_MF_RANGE) == 0ull;
+    const bool ok = tau <= GH_MF_TAU_MAX && in_range && qn <= GH_MFW_NORM_MAX;   // false for inf / NaN thresholds too
+    if (lane == 0 && !ok) st(&a.qexact[1 + atomicAdd(&a.qexact[0], 1)], (uint32_t)qi);
+    const float T = (tau - qn) + (GH_MFW_EPS * (qn + tau) + (1.1920928955078125e-07f * l1 + GH_MF_ABS));
+    _Float16 th, tm, tl;
+    gh_split3(-T, th, tm, tl);
+    const int k0 = 2 * lane;
+    const float c0 = __shfl(qcoord, k0 & 63, 64), c1 = __shfl(qcoord, (k0 + 1) & 63, 64);   // coordinates past D are 0
+    auto elem = [&](int k, float c) {
+        const _Float16 one = (_Float16)1.0f, zero = (_Float16)0.0f;
+        if (!ok) return k == base + 3 ? (_Float16)GH_MF_NEVER : zero;
+        _Float16 e = k < ND ? (_Float16)(-2.0f * c) : zero;
+        e = (k >= base && k < base + 3) ? one : e;
+        e = k == base + 3 ? th : e;
+        e = k == base + 4 ? tm : e;
+        e = k == base + 5 ? tl : e;
+        return e;
+    };
+    const uint32_t pk = (uint32_t)__builtin_bit_cast(uint16_t, elem(k0, c0)) | ((uint32_t)__builtin_bit_cast(uint16_t, elem(k0 + 1, c1)) << 16);
+    if (lane < 8 * KB) st(reinterpret_cast<uint32_t *>(a.qA + qi * (16 * KB)) + lane, pk);
+}
+
 // One wave, one query: the minima sit NV per lane in
 // registers (more than 64 * NV groups: folded by min, which only makes groups coarser), K rounds of a
 // wave-wide minimum retire the smallest value each (equal values retire together: the bound can only
 // get looser).  Then the pre-filter records of the scan (scan_core.h).
 template <int NV>
-__device__ __forceinline__ void gh_tau_query(const gh_tau_args &a, int64_t qi, int lane, unsigned long long *st8 = nullptr) {
-    const int D = a.D, QS = a.QS, QT = a.QT, K = a.K;
+__device__ __forceinline__ uint32_t gh_tau_kth(const gh_tau_args &a, int64_t qi, int lane, unsigned long long *st8 = nullptr) {
+    const int K = a.K;
     const int64_t G = a.Gpad;
-    // set-up done inside the previous normalise launch: the touched-list counter is reset here instead
-    if (a.tcount_reset && qi == 0 && lane == 0) *a.tcount_reset = 0;
     const uint32_t *row = a.gmin + qi * a.Gpad;
-    // lane d holds coordinate d (issued with the loads below; past the L1 inside the fused launch: no CU may hold a copy of
-    // a record line from before its threshold was stored)
-    // (always the sc1 form: with a plain-load alternative the compiler waits for this load before it issues the others)
-    const float qcoord = lane < D ? gh_ld_f32(&a.qt[qi * QS + lane], true) : 0.0f;
     uint32_t v[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = 0x7F800000u;
@@ -56,6 +81,19 @@ __device__ __forceinline__ void gh_tau_query(const gh_tau_args &a, int64_t qi, i
     uint32_t kth = 0x7F800000u;
     int need = K;
     if (st8 && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st8[1] = wall_clock64(); }
+    if (K >= 24) {
+        // many neighbours: the same order statistic bit by bit from the top -- 31 rounds of NV compares and ballots whatever
+        // K is, against K rounds of a wave minimum (k = 32: 6.7 -> 2.5 us); values are non-negative float bits
+        uint32_t prefix = 0;
+        for (int bit = 30; bit >= 0; --bit) {
+            const uint32_t t = prefix | (1u << bit);
+            int below = 0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) below += __popcll(__ballot(v[j] < t));
+            if (below < K) prefix = t;   // fewer than K values under t: the K-th smallest has this bit
+        }
+        return prefix;
+    }
     while (need > 0) {
         uint32_t m = v[0];
 #pragma unroll
@@ -77,14 +115,27 @@ __device__ __forceinline__ void gh_tau_query(const gh_tau_args &a, int64_t qi, i
             need -= __popcll(b);
         }
     }
+    return kth;
+}
+
+// The records of one query from its threshold: tau into the query record, the pre-filter record (-2q, t) of the
+// packed-VALU scan and, FORM >= 0, the operand row of an MFMA form (0: split f16, D <= 3; 1 / 2: wide, 16 / 32 deep).
+// FORM is a compile-time constant on purpose: this code runs once per CU from a cold instruction cache -- with the three
+// row forms and the three register counts of gh_tau_kth inlined into one another (9 copies, 3200 instructions, taken
+// branches over all but one) knn_tau_kernel went from 7.9 to 34 us and the producers inside the fused launch from 11 to 27.
+template <int FORM>
+__device__ __forceinline__ void gh_tau_records(const gh_tau_args &a, int64_t qi, int lane, float qcoord, uint32_t kth,
+                                               unsigned long long *st8 = nullptr) {
+    const int D = a.D, QS = a.QS, QT = a.QT;
     const float tau = __uint_as_float(kth);
     if (st8 && lane == 0) st8[2] = wall_clock64();
     float qs[16];
-    float qn = 0.0f;
+    float qn = 0.0f, l1 = 0.0f;
 #pragma unroll
     for (int d = 0; d < 16; ++d) {   // every lane gets all coordinates (coordinates past D are 0: fma(0, 0, s) == s)
         qs[d] = __shfl(qcoord, d, 64);
         qn = fmaf(qs[d], qs[d], qn);
+        if constexpr (FORM == 1 || FORM == 2) l1 += fabsf(qs[d]);
     }
     // scan record of the pre-filter (scan_core.h): (-2q, t),  t = tau - |q|^2 + eps*(2|q|^2 + tau)
     // Inside the fused launch every result leaves as an agent-scope atomic store (global_store ... sc1: written through,
@@ -102,7 +153,7 @@ __device__ __forceinline__ void gh_tau_query(const gh_tau_args &a, int64_t qi, i
         // MFMA form of the filter tests sign bits)
         st(&a.qscan[qi * QS + QT], __float_as_uint(fmaf(eps, fmaf(2.0f, qn, tau), tau - qn) + 1e-30f));
     }
-    if (a.qA && D <= 3) {  // operand row of the MFMA form of the filter (scan_core.h): lane k < 8 stores elements 2k, 2k+1
+    if constexpr (FORM == 0) {  // operand row of the split-f16 MFMA form (scan_core.h): lane k < 8 stores elements 2k, 2k+1
         _Float16 rowh[16];
         const bool ok = gh_mf_query_row(qs, D, tau, rowh);
         if (lane == 0 && !ok) st(&a.qexact[1 + atomicAdd(&a.qexact[0], 1)], (uint32_t)qi);
@@ -113,15 +164,33 @@ __device__ __forceinline__ void gh_tau_query(const gh_tau_args &a, int64_t qi, i
             mine = lane == k ? pk : mine;
         }
         if (lane < 8) st(reinterpret_cast<uint32_t *>(a.qA + qi * 16) + lane, mine);
+    } else if constexpr (FORM == 1 || FORM == 2) {
+        gh_tau_wide_row<FORM>(a, qi, lane, qcoord, qn, l1, tau, st);
     }
 }
 
-// Registers per lane for the group minima: the selection rounds rescan them all.
+// One query by one wave.  Registers per lane for the group minima: the selection rounds rescan them all
+// (a few groups past 64 * NV fold onto the first lanes by min: coarser groups, a valid and barely looser bound).
+__device__ __forceinline__ int gh_tau_nv(int64_t Gpad) { return Gpad <= 64 * 8 + 64 ? 8 : Gpad <= 64 * 16 + 256 ? 16 : 32; }
+__host__ inline int gh_tau_nv_host(int64_t Gpad) { return Gpad <= 64 * 8 + 64 ? 8 : Gpad <= 64 * 16 + 256 ? 16 : 32; }
+template <int FORM, int NVFIX = 0 /* 0: chosen at run time */>
 __device__ __forceinline__ void gh_tau_query_any(const gh_tau_args &a, int64_t qi, int lane, unsigned long long *st8 = nullptr) {
-    // (a few groups past 64 * NV fold onto the first lanes by min: coarser groups, a valid and barely looser bound)
-    if (a.Gpad <= 64 * 8 + 64) gh_tau_query<8>(a, qi, lane, st8);
-    else if (a.Gpad <= 64 * 16 + 256) gh_tau_query<16>(a, qi, lane, st8);
-    else gh_tau_query<32>(a, qi, lane, st8);
+    // set-up done inside the previous normalise launch: the touched-list counter is reset here instead
+    if (a.tcount_reset && qi == 0 && lane == 0) *a.tcount_reset = 0;
+    // lane d holds coordinate d (issued with the loads of gh_tau_kth; always the sc1 form -- past the L1: inside the fused
+    // launch no CU may hold a copy of a record line from before its threshold was stored, and with a plain-load
+    // alternative the compiler waits for this load before it issues the others)
+    const float qcoord = lane < a.D ? gh_ld_f32(&a.qt[qi * a.QS + lane], true) : 0.0f;
+    uint32_t kth;
+    if constexpr (NVFIX != 0) {
+        kth = gh_tau_kth<NVFIX>(a, qi, lane, st8);
+    } else {
+        const int nv = gh_tau_nv(a.Gpad);
+        if (nv == 8) kth = gh_tau_kth<8>(a, qi, lane, st8);
+        else if (nv == 16) kth = gh_tau_kth<16>(a, qi, lane, st8);
+        else kth = gh_tau_kth<32>(a, qi, lane, st8);
+    }
+    gh_tau_records<FORM>(a, qi, lane, qcoord, kth, st8);
 }
 
 // ---- thresholds inside the fused launch ---------------------------------------------------------------------------
@@ -137,14 +206,14 @@ __device__ __forceinline__ void gh_tau_query_any(const gh_tau_args &a, int64_t q
 // this protocol with stale copies planted (0 stale values in 200 launches x 8192 consumers).  The wait cannot deadlock while workgroups are started in index
 // order (the producers are the first of the grid and wait for nobody); it is bounded all the same: a consumer that
 // gives up sets *wait_failed, which the host reports at the next synchronisation instead of results.
-template <int NT>
+template <int NT, int FORM>
 __device__ __forceinline__ void gh_tau_produce(const gh_tau_args &a, unsigned long long *st8 = nullptr /* diagnostic: this workgroup's 8 stamps */) {
     const int lane = threadIdx.x & 63;
     const int64_t qi = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     if (qi >= a.S) return;
     if (threadIdx.x >= 64) st8 = nullptr;
     if (st8 && lane == 0) st8[0] = wall_clock64();
-    gh_tau_query_any(a, qi, lane, st8);
+    gh_tau_query_any<FORM>(a, qi, lane, st8);
     if (st8 && lane == 0) st8[3] = wall_clock64();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left before the counter moves
     if (st8 && lane == 0) st8[4] = wall_clock64();

@@ -536,11 +536,24 @@ def _fused_step_keys(n, D, edges, pos, sampled, k):
     (5000, 3, 8, "all"),         # every coordinate outside it: exact scans only
     (50000, 3, 8, "tiny"),       # coordinates ~1e-4: distances near the absolute slack of the filter
     (60000, 3, 8, "S1100"),      # 1100 queries: several query groups, the last one ragged (MFMA is the default form here)
+    # wide rows: one f16 piece per coordinate, contraction 16 deep (D <= 10) or 32 deep
+    (30000, 5, 8, "none"),
+    (30000, 8, 8, "none"),
+    (30000, 8, 8, "some"),
+    (30000, 10, 8, "none"),      # 16-deep contraction on 16-float rows
+    (30000, 11, 8, "none"),      # 32-deep
+    (30000, 16, 8, "none"),
+    (30000, 16, 8, "some"),
+    (5000, 16, 8, "all"),
+    (30000, 6, 8, "tiny"),       # coordinates ~1e-4: f16 subnormals, the absolute slack of the wide form
+    (30000, 12, 8, "S1100"),
+    (4000, 16, 44, "none"),      # C5 shape: few long workgroups, query slices over blockIdx.y, every row on the long path
 ])
 def test_fused_scan_knn_is_exact(form, n, D, deg, outliers, monkeypatch):
     """KNN of the fused spring+scan kernel (read back after gh_step_begin) against the oracle, for
-    both forms of its pre-filter: split-f16 MFMA (default for D <= 3) and packed fp32 VALU.  The
-    filter is conservative and the decision exact, so ids AND distance bits must be identical."""
+    both forms of its pre-filter: f16 MFMA (split operands for D <= 3, single-piece operands for D >= 5:
+    the default) and packed fp32 VALU.  The filter is conservative and the decision exact, so ids AND
+    distance bits must be identical."""
     monkeypatch.setenv("GRAPHEM_HIP_MFMA", "1" if form == "mfma" else "0")
     k, S = 10, (1100 if outliers == "S1100" else 256)
     edges, pos, sampled = _random_case(n, D, deg, k, S, seed=101)

@@ -8,6 +8,9 @@ import numpy as np, bench
 from graphem_rapids_amd import _native
 wl = sys.argv[1] if len(sys.argv) > 1 else "rr1m"
 n, D, k, S, edges, pos = bench.make_workload(wl)
+if os.environ.get("GRAPHEM_PROBE_DIM"):   # another number of components on the same graph
+    D = int(os.environ["GRAPHEM_PROBE_DIM"])
+    pos = (np.random.default_rng(0).standard_normal((n, D)) * 0.1).astype(np.float32)
 eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S)
 eng.set_positions(pos)
 eng.run(8)
