@@ -534,6 +534,9 @@ __global__ __launch_bounds__(256) void integrate_given_kernel(const float *__res
 //   k_inter * (x - c) / (|x - c| + 1e-6)^2,   c = (((p1 + p2) + q1) + q2) / 4
 // (pt.py:722-734).  Contributions are summed in fp64 atomics: with the handful of terms
 // a vertex receives the fp64 sum is exact, hence independent of arrival order.
+// DT: the dimension at compile time (2..16) or 0 = any (the scratch form); one small kernel per dimension instead of one
+// with all fifteen inlined behind a switch (14 000 instructions fetched through a cold instruction cache).
+template <int DT>
 __global__ __launch_bounds__(256) void intersect_kernel(const float *__restrict__ pos, int D, int LD,
                                                        const int32_t *__restrict__ edges,
                                                        const int32_t *__restrict__ sampled,
@@ -546,7 +549,10 @@ __global__ __launch_bounds__(256) void intersect_kernel(const float *__restrict_
     const int64_t r = t / k;
     // neighbour c of query r is key column c+1: column 0 is dropped blindly (pt.py:421)
     const int32_t i = sampled[r], j = (int32_t)gh_key_id(keys[r * (k + 1) + (t - r * k) + 1]);
-    gh_intersect_pair_any(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, scratch + t * LD);
+    if constexpr (DT >= 2)
+        gh_intersect_pair_t<DT, (DT <= 4 ? 4 : DT <= 8 ? 8 : 16)>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount);
+    else
+        gh_intersect_pair(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, scratch + t * LD);
 }
 
 // acc (double) -> dense fp32 F for the touched vertices (per-phase entry point).
@@ -767,9 +773,20 @@ gh_status gh_launch_intersect(gh_engine *h) {
     const int64_t P = h->S * h->k;
     if (P == 0) return GH_OK;
     gh_scope t(h, "intersect");
-    intersect_kernel<<<dim3(grid_for(P, 256)), dim3(256), 0, h->stream>>>(
-        h->d_pos, h->D, h->LD, h->d_edges, h->d_sampled_cur, h->d_keys_cur, h->S, h->k, h->prm.k_inter, h->d_acc,
-        h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch);
+#define GH_INTER_ONE(DD, LL)                                                                                       \
+    case DD:                                                                                                       \
+        intersect_kernel<DD><<<dim3(grid_for(P, 256)), dim3(256), 0, h->stream>>>(                                   \
+            h->d_pos, h->D, h->LD, h->d_edges, h->d_sampled_cur, h->d_keys_cur, h->S, h->k, h->prm.k_inter, h->d_acc, \
+            h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch);                                                 \
+        break;
+    switch (h->D) {
+        GH_FOR_EACH_DIM(GH_INTER_ONE)
+        default:
+            intersect_kernel<0><<<dim3(grid_for(P, 256)), dim3(256), 0, h->stream>>>(
+                h->d_pos, h->D, h->LD, h->d_edges, h->d_sampled_cur, h->d_keys_cur, h->S, h->k, h->prm.k_inter, h->d_acc,
+                h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch);
+    }
+#undef GH_INTER_ONE
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

@@ -44,23 +44,40 @@ struct inter_args {
 };
 
 // Whole workgroup; best[] in LDS, visible to all threads (the callers' extraction ends with a barrier).
+// DT: the number of components as a compile-time constant (2..16), or 0 = whatever ia.D says.  The kernels that end with
+// this are instantiated per dimension: with all fifteen wide instantiations inlined behind a switch they were 28 000
+// instructions each, and a workgroup that runs once per launch fetches its path through them from a cold instruction
+// cache (see tau_core.h for what that cost the threshold kernel).
+template <int DT>
 __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi, const uint64_t *best, gh_pair_list *pl) {
-    if (ia.LD <= 16 && ia.k <= 127 && blockDim.x % (4 * ia.LD) == 0 && ia.D >= 2 && ia.D <= 16) {   // lanes = (role, coordinate)
-        const int32_t i = ia.sampled[qi];
-#define GH_WIDE_ONE(DD, LL)                                                                                              \
-    case DD:                                                                                                             \
-        gh_intersect_query_wide<DD, LL>(ia.pos, ia.edges, i, best, ia.k, ia.k_inter, ia.acc, ia.tflag, ia.touched,     \
-                                        ia.tcount, pl);                                                                  \
-        break;
-        switch (ia.D) { GH_FOR_EACH_DIM(GH_WIDE_ONE) default: break; }
-#undef GH_WIDE_ONE
-        return;
+    if constexpr (DT >= 2) {
+        constexpr int LL = DT <= 4 ? 4 : DT <= 8 ? 8 : 16;
+        if (ia.k <= 127 && blockDim.x % (4 * LL) == 0) {   // lanes = (role, coordinate)
+            gh_intersect_query_wide<DT, LL>(ia.pos, ia.edges, ia.sampled[qi], best, ia.k, ia.k_inter, ia.acc, ia.tflag, ia.touched,
+                                            ia.tcount, pl);
+            return;
+        }
     }
     // neighbour c of the query is key column c+1: column 0 is dropped blindly (pt.py:421)
-    for (int c = threadIdx.x; c < ia.k; c += blockDim.x)
-        gh_intersect_pair_any(ia.pos, ia.D, ia.LD, ia.edges, ia.sampled[qi], (int32_t)gh_key_id(best[c + 1]), ia.k_inter,
-                          ia.acc, ia.tflag, ia.touched, ia.tcount, ia.scratch + (qi * ia.k + c) * ia.LD);
+    for (int c = threadIdx.x; c < ia.k; c += blockDim.x) {
+        const int32_t j = (int32_t)gh_key_id(best[c + 1]);
+        if constexpr (DT >= 2)
+            gh_intersect_pair_t<DT, (DT <= 4 ? 4 : DT <= 8 ? 8 : 16)>(ia.pos, ia.edges, ia.sampled[qi], j, ia.k_inter, ia.acc, ia.tflag,
+                                                                     ia.touched, ia.tcount);
+        else
+            gh_intersect_pair(ia.pos, ia.D, ia.LD, ia.edges, ia.sampled[qi], j, ia.k_inter, ia.acc, ia.tflag, ia.touched, ia.tcount,
+                              ia.scratch + (qi * ia.k + c) * ia.LD);
+    }
 }
+// host side: run X<DT> for the engine's dimension (0 past 16)
+#define GH_DISPATCH_DIM(Dval, X)                                                      \
+    switch (Dval) {                                                                   \
+        case 2: X(2); break;  case 3: X(3); break;  case 4: X(4); break;  case 5: X(5); break;    \
+        case 6: X(6); break;  case 7: X(7); break;  case 8: X(8); break;  case 9: X(9); break;    \
+        case 10: X(10); break; case 11: X(11); break; case 12: X(12); break; case 13: X(13); break; \
+        case 14: X(14); break; case 15: X(15); break; case 16: X(16); break;                        \
+        default: X(0); break;                                                         \
+    }
 
 // ---------------------------------------------------------------------------------
 // One launch sets a KNN search up from the CURRENT positions (setup_core.h): sample ids, query
@@ -133,7 +150,7 @@ __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 // unique (the id is part of the key), so the owner of a round's minimum retires it by equality
 // -- and the survivors are ranked by counting.  wsc: (NT/64) * GH_EXTRACT_MAX_K keys of LDS scratch.
 template <int NPT, int NT = 256>
-__device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *out, uint64_t *wsc) {
+__device__ __forceinline__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *out, uint64_t *wsc) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int r = 0; r < K; ++r) {
         uint64_t m = keys[0];
@@ -170,7 +187,7 @@ __device__ void block_extract_smallest(uint64_t (&keys)[NPT], int K, uint64_t *o
 // LDS copy.  The wave-minimum rounds above cost ~100 instructions per extracted key and run K times in a row: at
 // K = 33 (n_neighbors = 32) that was 8 us of a select launch; counting costs c/2 LDS reads whatever K is.
 template <int NT = 256>
-__device__ void block_rank_smallest(const uint64_t *src, int c, int K, uint64_t *out, uint64_t *stage /* >= 2 * NT keys */) {
+__device__ __forceinline__ void block_rank_smallest(const uint64_t *src, int c, int K, uint64_t *out, uint64_t *stage /* >= 2 * NT keys */) {
     uint64_t mine[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -193,8 +210,10 @@ __device__ void block_rank_smallest(const uint64_t *src, int c, int K, uint64_t 
     __syncthreads();
 }
 
+// (forced inline, like the others here: once the kernels were instantiated per dimension the compiler stopped inlining
+// this one, and the call -- 246 VGPRs for the callee's worst case -- cost the k = 32 selection 4.6 us)
 template <int MAXNPT, int NT = 256>
-__device__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64_t *out, uint64_t *red) {
+__device__ __forceinline__ void block_extract_adaptive(const uint64_t *src, int c, int K, uint64_t *out, uint64_t *red) {
     if (K > 16 && c <= 2 * NT && 2 * NT <= (NT / 64) * GH_EXTRACT_MAX_K) {   // red holds (NT/64) * GH_EXTRACT_MAX_K keys
         block_rank_smallest<NT>(src, c, K, out, red);
         return;
@@ -235,7 +254,7 @@ struct search_args {  // what the exact per-query search reads
 };
 
 // best[0..K) <- the K smallest keys of query qi; qs: LD floats of LDS, red: extraction scratch.
-__device__ void block_search_query(const search_args &a, int64_t qi, int K, float *qs, uint64_t *best, uint64_t *red) {
+__device__ __forceinline__ void block_search_query(const search_args &a, int64_t qi, int K, float *qs, uint64_t *best, uint64_t *red) {
     const float *__restrict__ mid = a.mid, *__restrict__ pos = a.pos, *__restrict__ qt = a.qt;
     const int32_t *__restrict__ edges = a.edges, *__restrict__ eids = a.eids;
     const int LD = a.LD, D = a.D, QS = a.QS;
@@ -282,6 +301,7 @@ __device__ void block_search_query(const search_args &a, int64_t qi, int K, floa
     }
 }
 
+template <int DT>
 __global__ __launch_bounds__(256) void knn_block_select_kernel(search_args a, int K,
                                                                const int32_t *__restrict__ only_flagged,
                                                                uint64_t *__restrict__ out_keys /* (S, K) or null */,
@@ -298,7 +318,7 @@ __global__ __launch_bounds__(256) void knn_block_select_kernel(search_args a, in
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
     if (tau_out && threadIdx.x == 0) tau_out[qi * a.QS] = best[K - 1] != GH_KEY_INF ? gh_key_d2(best[K - 1]) : INFINITY;
     __shared__ gh_pair_list pairs;
-    if (ia.pos) intersect_query(ia, qi, best, &pairs);
+    if (ia.pos) intersect_query<DT>(ia, qi, best, &pairs);
 }
 
 // The same selection for large K (> GH_EXTRACT_MAX_K): running threshold + LDS compaction +
@@ -430,6 +450,7 @@ __global__ __launch_bounds__(64) void knn_tau_kernel(gh_tau_args a) { gh_tau_que
 // intersection phase of the query when ia is set), else tighten tau.  A final list that overflowed
 // is not trustworthy: that query is searched exactly over all own edges right here (fb), which is
 // rare (thousands of edges within tau: tied distances) and slow, but needs no further launch.
+template <int DT>
 __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ cand, int32_t *__restrict__ cnt,
                                                          int K, int final_level, float *__restrict__ tau, int QS,
                                                          uint64_t *__restrict__ out_keys,
@@ -470,7 +491,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     const int c = cnt[qi * GH_CNT_STRIDE];
     __syncthreads();
     if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; }
-    if (c > GH_CAND_CAP || c < K) {
+    if (__builtin_expect(c > GH_CAND_CAP || c < K, 0)) {   // (cold: laid out behind the usual path)
         if (!final_level) return;  // tau keeps its previous (still valid, looser) value
         if (threadIdx.x == 0) ovf[qi] = 1;
         block_search_query(fb, qi, K, qs, best, red);
@@ -484,7 +505,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     if (final_level) {
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];
         __shared__ gh_pair_list pairs;
-        if (ia.pos) intersect_query(ia, qi, best, &pairs);
+        if (ia.pos) intersect_query<DT>(ia, qi, best, &pairs);
     } else if (threadIdx.x == 0) {
         tau[qi * QS] = gh_key_d2(best[K - 1]);
     }
@@ -493,6 +514,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
 // Merge the per-rank key lists (world, S, K) into the K globally best keys per query (S, K).
 // Only launched for world > 1; the intersection phase reads keys and drops column 0 itself
 // (pt.py:421: knn_indices[:, 1:]).
+template <int DT>
 __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restrict__ gathered, int world, int64_t S,
                                                         int K, uint64_t *__restrict__ merged, inter_args ia) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -512,7 +534,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t *__restri
     block_sort(buf, n2);
     for (int c = threadIdx.x; c < K; c += blockDim.x) merged[qi * K + c] = buf[c];
     __shared__ gh_pair_list pairs;
-    if (ia.pos) intersect_query(ia, qi, buf, &pairs);  // the k candidate pairs of this query, same launch (pt.py:638-774)
+    if (ia.pos) intersect_query<DT>(ia, qi, buf, &pairs);  // the k candidate pairs of this query, same launch (pt.py:638-774)
 }
 
 template <int D, int R>
@@ -564,9 +586,12 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
     const int QS = gh_qs(h->D, h->LD);
     float *tau_out = write_tau ? h->d_q + gh_qtau(h->D, h->LD) : nullptr;
     if (h->K <= GH_EXTRACT_MAX_K) {
-        knn_block_select_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
-            make_search_args(h, mid, M, mem_stride, id_stride), h->K, only_flagged, out_keys, tau_out,
-            make_inter_args(h, with_intersect));
+#define GH_BSEL(DD)                                                                                             \
+    knn_block_select_kernel<DD><<<dim3((unsigned)h->S), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(       \
+        make_search_args(h, mid, M, mem_stride, id_stride), h->K, only_flagged, out_keys, tau_out,                     \
+        make_inter_args(h, with_intersect))
+        if (with_intersect) { GH_DISPATCH_DIM(h->D, GH_BSEL) } else { GH_BSEL(0); }   // (no intersection phase: nothing depends on the dimension at compile time)
+#undef GH_BSEL
     } else {
         const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)h->LD;
         knn_block_select_sort_kernel<<<dim3((unsigned)h->S), dim3(256), smem, h->stream>>>(
@@ -608,11 +633,14 @@ gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect, con
     // the column sums of the fused kernel's workgroup partials ride along (stats_fix_kernel then skips them)
     const bool reduce = final_level && h->new0_ready && h->rows > 0 && h->LD <= 16;
     gh_scope t(h, with_intersect ? "knn_select_intersect" : "knn_select");
-    knn_select_kernel<<<dim3((unsigned)h->S + (reduce ? 2u * (unsigned)h->LD : 0u)), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>(
-        h->d_cand, h->d_cnt, h->K, final_level ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), gh_qs(h->D, h->LD),
-        h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S,
-        make_search_args(h, fb_mid, h->own_count, 1, 1), make_inter_args(h, with_intersect), (int)h->S,
-        h->d_blockstats, h->n_vblocks, h->d_stats);
+#define GH_SEL(DD)                                                                                                                          \
+    knn_select_kernel<DD><<<dim3((unsigned)h->S + (reduce ? 2u * (unsigned)h->LD : 0u)), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>( \
+        h->d_cand, h->d_cnt, h->K, final_level ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), gh_qs(h->D, h->LD),                                     \
+        h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S,                                                           \
+        make_search_args(h, fb_mid, h->own_count, 1, 1), make_inter_args(h, with_intersect), (int)h->S,                                        \
+        h->d_blockstats, h->n_vblocks, h->d_stats)
+    if (with_intersect) { GH_DISPATCH_DIM(h->D, GH_SEL) } else { GH_SEL(0); }
+#undef GH_SEL
     GH_LAUNCH_CHECK();
     h->stats_reduced = reduce;
     return GH_OK;
@@ -753,8 +781,11 @@ gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {
         return GH_ERR_INVALID;
     }
     gh_scope t(h, "knn_merge_intersect");
-    knn_merge_kernel<<<dim3((unsigned)h->S), dim3(256), sizeof(uint64_t) * (size_t)n2, h->stream>>>(
-        gathered, world, h->S, h->K, h->d_merged, make_inter_args(h, !h->intersect_done));
+#define GH_MERGE(DD)                                                                                      \
+    knn_merge_kernel<DD><<<dim3((unsigned)h->S), dim3(256), sizeof(uint64_t) * (size_t)n2, h->stream>>>(      \
+        gathered, world, h->S, h->K, h->d_merged, make_inter_args(h, !h->intersect_done))
+    if (!h->intersect_done) { GH_DISPATCH_DIM(h->D, GH_MERGE) } else { GH_MERGE(0); }
+#undef GH_MERGE
     GH_LAUNCH_CHECK();
     h->d_keys_cur = h->d_merged;
     h->intersect_done = true;
@@ -839,7 +870,7 @@ gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq,
     if (nq == 0) return GH_OK;
     inter_args none{};
     if (K <= GH_EXTRACT_MAX_K) {
-        knn_block_select_kernel<<<dim3((unsigned)nq), dim3(256), sizeof(float) * (size_t)D, stream>>>(
+        knn_block_select_kernel<0><<<dim3((unsigned)nq), dim3(256), sizeof(float) * (size_t)D, stream>>>(
             search_args{d_ref, nullptr, nullptr, nullptr, D, D, 0, nref, 1, 1, d_q, D}, K, nullptr, d_keys, nullptr, none);
     } else {
         const size_t smem = sizeof(uint64_t) * GH_SEL_BUF + sizeof(float) * (size_t)D;
