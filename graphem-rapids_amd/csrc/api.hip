@@ -427,10 +427,10 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     // 64.9 -> 60.6 us).  A large graph gains nothing (1 M vertices: 175.7 -> 176.7 us, the first round of workgroups waits
     // ~3 us for producers that share their CUs with gathers) and keeps the launch of its own.
     // GRAPHEM_HIP_TAU_SEPARATE=1 / 0 forces either form.
-    // Wide rows (D >= 5) always: their spring phase is long enough to cover the producers (7.5 + 3 us against 11 us), and
-    // the stand-alone kernel is slow behind the 32 - 64 MB normalise launch of such rows (33 us at 1 M vertices, D = 6,
-    // against 8 at D = 3; the same code inside the fused launch is done after 11 us).
-    h->tau_embedded = h->n_vblocks <= 2048 || h->D >= 5;
+    // The wide MFMA form (D >= 4) always: its spring phase is long enough to cover the producers (7.5 + 3 us against 11 us),
+    // and knn_tau_kernel with the wide operand row takes 23 - 33 us as a launch of its own (8 us without the row, 11 us for
+    // the same code inside the fused launch; not understood).
+    h->tau_embedded = h->n_vblocks <= 2048 || h->D >= 4;
     if (const char *e = getenv("GRAPHEM_HIP_TAU_SEPARATE")) h->tau_embedded = atoi(e) == 0;
     if (getenv("GRAPHEM_HIP_STAMPS")) GH_A2(d_stamps, ((size_t)std::max(h->n_vblocks, 1) + GH_STAMP_EXTRA) * 8);
     if (h->thr_M1 > 0) {  // endpoints of the threshold subset: every thr_stride-th own edge

@@ -32,11 +32,12 @@
 // phase's gathers a wave of occupancy, and wins all the same: 1M vertices, 256 queries: 4410 vs 4300
 // it/s over the first 55 iterations and 4700 vs 4440 in the steady state of a long run
 // (tools/soak_s.py); 100K vertices 10760 vs 9730; 1024 queries 433 vs 566 us per iteration, 4096
-// queries 640 vs 1434 us for the kernel.  GRAPHEM_HIP_MFMA=0 selects the packed-VALU form (D <= 3;
-// D = 4 and the LD = 8 / 16 kernels always use it).
+// queries 640 vs 1434 us for the kernel.  4 <= D <= 16 take the wide MFMA form (single-piece f16 operands, scan_core.h):
+// D/2 packed-VALU instructions per pair and lane against one or two matrix instructions per 1024 pairs (1M vertices,
+// D = 12: 818 -> 508 us per iteration).  GRAPHEM_HIP_MFMA=0 selects the packed-VALU form for every D.
 static bool fused_mfma(int LD, int D, int64_t S) {
     (void)S;
-    if (D == 4 || D > 16 || (LD != 4 && LD != 8 && LD != 16)) return false;   // D <= 3: split form; 5..16: wide form (scan_core.h)
+    if (D > 16 || (LD != 4 && LD != 8 && LD != 16)) return false;   // D <= 3: split form; 4..16: wide form (scan_core.h)
     if (const char *e = getenv("GRAPHEM_HIP_MFMA")) return atoi(e) != 0;
     return true;
 }
@@ -45,7 +46,7 @@ static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int 
     *nt = 256;
     *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
     if (LD <= 4 && (own_edges < 1500000 || fused_mfma(LD, D, S))) *r = 2;  // MFMA form: 95 VGPRs / 27 KB instead of 115 / 37
-    if (LD > 4 && fused_mfma(LD, D, S)) *r = 2;  // wide MFMA form: tiles of 512 (the fp32 tile stays in LDS for the exact checks)
+    if (D > 3 && fused_mfma(LD, D, S)) { *r = 2; *nt = 256; }  // wide MFMA form: tiles of 512 (the fp32 tile stays in LDS for the exact checks)
     if (LD <= 4 && own_edges < 400000 && !fused_mfma(LD, D, S)) *nt = 128;  // the MFMA form needs 256 threads
     const char *e = getenv("GRAPHEM_HIP_FUSED_CFG");
     if (e && LD <= 4) {
@@ -684,8 +685,9 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
         case 3: launch<3, 4, RR, NTT>(h); break;              \
         default: launch<4, 4, RR, NTT>(h); break;             \
     }
-    if (fused_mfma(h->LD, h->D, h->S) && h->D > 4) {
+    if (fused_mfma(h->LD, h->D, h->S) && h->D > 3) {
         switch (h->D) {
+            case 4: launch_mfmaw<4, 4>(h); break;
             case 5: launch_mfmaw<5, 8>(h); break;
             case 6: launch_mfmaw<6, 8>(h); break;
             case 7: launch_mfmaw<7, 8>(h); break;

@@ -537,6 +537,8 @@ def _fused_step_keys(n, D, edges, pos, sampled, k):
     (50000, 3, 8, "tiny"),       # coordinates ~1e-4: distances near the absolute slack of the filter
     (60000, 3, 8, "S1100"),      # 1100 queries: several query groups, the last one ragged (MFMA is the default form here)
     # wide rows: one f16 piece per coordinate, contraction 16 deep (D <= 10) or 32 deep
+    (30000, 4, 8, "none"),       # 4-float rows
+    (30000, 4, 8, "some"),
     (30000, 5, 8, "none"),
     (30000, 8, 8, "none"),
     (30000, 8, 8, "some"),
