@@ -387,7 +387,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_sampled, S, true);
     GH_A(d_q, S * (size_t)(h->LD + 4), true);
     GH_A(d_qscan, S * (size_t)(h->LD + 4), true);
-    GH_A(d_qA, S * 32, true);
+    GH_A(d_qA, S * 16, true);
     GH_A(d_qexact, S + 1, true);
     GH_A(d_cand, scan_path ? S * GH_CAND_CAP : 1, false);
     GH_A(d_cnt, S * GH_CNT_STRIDE, true);
@@ -427,10 +427,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     // 64.9 -> 60.6 us).  A large graph gains nothing (1 M vertices: 175.7 -> 176.7 us, the first round of workgroups waits
     // ~3 us for producers that share their CUs with gathers) and keeps the launch of its own.
     // GRAPHEM_HIP_TAU_SEPARATE=1 / 0 forces either form.
-    // The wide MFMA form (D >= 4) always: its spring phase is long enough to cover the producers (7.5 + 3 us against 11 us),
-    // and knn_tau_kernel with the wide operand row takes 23 - 33 us as a launch of its own (8 us without the row, 11 us for
-    // the same code inside the fused launch; not understood).
-    h->tau_embedded = h->n_vblocks <= 2048 || h->D >= 4;
+    h->tau_embedded = h->n_vblocks <= 2048;
     if (const char *e = getenv("GRAPHEM_HIP_TAU_SEPARATE")) h->tau_embedded = atoi(e) == 0;
     if (getenv("GRAPHEM_HIP_STAMPS")) GH_A2(d_stamps, ((size_t)std::max(h->n_vblocks, 1) + GH_STAMP_EXTRA) * 8);
     if (h->thr_M1 > 0) {  // endpoints of the threshold subset: every thr_stride-th own edge

@@ -109,7 +109,7 @@ struct gh_engine {
     float *d_iscratch = nullptr;  // (S * k, LD) per-pair scratch of the intersection kernel
     float *d_q = nullptr;         // (S, QS) query records: midpoint coordinates + tau (knn.hip gh_qs)
     float *d_qscan = nullptr;     // (S, QS) pre-filter records (-2q, t) written by the threshold kernel
-    uint16_t *d_qA = nullptr;     // (S, 16 or 32) f16 A-operand rows of the MFMA pre-filters, same kernel
+    uint16_t *d_qA = nullptr;     // (S, 16) f16 A-operand rows of the split-f16 MFMA pre-filter (D <= 3), same kernel
     int32_t *d_order = nullptr;       // internal row of every vertex (BFS reordering), or null: identity
     std::vector<int32_t> order_host;  // the same on the host (empty: identity)
     std::vector<int32_t> edges_internal;  // gh_create scratch: the edge list in internal vertex numbers
@@ -187,7 +187,7 @@ gh_status gh_grid_alloc(gh_engine *h);
 gh_status gh_grid_search(gh_engine *h);            // d_mid + tau -> candidate lists
 // fused.hip
 gh_status gh_radial_topk_device(gh_engine *h, int K, uint64_t *d_part, int nparts, int32_t *d_ids);
-int gh_fused_mfma_kb(const gh_engine *h);          // -1: packed-VALU pre-filter; 0: split-f16 MFMA form (D <= 3); 1 / 2: wide MFMA form, 16 / 32 deep
+int gh_fused_mfma_kb(const gh_engine *h);          // operand rows the thresholds must write: 0 = split-f16 MFMA form (D <= 3), -1 = none
 bool gh_fused_uses_mfma(const gh_engine *h);       // the fused kernel's pre-filter runs on the matrix pipe
 int gh_fused_tile(const gh_engine *h);              // edges per fused workgroup
 gh_status gh_launch_spring_scan(gh_engine *h);             // d_Fs + final-level candidates in one kernel

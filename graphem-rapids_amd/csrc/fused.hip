@@ -41,7 +41,8 @@ static bool fused_mfma(int LD, int D, int64_t S) {
     if (const char *e = getenv("GRAPHEM_HIP_MFMA")) return atoi(e) != 0;
     return true;
 }
-static int fused_mfma_kb(int LD, int D, int64_t S) { return !fused_mfma(LD, D, S) ? -1 : D <= 3 ? 0 : D <= 10 ? 1 : 2; }
+// operand rows the threshold computation writes: only the split form has any (the wide form builds its rows at staging)
+static int fused_mfma_kb(int LD, int D, int64_t S) { return fused_mfma(LD, D, S) && D <= 3 ? 0 : -1; }
 static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int *r) {
     *nt = 256;
     *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
@@ -413,14 +414,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
     const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
     const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
     float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
-    const float *__restrict__ qscan, const gh_h8 *__restrict__ qA, const int32_t *__restrict__ qexact, int S,
+    const float *__restrict__ qscan, int S,
     uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, gh_long_args la, gh_tau_args ta,
     unsigned long long *__restrict__ stamps) {
     constexpr int NT = 256, R = 2, TILE = NT * R, NB = 2 * R, HITBUF = 512;
     constexpr int KB = D <= 10 ? 1 : 2;
     constexpr int QS = LD + 4, QT = LD;
     if ((int)blockIdx.x < ta.nblocks) {
-        if (blockIdx.y == 0) gh_tau_produce<NT, KB>(ta, stamps ? stamps + ((int64_t)gridDim.x - 2 * ta.nblocks + GH_STAMP_EXTRA + blockIdx.x) * 8 : nullptr);
+        if (blockIdx.y == 0) gh_tau_produce<NT, -1>(ta, stamps ? stamps + ((int64_t)gridDim.x - 2 * ta.nblocks + GH_STAMP_EXTRA + blockIdx.x) * 8 : nullptr);
         return;
     }
     const bool coh = ta.nblocks > 0;
@@ -435,13 +436,14 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
     __shared__ int hq[HITBUF];
     __shared__ uint16_t badlist[TILE];
     __shared__ uint32_t ids[TILE];
-    __shared__ int hcount, nbad;
+    __shared__ uint16_t exq[GH_SCAN_QGROUP];               // queries of the group outside the f16 range
+    __shared__ int hcount, nbad, nexq;
     float *mids = reinterpret_cast<float *>(tile);
 
     const int v0 = vblock[bx], v1 = vblock[bx + 1];
     const int fe0 = first_edge[v0];
     const int nedges = first_edge[v1] - fe0;
-    if (threadIdx.x == 0) { hcount = 0; nbad = 0; }
+    if (threadIdx.x == 0) { hcount = 0; nbad = 0; nexq = 0; }
     for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
 
     // ---- phase A (every query slice redoes it for its tile, slice 0 alone stores its results)
@@ -489,7 +491,6 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
     if (ta.nblocks > 0 && threadIdx.x == 0) gh_tau_wait(ta);  // thresholds of this launch: out by now, as a rule
     if (stamps && ta.nblocks > 0 && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + 7] = wall_clock64();
     __syncthreads();
-    const int nex = (int)gh_ld_u32(qexact, coh);
     GH_STAMP(3);
 
     const int per = (S + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -498,33 +499,45 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
     for (int s_lo = s_begin; s_lo < s_end; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(s_end - s_lo, GH_SCAN_QGROUP);
         if (s_lo > s_begin) {
-            __syncthreads();  // the previous group's rows are still being read
-            if (hcount >= HITBUF / 4) {  // many query groups: the parked hits leave before the buffer fills
-                gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
-                __syncthreads();
-                if (threadIdx.x == 0) hcount = 0;
-            }
+            __syncthreads();  // the previous group's rows and list are still being read
+            const bool flush = hcount >= HITBUF / 4;   // many query groups: the parked hits leave before the buffer fills
+            if (flush) gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+            __syncthreads();
+            if (threadIdx.x == 0) { nexq = 0; if (flush) hcount = 0; }
+            __syncthreads();
         }
         gh_stage_queries<QS, QT, NT>(qscan, qt, s_lo, nq, qsh, taush, coh);
         {
-            const int q = threadIdx.x;  // one query per thread: 32 * KB bytes of A row
-            float4 *dst = reinterpret_cast<float4 *>(qa) + q * (2 * KB);
+            // one query per thread: its A row is BUILT here from the query record and the threshold (80 instructions per
+            // group and thread) -- the threshold kernel then carries no operand-row code for this form, which as a launch of
+            // its own cost it 15 - 25 us (tau_core.h), and a query outside the f16 range goes on a list of this workgroup
+            const int q = threadIdx.x;
+            _Float16 row[16 * KB];
+            bool ok = true;
             if (q < nq) {
-                const float4 *src = reinterpret_cast<const float4 *>(qA) + (int64_t)(s_lo + q) * (2 * KB);
+                const float4 *src = reinterpret_cast<const float4 *>(qscan) + (int64_t)(s_lo + q) * (QS / 4);
+                float qv[16];
 #pragma unroll
-                for (int i = 0; i < 2 * KB; ++i) dst[i] = gh_ld_f4(src + i, coh);
+                for (int d = 0; d < 16; ++d) qv[d] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < LD / 4; ++i) {
+                    const float4 v = gh_ld_f4(src + i, coh);   // (-2q_0 ..): the record holds -2q, exact both ways
+                    qv[4 * i] = -0.5f * v.x; qv[4 * i + 1] = -0.5f * v.y; qv[4 * i + 2] = -0.5f * v.z; qv[4 * i + 3] = -0.5f * v.w;
+                }
+                const float tau = gh_ld_f32(qt + (int64_t)(s_lo + q) * QS + QT, coh);
+                ok = gh_mfw_query_row<KB>(qv, tau, row);
+                if (!ok) exq[atomicAdd(&nexq, 1)] = (uint16_t)q;
             } else {  // padding row: never passes
-                _Float16 row[16 * KB];
 #pragma unroll
                 for (int k = 0; k < 16 * KB; ++k) row[k] = (_Float16)0.0f;
                 row[gh_mfw<KB>::base + 3] = (_Float16)GH_MF_NEVER;
+            }
 #pragma unroll
-                for (int i = 0; i < 2 * KB; ++i) {
-                    gh_h8 hv;
+            for (int i = 0; i < 2 * KB; ++i) {
+                gh_h8 hv;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hv[e] = row[i * 8 + e];
-                    reinterpret_cast<gh_h8 *>(dst)[i] = hv;
-                }
+                for (int e = 0; e < 8; ++e) hv[e] = row[i * 8 + e];
+                qa[q * (2 * KB) + i] = hv;
             }
         }
         __syncthreads();   // staged rows, edge ids, the list of out-of-range references: visible to every thread
@@ -566,9 +579,9 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
             }
         }
         // outside the f16 range: exact scan of this group's listed queries over the whole tile ...
+        const int nex = nexq;   // complete: the staging barrier of this group came after the rows were built
         for (int x = 0; x < nex; ++x) {
-            const int s = (int)gh_ld_u32(qexact + 1 + x, coh) - s_lo;
-            if (s < 0 || s >= nq) continue;
+            const int s = exq[x];
             for (int j = threadIdx.x; j < nedges; j += NT) park(s_lo, s, j);
         }
         // ... and of the tile's out-of-range references against every query of the group
@@ -656,7 +669,7 @@ void launch_mfmaw_l(gh_engine *h) {
     const gh_tau_args ta = fused_tau_args(h, 256);
     spring_scan_mfmaw_kernel<D, LD, LONG><<<dim3((unsigned)(h->n_vblocks + ta.nblocks), ny), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
-        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, reinterpret_cast<const gh_h8 *>(h->d_qA), h->d_qexact, (int)h->S,
+        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S,
         h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta, h->d_stamps);
 }
 template <int D, int LD>

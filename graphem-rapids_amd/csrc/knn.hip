@@ -723,12 +723,8 @@ gh_status gh_knn_thresholds(gh_engine *h) {
     const gh_tau_args a = gh_make_tau_args(h);
     const int nv = gh_tau_nv_host(a.Gpad);
 #define GH_TAU_FORM(NVv)                                                                            \
-    switch (a.qA_kb) {                                                                              \
-        case 0: knn_tau_kernel<NVv, 0><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a); break;  \
-        case 1: knn_tau_kernel<NVv, 1><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a); break;  \
-        case 2: knn_tau_kernel<NVv, 2><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a); break;  \
-        default: knn_tau_kernel<NVv, -1><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a); break; \
-    }
+    if (a.qA_kb == 0) knn_tau_kernel<NVv, 0><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a);  \
+    else knn_tau_kernel<NVv, -1><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a);
     if (nv == 8) { GH_TAU_FORM(8) } else if (nv == 16) { GH_TAU_FORM(16) } else { GH_TAU_FORM(32) }
 #undef GH_TAU_FORM
     GH_LAUNCH_CHECK();

@@ -14,7 +14,7 @@ struct gh_tau_args {
     int D, QS, QT, K, S;
     float *qt, *qscan;        // query records (coordinates, tau) and pre-filter records (-2q, t)
     _Float16 *qA;             // operand rows of the MFMA forms of the filter, or null
-    int qA_kb;                // host side: which row form knn_tau_kernel writes (-1 none, 0 split form of D <= 3, 1 / 2 wide form)
+    int qA_kb;                // host side: which row form knn_tau_kernel writes (-1 none, 0 split form of D <= 3)
     int32_t *qexact;          // [0] = count, then the queries outside the f16 range of that filter
     int32_t *tcount_reset;    // the touched-list counter to reset (set-up ran inside the previous normalise launch), or null
     // -- inside the fused launch only
@@ -23,36 +23,6 @@ struct gh_tau_args {
     int nblocks;              // workgroups at the head of the grid that compute thresholds (0: a launch of their own did)
     int32_t *wait_failed;     // set when a consumer gave up waiting (cannot happen while workgroups start in index order)
 };
-
-// Operand row of the wide MFMA form (the layout and the bounds of scan_core.h gh_mfw_query_row, which states them): 16 * KB
-// halfs, lane k < 8 * KB stores elements 2k, 2k+1.  Every lane builds just its own two elements -- lane d holds
-// coordinate d, the norms come from the caller's loop: this code runs once per CU from a cold instruction cache, and a
-// row built in full by every lane (400 instructions) took longer to fetch than to execute.
-template <int KB, class ST>
-__device__ __forceinline__ void gh_tau_wide_row(const gh_tau_args &a, int64_t qi, int lane, float qcoord, float qn, float l1,
-                                                float tau, ST st) {
-    constexpr int base = gh_mfw<KB>::base, ND = KB == 1 ? 10 : 16;
-    const bool in_range = __ballot(fabsf(qcoord) > GH_MF_RANGE) == 0ull;
-    const bool ok = tau <= GH_MF_TAU_MAX && in_range && qn <= GH_MFW_NORM_MAX;   // false for inf / NaN thresholds too
-    if (lane == 0 && !ok) st(&a.qexact[1 + atomicAdd(&a.qexact[0], 1)], (uint32_t)qi);
-    const float T = (tau - qn) + (GH_MFW_EPS * (qn + tau) + (1.1920928955078125e-07f * l1 + GH_MF_ABS));
-    _Float16 th, tm, tl;
-    gh_split3(-T, th, tm, tl);
-    const int k0 = 2 * lane;
-    const float c0 = __shfl(qcoord, k0 & 63, 64), c1 = __shfl(qcoord, (k0 + 1) & 63, 64);   // coordinates past D are 0
-    auto elem = [&](int k, float c) {
-        const _Float16 one = (_Float16)1.0f, zero = (_Float16)0.0f;
-        if (!ok) return k == base + 3 ? (_Float16)GH_MF_NEVER : zero;
-        _Float16 e = k < ND ? (_Float16)(-2.0f * c) : zero;
-        e = (k >= base && k < base + 3) ? one : e;
-        e = k == base + 3 ? th : e;
-        e = k == base + 4 ? tm : e;
-        e = k == base + 5 ? tl : e;
-        return e;
-    };
-    const uint32_t pk = (uint32_t)__builtin_bit_cast(uint16_t, elem(k0, c0)) | ((uint32_t)__builtin_bit_cast(uint16_t, elem(k0 + 1, c1)) << 16);
-    if (lane < 8 * KB) st(reinterpret_cast<uint32_t *>(a.qA + qi * (16 * KB)) + lane, pk);
-}
 
 // One wave, one query: the minima sit NV per lane in
 // registers (more than 64 * NV groups: folded by min, which only makes groups coarser), K rounds of a
@@ -119,7 +89,8 @@ __device__ __forceinline__ uint32_t gh_tau_kth(const gh_tau_args &a, int64_t qi,
 }
 
 // The records of one query from its threshold: tau into the query record, the pre-filter record (-2q, t) of the
-// packed-VALU scan and, FORM >= 0, the operand row of an MFMA form (0: split f16, D <= 3; 1 / 2: wide, 16 / 32 deep).
+// packed-VALU scan and, FORM == 0, the operand row of the split-f16 MFMA form (D <= 3; the wide form builds its rows
+// when it stages the queries, fused.hip).
 // FORM is a compile-time constant on purpose: this code runs once per CU from a cold instruction cache -- with the three
 // row forms and the three register counts of gh_tau_kth inlined into one another (9 copies, 3200 instructions, taken
 // branches over all but one) knn_tau_kernel went from 7.9 to 34 us and the producers inside the fused launch from 11 to 27.
@@ -130,12 +101,11 @@ __device__ __forceinline__ void gh_tau_records(const gh_tau_args &a, int64_t qi,
     const float tau = __uint_as_float(kth);
     if (st8 && lane == 0) st8[2] = wall_clock64();
     float qs[16];
-    float qn = 0.0f, l1 = 0.0f;
+    float qn = 0.0f;
 #pragma unroll
     for (int d = 0; d < 16; ++d) {   // every lane gets all coordinates (coordinates past D are 0: fma(0, 0, s) == s)
         qs[d] = __shfl(qcoord, d, 64);
         qn = fmaf(qs[d], qs[d], qn);
-        if constexpr (FORM == 1 || FORM == 2) l1 += fabsf(qs[d]);
     }
     // scan record of the pre-filter (scan_core.h): (-2q, t),  t = tau - |q|^2 + eps*(2|q|^2 + tau)
     // Inside the fused launch every result leaves as an agent-scope atomic store (global_store ... sc1: written through,
@@ -164,8 +134,6 @@ __device__ __forceinline__ void gh_tau_records(const gh_tau_args &a, int64_t qi,
             mine = lane == k ? pk : mine;
         }
         if (lane < 8) st(reinterpret_cast<uint32_t *>(a.qA + qi * 16) + lane, mine);
-    } else if constexpr (FORM == 1 || FORM == 2) {
-        gh_tau_wide_row<FORM>(a, qi, lane, qcoord, qn, l1, tau, st);
     }
 }
 
