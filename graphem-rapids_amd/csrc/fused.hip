@@ -447,7 +447,10 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
     for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
 
     // ---- phase A (every query slice redoes it for its tile, slice 0 alone stores its results)
-    __shared__ double red[(NT / 64) * 2 * LD];
+    // (the reduction scratch lives in the hit buffer, idle until the scan: two workgroups of 16-float rows fit the CU's
+    // 160 KB of LDS with 3 KB to spare instead of 0.8)
+    static_assert(sizeof(double) * (NT / 64) * 2 * LD <= sizeof(uint64_t) * HITBUF, "reduction scratch must fit the hit buffer");
+    double *red = reinterpret_cast<double *>(hkey);
     {
         double sx[LD], sxx[LD];
         const bool store = blockIdx.y == 0;
