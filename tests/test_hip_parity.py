@@ -615,14 +615,14 @@ def test_thresholds_inside_the_fused_launch_equal_the_separate_kernel(n, D, k, S
     assert np.abs(out["0"] - out["1"]).max() <= 1e-6
 
 
-@pytest.mark.parametrize("reorder", ["off", "bfs"])
-def test_skewed_degrees_hubs(reorder):
+@pytest.mark.parametrize("reorder,D", [("off", 3), ("bfs", 3), ("bfs", 4), ("off", 8), ("bfs", 12)])
+def test_skewed_degrees_hubs(reorder, D):
     """A graph with hubs (degrees 20000, 2000, 600 on top of a sparse random graph): one row owns more
     edges than a fused workgroup holds, so the engine must take its unfused kernels; one thread
     walks a 20000-long pull list in the reference's order.  Every phase against the oracle."""
     from graphem_rapids_amd import _native
     import graphem_rapids_amd as gra
-    n, D, k, S = 50000, 3, 10, 256
+    n, k, S = 50000, 10, 256      # (D > 3: the long-row instantiation of the wide MFMA kernel)
     rng = np.random.default_rng(11)
     base = gra.random_regular_edges(n, 4, seed=9).astype(np.int64)
     extra = []
