@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
     const float *__restrict__ qscan, int S,
     uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, gh_long_args la, gh_tau_args ta,
     unsigned long long *__restrict__ stamps) {
-    constexpr int NT = 256, R = 2, TILE = NT * R, NB = 2 * R, HITBUF = 512;
+    constexpr int NT = 256, R = 2, TILE = NT * R, NB = 2 * R;
+    constexpr int HITBUF = LD == 16 ? 256 : 512;   // (16-float rows: two workgroups per CU must fit 160 KB of LDS)
     constexpr int KB = D <= 10 ? 1 : 2;
     constexpr int QS = LD + 4, QT = LD;
     if ((int)blockIdx.x < ta.nblocks) {
@@ -437,13 +438,20 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
     __shared__ uint16_t badlist[TILE];
     __shared__ uint32_t ids[TILE];
     __shared__ uint16_t exq[GH_SCAN_QGROUP];               // queries of the group outside the f16 range
-    __shared__ int hcount, nbad, nexq;
+    // pairs that passed the filter, (query of the group) << 16 | reference: listed by the lane that found them and decided
+    // exactly by ALL threads after the group's last matrix instruction -- inline, each pair is a divergent detour of a
+    // D-step chain and two LDS row reads for one lane of a wave, and this form lets ~3x the necessary pairs through
+    // (D = 6 at 1 M vertices: 277 -> 266 us per iteration; the split form of D <= 3 keeps the inline check: there the list
+    // cost it three VGPRs -- a wave of occupancy -- for a dozen pairs per workgroup: 173 -> 189 us)
+    constexpr int PENDCAP = 512;
+    __shared__ uint32_t pend[PENDCAP];
+    __shared__ int hcount, nbad, nexq, npend;
     float *mids = reinterpret_cast<float *>(tile);
 
     const int v0 = vblock[bx], v1 = vblock[bx + 1];
     const int fe0 = first_edge[v0];
     const int nedges = first_edge[v1] - fe0;
-    if (threadIdx.x == 0) { hcount = 0; nbad = 0; nexq = 0; }
+    if (threadIdx.x == 0) { hcount = 0; nbad = 0; nexq = 0; npend = 0; }
     for (int j = threadIdx.x; j < nedges; j += NT) ids[j] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
 
     // ---- phase A (every query slice redoes it for its tile, slice 0 alone stores its results)
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
             const bool flush = hcount >= HITBUF / 4;   // many query groups: the parked hits leave before the buffer fills
             if (flush) gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
             __syncthreads();
-            if (threadIdx.x == 0) { nexq = 0; if (flush) hcount = 0; }
+            if (threadIdx.x == 0) { nexq = 0; npend = 0; if (flush) hcount = 0; }
             __syncthreads();
         }
         gh_stage_queries<QS, QT, NT>(qscan, qt, s_lo, nq, qsh, taush, coh);
@@ -574,13 +582,19 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
                             m &= ~(1u << bit);
                             const int i = 15 - bit;
                             const int s = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
-                            if (s < nq) park(s_lo, s, j);
+                            if (s < nq) {
+                                const int p = atomicAdd(&npend, 1);
+                                if (p < PENDCAP) pend[p] = ((uint32_t)s << 16) | (uint32_t)j;
+                                else park(s_lo, s, j);   // list full: decided on the spot
+                            }
                         }
                     }
                 }
                 f = fn;
             }
         }
+        __syncthreads();
+        for (int p = threadIdx.x, np = min(npend, PENDCAP); p < np; p += NT) park(s_lo, (int)(pend[p] >> 16), (int)(pend[p] & 0xFFFFu));
         // outside the f16 range: exact scan of this group's listed queries over the whole tile ...
         const int nex = nexq;   // complete: the staging barrier of this group came after the rows were built
         for (int x = 0; x < nex; ++x) {
