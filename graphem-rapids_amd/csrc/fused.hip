@@ -227,7 +227,11 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
 // and 16 query rows of every 32x32 result: a min tree over its 16 accumulators and one compare
 // decide whether any of those pairs needs the exact re-check (fp32 fma chain on the fp32 midpoint
 // and query kept in LDS -- bit-identical to the VALU form and to the oracle).
-template <int D, int R>
+// DEFER: the pairs that pass the filter are listed and decided by all threads after the group's last matrix instruction
+// (as in spring_scan_mfmaw_kernel) instead of on the spot by the lane that found them.  Pays where a workgroup meets many
+// of them -- a graph of 100 K vertices, ~70 per workgroup: 59.4 -> 58.2 us per iteration -- and costs three VGPRs, i.e. a wave
+// of occupancy: the launcher takes it for graphs whose workgroups all run at once anyway (1 M vertices with it: 173 -> 189 us).
+template <int D, int R, bool DEFER = false>
 __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
     const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
@@ -252,13 +256,15 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     __shared__ int hq[HITBUF];
     __shared__ uint16_t badlist[TILE];               // references outside the f16 range of the filter
     __shared__ uint32_t ids[TILE];                   // edge ids of the tile's references (the exact path must not wait for memory)
-    __shared__ int hcount, nbad;
+    constexpr int PENDCAP = DEFER ? 512 : 1;
+    __shared__ uint32_t pend[PENDCAP];   // (query of the group) << 16 | reference
+    __shared__ int hcount, nbad, npend;
     float *mids = reinterpret_cast<float *>(tile);
 
     const int v0 = vblock[bx], v1 = vblock[bx + 1];
     const int fe0 = first_edge[v0];
     const int nedges = first_edge[v1] - fe0;
-    if (threadIdx.x == 0) { hcount = 0; nbad = 0; }
+    if (threadIdx.x == 0) { hcount = 0; nbad = 0; npend = 0; }
     // The tile's edge ids do not depend on the spring phase: fetched now, under its gathers.  (So were the first query
     // group's operand rows while the thresholds had a launch of their own -- measured neutral at 100 K and 1 M vertices,
     // tools/stamp_probe.py: the scan's 8 us per workgroup there are its ~70 divergent hits, not its staging.)
@@ -332,12 +338,13 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
     for (int s_lo = 0; s_lo < S; s_lo += GH_SCAN_QGROUP) {
         const int nq = min(S - s_lo, GH_SCAN_QGROUP);
         if (s_lo > 0) {
-            __syncthreads();  // the previous group's rows are still being read
+            __syncthreads();  // the previous group's rows (and pair list) are still being read
             if (hcount >= HITBUF / 4) {  // many query groups: the parked hits leave before the buffer fills
                 gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
                 __syncthreads();
                 if (threadIdx.x == 0) hcount = 0;
             }
+            if constexpr (DEFER) { if (threadIdx.x == 0) npend = 0; }
         }
         stage_queries(s_lo, nq);
         __syncthreads();   // staged rows, edge ids, the list of out-of-range references: visible to every thread
@@ -371,12 +378,24 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
                             m &= ~(1u << bit);
                             const int i = 15 - bit;
                             const int s = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
-                            if (s < nq) park(s_lo, s, j);
+                            if (s < nq) {
+                                if constexpr (DEFER) {
+                                    const int p = atomicAdd(&npend, 1);
+                                    if (p < PENDCAP) pend[p] = ((uint32_t)s << 16) | (uint32_t)j;
+                                    else park(s_lo, s, j);   // list full: decided on the spot
+                                } else {
+                                    park(s_lo, s, j);
+                                }
+                            }
                         }
                     }
                 }
                 f = fn;
             }
+        }
+        if constexpr (DEFER) {
+            __syncthreads();
+            for (int p = threadIdx.x, np = min(npend, PENDCAP); p < np; p += NT) park(s_lo, (int)(pend[p] >> 16), (int)(pend[p] & 0xFFFFu));
         }
         // outside the f16 range: exact scan of this group's listed queries over the whole tile ...
         for (int x = 0; x < nex; ++x) {
@@ -631,13 +650,18 @@ gh_tau_args fused_tau_args(gh_engine *h, int nt) {
     return ta;
 }
 
-template <int D, int R>
-void launch_mfma(gh_engine *h) {
+template <int D, int R, bool DEFER>
+void launch_mfma_d(gh_engine *h) {
     const gh_tau_args ta = fused_tau_args(h, 256);
-    spring_scan_mfma_kernel<D, R><<<dim3((unsigned)(h->n_vblocks + ta.nblocks)), dim3(256), 0, h->stream>>>(
+    spring_scan_mfma_kernel<D, R, DEFER><<<dim3((unsigned)(h->n_vblocks + ta.nblocks)), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min,
         -h->prm.k_attr, h->d_Fs, h->d_new, h->d_blockstats, h->d_q, reinterpret_cast<const gh_h8 *>(h->d_qA),
         h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta, h->d_stamps);
+}
+template <int D, int R>
+void launch_mfma(gh_engine *h) {
+    if (R == 2 && h->n_vblocks <= 2048) launch_mfma_d<D, R, (R == 2)>(h);   // one round of workgroups: occupancy does not matter
+    else launch_mfma_d<D, R, false>(h);
 }
 
 template <int D, int LD, int R, int NT, bool LONG>
