@@ -75,7 +75,7 @@ static gh_status check_handle(gh_engine *h) {
 
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
-                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
+                    h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
                     h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -274,7 +274,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     // row are consecutive ids and the offset is the first of them.  Hashed rule: a prefix count
     // into the list own_eids of owned edge ids in (row, pull list) order.
     std::vector<int32_t> first_edge((size_t)h->rows + 1, 0);
-    std::vector<int32_t> own_eids, long_rows, long_ownptr, long_ownadj, long_eptr;
+    std::vector<int32_t> own_eids, long_rows, long_ownptr, long_ownadj, long_eptr, long_erow;
     std::vector<uint8_t> own_long;
     if (hashed) {
         own_eids.reserve((size_t)(E / std::max<int64_t>(1, n / std::max<int64_t>(h->rows, 1)) + 16));
@@ -298,6 +298,9 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
             }
             h->nlong = (int)long_rows.size();
             h->long_entries = long_eptr.back();
+            long_erow.resize((size_t)h->long_entries);   // list entry -> index of its long row (spares long_terms_kernel a binary search)
+            for (size_t r = 0; r + 1 < long_eptr.size(); ++r)
+                for (int32_t t = long_eptr[r]; t < long_eptr[r + 1]; ++t) long_erow[(size_t)t] = (int32_t)r;
             own_long.assign(own_eids.size() + 1, 0);   // owned-edge slots of the long rows
             for (int64_t i = 0; i < h->rows; ++i)
                 if (rowptr[(size_t)i + 1] - rowptr[(size_t)i] > long_deg)
@@ -371,6 +374,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         GH_A(d_long_ownptr, long_ownptr.size(), false);
         GH_A(d_long_ownadj, long_ownadj.size() + 1, true);
         GH_A(d_long_eptr, long_eptr.size(), false);
+        GH_A(d_long_erow, long_erow.size() + 1, false);
         GH_A(d_long_terms, (size_t)h->long_entries * D, false);
         GH_A(d_own_long, own_long.size(), false);
     }
@@ -413,6 +417,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         (h->nlong && (!up(h->d_long_rows, long_rows.data(), sizeof(int32_t) * long_rows.size()) ||
                       !up(h->d_long_ownptr, long_ownptr.data(), sizeof(int32_t) * long_ownptr.size()) ||
                       !up(h->d_long_eptr, long_eptr.data(), sizeof(int32_t) * long_eptr.size()) ||
+                      !up(h->d_long_erow, long_erow.data(), sizeof(int32_t) * long_erow.size()) ||
                       !up(h->d_long_ownadj, long_ownadj.data(), sizeof(int32_t) * long_ownadj.size()) ||
                       !up(h->d_own_long, own_long.data(), own_long.size()))) ||
         hipStreamSynchronize(h->stream) != hipSuccess) {

@@ -62,6 +62,7 @@ struct gh_engine {
     int32_t *d_long_ownptr = nullptr; // their owned (hub-hub) edges: offsets ...
     int32_t *d_long_ownadj = nullptr; // ... and neighbours
     int32_t *d_long_eptr = nullptr;   // (nlong + 1) prefix of their degrees
+    int32_t *d_long_erow = nullptr;   // (long_entries) index of the long row a list entry belongs to
     uint8_t *d_own_long = nullptr;    // (own_count) owned-edge slots whose owner row is long (common.h gh_long_midpoints)
     float *d_long_terms = nullptr;    // (long_entries * D) force terms of their neighbours, component-major per row
     int nlong = 0;

@@ -53,15 +53,12 @@ template <int D, int LD>
 __global__ __launch_bounds__(256) void long_terms_kernel(const float *__restrict__ pos, const int32_t *__restrict__ rowptr,
                                                         const int32_t *__restrict__ adj,
                                                         const int32_t *__restrict__ long_rows,
-                                                        const int32_t *__restrict__ eptr, int nlong, int64_t row_lo,
-                                                        float L_min, float neg_k, float *__restrict__ terms) {
+                                                        const int32_t *__restrict__ eptr, const int32_t *__restrict__ erow,
+                                                        int nentries, int64_t row_lo, float L_min, float neg_k,
+                                                        float *__restrict__ terms) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= eptr[nlong]) return;
-    int lo = 0, hi = nlong - 1;
-    while (lo < hi) {  // last r with eptr[r] <= t
-        const int m = (lo + hi + 1) >> 1;
-        if (eptr[m] <= t) lo = m; else hi = m - 1;
-    }
+    if (t >= nentries) return;
+    const int lo = erow[t];   // (a table: the binary search over eptr was up to 12 dependent loads per entry)
     const int i = long_rows[lo];
     const int idx = t - eptr[lo], deg = eptr[lo + 1] - eptr[lo];
     const int64_t y = (uint32_t)adj[rowptr[i] + idx] & 0x7FFFFFFFu;
@@ -662,7 +659,8 @@ gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0) {
     const float neg_k = -h->prm.k_attr;
 #define GH_LONG_CASE(DD, LL)                                                                                          \
     long_terms_kernel<DD, LL><<<dim3(grid_for(h->long_entries, 256)), dim3(256), 0, h->stream>>>(                       \
-        h->d_pos, h->d_rowptr, h->d_adj, la.rows, h->d_long_eptr, la.n, h->part.row_lo, h->prm.L_min, neg_k, h->d_long_terms); \
+        h->d_pos, h->d_rowptr, h->d_adj, la.rows, h->d_long_eptr, h->d_long_erow, (int)h->long_entries, h->part.row_lo,     \
+        h->prm.L_min, neg_k, h->d_long_terms);                                                                          \
     long_sum_kernel<DD, LL><<<dim3((unsigned)((la.n + 3) / 4)), dim3(256), 0, h->stream>>>(h->d_long_terms, la.rows,   \
                                                                                           h->d_long_eptr, la.n, outF, f_row0)
 #define GH_LONG_ONE(DD, LL) case DD: GH_LONG_CASE(DD, LL); break;
