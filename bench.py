@@ -124,6 +124,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-size", type=int, default=None, help="override the workload's number of sampled midpoints")
     ap.add_argument("--knn", default="auto", choices=["auto", "scan", "grid"], help="KNN search (gh_params.knn_method)")
+    ap.add_argument("--knn-distance", default="exact", choices=["exact", "cdist"],
+                    help="exact = speed mode; cdist = the reference's cdist + topk rows (parity mode, gh_params.knn_distance)")
     ap.add_argument("--dim", type=int, default=None, help="override the workload's number of components (experiments)")
     ap.add_argument("--dist", action="store_true",
                     help="use the multi-GPU driver (RCCL collectives) even for one rank: rehearsal of the N>1 path")
@@ -162,7 +164,8 @@ def main():
         barrier = dist.barrier
         eng = lay.engine.eng
     else:
-        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, device_id=local_rank, knn_method=args.knn)
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, device_id=local_rank, knn_method=args.knn,
+                             knn_distance=args.knn_distance)
         eng.set_positions(pos)
         stream = None
         if args.sampler == "host":  # ids drawn on the host before the timed region (parity-style stream)
@@ -250,7 +253,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "graph": WORKLOADS[args.workload][0], "n_vertices": n,
                        "n_edges": E, "n_components": D, "n_neighbors": k, "sample_size": S,
-                       "sampler": args.sampler, "knn": args.knn, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else "")},
+                       "sampler": args.sampler, "knn": args.knn, "knn_distance": args.knn_distance, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else "")},
             "roofline": roofline, "roofline_knn_fp32": knn_fp32, "roofline_iter_hbm": hbm, "kernels": kern,
         }
         if use_dist:  # rank 0's split of an iteration (HIP events on the engine's stream, second pass): where a scaling run loses its time

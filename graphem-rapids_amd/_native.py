@@ -25,17 +25,19 @@ SYMBOLS = [
     "gh_step_finish_gathered", "gh_vertex_order", "gh_positions_unpadded_device", "gh_radial_topk",
     "gh_comm_unique_id", "gh_comm_init_rccl", "gh_loopback_group_create", "gh_loopback_group_destroy",
     "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error", "gh_debug_stamps",
+    "gh_knn_cdist_stats",
 ]
 
 
 class GhParams(ctypes.Structure):
     _fields_ = [("L_min", ctypes.c_float), ("k_attr", ctypes.c_float), ("k_inter", ctypes.c_float),
                 ("n_neighbors", ctypes.c_int32), ("sample_size", ctypes.c_int32), ("seed", ctypes.c_uint64),
-                ("reorder", ctypes.c_int32), ("knn_method", ctypes.c_int32)]
+                ("reorder", ctypes.c_int32), ("knn_method", ctypes.c_int32), ("knn_distance", ctypes.c_int32)]
 
 
 REORDER = {"auto": 0, "off": 1, "bfs": 2}  # gh_params.reorder (include/graphem_hip.h GH_REORDER_*)
 KNN_METHOD = {"auto": 0, "scan": 1, "grid": 2}  # gh_params.knn_method (GH_KNN_*)
+KNN_DISTANCE = {"exact": 0, "cdist": 1}  # gh_params.knn_distance (GH_DIST_*)
 
 
 class GhPartition(ctypes.Structure):
@@ -127,6 +129,8 @@ def load():
     L.gh_knn_points.restype = ctypes.c_int
     L.gh_knn_last_counts.argtypes = [vp, vp, vp, vp]
     L.gh_knn_last_counts.restype = ctypes.c_int
+    L.gh_knn_cdist_stats.argtypes = [vp, vp, vp]
+    L.gh_knn_cdist_stats.restype = ctypes.c_int
     L.gh_comm_unique_id.argtypes = [vp]
     L.gh_comm_unique_id.restype = ctypes.c_int
     L.gh_comm_init_rccl.argtypes = [vp, i32, i32, vp]
@@ -174,14 +178,14 @@ class Engine:
     """Thin RAII wrapper over a gh_handle."""
 
     def __init__(self, n, D, edges, L_min, k_attr, k_inter, n_neighbors, sample_size, seed=0, device_id=0,
-                 partition=None, reorder="auto", knn_method="auto"):
+                 partition=None, reorder="auto", knn_method="auto", knn_distance="exact"):
         self.lib = load()
         self.handle = ctypes.c_void_p()
         self.n, self.D = int(n), int(D)
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
         self.E = edges.shape[0]
         prm = GhParams(float(L_min), float(k_attr), float(k_inter), int(n_neighbors), int(sample_size),
-                       int(seed) & 0xFFFFFFFFFFFFFFFF, REORDER[reorder], KNN_METHOD[knn_method])
+                       int(seed) & 0xFFFFFFFFFFFFFFFF, REORDER[reorder], KNN_METHOD[knn_method], KNN_DISTANCE[knn_distance])
         part = None
         if partition is not None:
             vals = [int(x) for x in partition]  # (row_lo, row_hi, edge_lo, edge_hi[, edge_rule])
@@ -357,6 +361,13 @@ class Engine:
         a, b, c = (np.zeros(self.S, dtype=np.int32) for _ in range(3))
         self._chk(self.lib.gh_knn_last_counts(self.handle, ptr(a), ptr(b), ptr(c)))
         return a, b, c
+
+    def knn_cdist_stats(self):
+        """(rows that took the pass over all edges, rows with a tie ATen's nth_element path decides) of the last
+        KNN search of a knn_distance='cdist' engine."""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._chk(self.lib.gh_knn_cdist_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     # instrumentation
     def timing_enable(self, on=True):

@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_rare, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -115,6 +115,11 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     if (h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID)   // AUTO (and anything unknown)
         h->prm.knn_method = (D <= 3 && h->S >= 12288) ? GH_KNN_GRID : GH_KNN_SCAN;
     if (const char *e = getenv("GRAPHEM_HIP_KNN")) h->prm.knn_method = atoi(e) == GH_KNN_GRID ? GH_KNN_GRID : GH_KNN_SCAN;  // A/B runs
+    if (params->knn_distance != GH_DIST_EXACT && params->knn_distance != GH_DIST_CDIST) { delete h; return fail(GH_ERR_INVALID, "unknown knn_distance"); }
+    h->cdist = params->knn_distance == GH_DIST_CDIST;
+    if (h->cdist && part) { delete h; return fail(GH_ERR_INVALID, "knn_distance = GH_DIST_CDIST needs the whole graph on one engine (no gh_partition)"); }
+    if (h->cdist) h->prm.knn_method = GH_KNN_SCAN;   // the grid search knows exact distances only
+    h->Ksel = h->K + (h->cdist ? 1 : 0);
     if (part) h->part = *part;
     else h->part = gh_partition{0, n, 0, E, GH_EDGES_RANGE};
     if (h->part.edge_rule == GH_EDGES_HASHED) h->part.edge_lo = h->part.edge_hi = 0;  // not used by this rule
@@ -425,6 +430,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         return bail(GH_ERR_HIP);
     }
     if ((st = gh_grid_alloc(h)) != GH_OK) return bail(st);
+    if ((st = gh_cdist_alloc(h)) != GH_OK) return bail(st);
     GH_A2(d_tau_flag, 1);
     GH_A2(d_wait_failed, 1);
     // Thresholds by the first workgroups of the fused launch (tau_core.h) where that launch is a single round of
@@ -725,6 +731,7 @@ extern "C" gh_status gh_gather_layout(gh_handle h, int32_t world, int32_t rank, 
         return GH_ERR_INVALID;
     }
     if (h->d_gbuf) { h->err = "gather layout already set"; return GH_ERR_INVALID; }
+    if (h->cdist) { h->err = "GH_DIST_CDIST engines do not take a gather layout"; return GH_ERR_INVALID; }
     const int64_t stats_bytes = (int64_t)sizeof(double) * (2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
     const int64_t slot = (chunk * h->LD * (int64_t)sizeof(float) + stats_bytes + 15) / 16 * 16;
     GH_HIP(hipStreamSynchronize(h->stream));
@@ -885,6 +892,20 @@ extern "C" gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int
     if (final_counts) GH_HIP(hipMemcpyAsync(final_counts, h->d_dbg_cnt + h->S, bytes, hipMemcpyDeviceToHost, h->stream));
     if (overflow) GH_HIP(hipMemcpyAsync(overflow, h->d_ovf, bytes, hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipStreamSynchronize(h->stream));
+    return GH_OK;
+}
+
+extern "C" gh_status gh_knn_cdist_stats(gh_handle h, int32_t *full_pass_rows, int32_t *unresolved_tie_rows) {
+    GH_TRY(check_handle(h));
+    int32_t rare = 0, stat = 0;
+    if (h->cdist && h->d_rare) {
+        GH_HIP(hipMemcpyAsync(&rare, h->d_rare, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        GH_HIP(hipMemcpyAsync(&stat, h->d_cd_stat, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        GH_HIP(hipStreamSynchronize(h->stream));
+        if (!gh_knn_scan_path(h)) rare = (int32_t)h->S;   // a graph too small for the filtered scan: every row
+    }
+    if (full_pass_rows) *full_pass_rows = rare;
+    if (unresolved_tie_rows) *unresolved_tie_rows = stat;
     return GH_OK;
 }
 

@@ -653,7 +653,7 @@ static int64_t own_edges(const gh_engine *h) { return h->own_count; }
 
 bool gh_knn_scan_path(const gh_engine *h) {
     const int64_t Mtot = own_edges(h);
-    return Mtot >= GH_SCAN_MIN_EDGES && h->LD <= 16 && h->D >= 2 && h->K <= GH_EXTRACT_MAX_K && h->S <= 0x7FFFFFFF;
+    return Mtot >= GH_SCAN_MIN_EDGES && h->LD <= 16 && h->D >= 2 && h->Ksel <= GH_EXTRACT_MAX_K && h->S <= 0x7FFFFFFF;
 }
 
 // Sample ids (if still pending), query records, list reset and -- on the scan path -- the compact
@@ -662,7 +662,7 @@ gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint6
     if (h->thr_stride == 0) {  // fixed at the first use: d_gmin is sized from it
         const int64_t Mtot = own_edges(h);
         const bool scan = gh_knn_scan_path(h) && !gh_grid_path(h);   // the grid search takes its thresholds from the grid
-        h->thr_stride = scan ? subset_stride(Mtot, h->K, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h)) : 1;
+        h->thr_stride = scan ? subset_stride(Mtot, h->Ksel, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h)) : 1;
         h->thr_M1 = scan ? (Mtot + h->thr_stride - 1) / h->thr_stride : 0;
     }
     const int tiles = (int)((h->thr_M1 + GH_THR_TILE - 1) / GH_THR_TILE);
@@ -706,7 +706,7 @@ gh_tau_args gh_make_tau_args(gh_engine *h) {
     t.D = h->D;
     t.QS = gh_qs(h->D, h->LD);
     t.QT = gh_qtau(h->D, h->LD);
-    t.K = h->K;
+    t.K = h->Ksel;   // GH_DIST_CDIST: a bound for K + 1 neighbours (cdist_core.h)
     t.S = (int)h->S;
     t.qt = h->d_q;
     t.qscan = h->d_qscan;
@@ -737,6 +737,7 @@ gh_status gh_knn_thresholds(gh_engine *h) {
 // fuse_intersect (single-rank steps): the same launches also run the intersection phase of each
 // query they finish (h->intersect_done tells the caller).
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect) {
+    if (h->cdist) return gh_knn_finish_cdist(h, false);   // the reference's cdist + topk rows (cdist_core.h)
     const bool fuse = fuse_intersect && h->K <= GH_EXTRACT_MAX_K;
     GH_TRY_ST(launch_select(h, true, fuse, have_mid ? h->d_mid : nullptr));
     h->intersect_done = fuse;
@@ -748,6 +749,7 @@ gh_status gh_knn_local(gh_engine *h, bool fuse_intersect) {
     const int64_t Mtot = own_edges(h);
     GH_TRY_ST(gh_knn_prepare(h));
     if (!gh_knn_scan_path(h)) {
+        if (h->cdist) return gh_knn_finish_cdist(h, true);   // every query against all edges (cdist_core.h)
         const bool fuse = fuse_intersect && h->K <= GH_EXTRACT_MAX_K;
         gh_scope t(h, "knn_block_select");
         launch_block_select(h, h->d_mid, Mtot, 1, 1, nullptr, h->d_partial, false, fuse);
@@ -880,3 +882,4 @@ gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq,
 }
 
 #include "grid_core.h"
+#include "cdist_core.h"

@@ -55,6 +55,7 @@ class GraphEmbedderHIP:
         sampler="auto",
         init="auto",
         knn_method="auto",
+        knn_distance="auto",
     ):
         """Arguments as pt.py:51-104.  Extra keyword-only arguments:
 
@@ -66,6 +67,11 @@ class GraphEmbedderHIP:
             exact search through a uniform grid over the midpoints rebuilt every iteration -- sub-quadratic, pays from
             several thousand sampled midpoints on; the counterpart of the reference's cuVS indexes,
             embedder_cuvs.py:255-313), or 'auto' = 'grid' when n_components <= 3 and sample_size >= 12288.
+        knn_distance : 'cdist' ranks the neighbours on the value torch.cdist gives (ATen's matmul form, fp32) and orders
+            equal values as torch.topk does, i.e. the neighbour ids of the reference's PyTorch-CPU backend row for row
+            (pt.py:580-583); 'exact' ranks on the exact-difference squared distance, ties on the smaller id (what the
+            reference's KeOps path computes, pt.py:527-534; one launch less per iteration).  'auto' = 'cdist' with
+            sampler='torch' (the parity mode), 'exact' with sampler='device' (the speed mode).
         init : 'laplacian' (scipy eigsh exactly as pt.py:337-379), 'laplacian_hip' (the same
             eigenvectors by thick-restart Lanczos on the GPU, spectral.py: 1.2 s at 100 K vertices where
             eigsh takes 29 s, 3.4 s at 1 M where it is impractical), 'random' (the reference's own
@@ -132,13 +138,25 @@ class GraphEmbedderHIP:
         if sampler == "auto":
             sampler = "torch" if self.n_edges <= (1 << 20) else "device"
         self.sampler = sampler
+        if knn_distance not in ("auto", "exact", "cdist"):
+            raise ValueError(f"Invalid knn_distance: {knn_distance}")
+        if knn_distance == "auto":
+            knn_distance = "cdist" if sampler == "torch" else "exact"
+        self.knn_distance = knn_distance
 
         # the device sampler's key: an unseeded embedder draws it from torch's global generator, so unseeded
         # runs differ from each other (like the reference's) while torch.manual_seed still controls both samplers
-        self._engine_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+        # (drawn only for the device sampler: with sampler='torch' the draw would shift the randperm stream the reference's
+        # CPU backend consumes after torch.manual_seed, pt.py:409)
+        if seed is not None:
+            self._engine_seed = int(seed)
+        elif self.sampler == "device":
+            self._engine_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        else:
+            self._engine_seed = 0
         self._engine = _native.Engine(
             self.n, n_components, self._edges_np, L_min, k_attr, k_inter, n_neighbors, self.sample_size,
-            seed=self._engine_seed, device_id=self.device.index, knn_method=knn_method)
+            seed=self._engine_seed, device_id=self.device.index, knn_method=knn_method, knn_distance=knn_distance)
         if self.verbose:
             self.logger.info("Initialized GraphEmbedderHIP on %s", self.device)
             self.logger.info("Graph: %d vertices, %d edges, %dD", self.n, self.n_edges, self.n_components)

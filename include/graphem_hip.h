@@ -48,7 +48,23 @@ typedef struct {
     uint64_t seed;        /* seed of the on-device sampler (used when no sample ids are passed) */
     int32_t reorder;      /* internal vertex order: GH_REORDER_AUTO / _OFF / _BFS (no reference counterpart) */
     int32_t knn_method;   /* GH_KNN_AUTO / _SCAN / _GRID: how the exact KNN of the sampled midpoints is searched */
+    int32_t knn_distance; /* GH_DIST_EXACT / GH_DIST_CDIST: which distance ranks the neighbours (below) */
 } gh_params;
+
+/* Distance the KNN ranks on (pt.py:543-593).
+ *   GH_DIST_EXACT  squared Euclidean distance in exact-difference form, sum_d (q_d - m_d)^2 as an fma chain in
+ *                  coordinate order, ties on the smaller edge id: what the reference's KeOps path computes
+ *                  (pt.py:527-534) and the fp64-correct ranking.  The speed mode; 0, so a zeroed struct selects it.
+ *   GH_DIST_CDIST  the value and order the reference's PyTorch-CPU backend gets from torch.cdist + torch.topk
+ *                  (pt.py:580-583): ATen's matmul form  acc = fma(-2 q_d, m_d, acc) ...; acc += |q|^2; acc += |m|^2;
+ *                  sqrt(max(acc, 0))  with |x|^2 = sum of rounded squares, left to right, and equal values in the
+ *                  order std::partial_sort leaves them (ATen/native/TopKImpl.h; K * 64 <= E).  The sampled edge is not
+ *                  special-cased: column 0 is whatever ranks first (pt.py:417-421).  Neighbour ids then equal the
+ *                  reference's row by row at every size.  Costs one more launch per iteration plus, for the rows whose
+ *                  K + 1 smallest values hold a tie (about 1 in 100 at a million vertices), a pass over all E edges.
+ *                  Whole-graph engines only (no gh_partition); forces GH_KNN_SCAN. */
+#define GH_DIST_EXACT 0
+#define GH_DIST_CDIST 1
 
 /* KNN search (the reference's cdist + topk, pt.py:543-593; its cuVS backend reaches for IVF indexes,
  * embedder_cuvs.py:255-313).  Every method returns the EXACT k+1 nearest midpoints, identical ids.
@@ -220,6 +236,11 @@ gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64_t count);
  * level and the final level saw, and whether the exact fallback had to redo the query
  * (any of the three (S,) host pointers may be NULL).  Blocking. */
 gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final_counts, int32_t *overflow);
+/* GH_DIST_CDIST engines, last KNN search: rows that needed the pass over all edges (a tie among their K + 1 smallest
+ * cdist values, or a candidate list that could not be proven complete), and rows whose tie order ATen decides with
+ * std::nth_element (K * 64 > E, tiny graphs) -- there equal values come out in (value, id) order and the row is
+ * counted here instead of being reproduced.  Either pointer may be NULL.  Blocking. */
+gh_status gh_knn_cdist_stats(gh_handle h, int32_t *full_pass_rows, int32_t *unresolved_tie_rows);
 
 /* Plain point-set KNN without a handle: the reference's _compute_knn_chunked /
  * _compute_knn_torch (pt.py:426-483, 543-593).  q (nq, D), ref (nref, D) host float32 row-major;

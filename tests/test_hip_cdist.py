@@ -1,0 +1,160 @@
+"""knn_distance='cdist': the HIP path must return the neighbour rows of the reference's PyTorch-CPU backend --
+torch.cdist's fp32 matmul-form values ranked by torch.topk, ties in std::partial_sort's order (pt.py:580-583) --
+id for id, at every size.  Checked against the reference's own rows (golden fixtures) and against
+oracle/aten_cdist_topk.cpp, the CPU statement of ATen's algorithm that tests/test_oracle_reference_fullsize.py pins to
+the reference at 100 K and 1 M vertices.  Needs a real MI355X (`pytest -m gpu`)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN_CASES, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(n, D, edges, k, S, params=(1.0, 0.2, 0.5), **kw):
+    from graphem_rapids_amd import _native
+    return _native.Engine(n, D, edges, *params, k, S, knn_distance="cdist", **kw)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_cdist_rows_are_the_references_on_the_small_fixtures(case):
+    """Seven graphs of 6 .. 2000 vertices, every captured step: the rows torch.topk returned."""
+    g = load_golden(case)
+    n, D, k, S = int(g["n"]), int(g["D"]), int(g["k"]), int(g["S"])
+    eng = _engine(n, D, g["edges"], k, S, params=tuple(float(x) for x in g["params"]))
+    for t in g["steps"]:
+        pos, sampled = g[f"pos_{t}"], g[f"sampled_{t}"]
+        eng.set_positions(pos)
+        knn = eng.knn_midpoints(sampled)
+        full, unresolved = eng.knn_cdist_stats()
+        assert np.array_equal(knn, oracle.knn_midpoints_aten(pos, g["edges"], sampled, k)), f"{case} step {t}"
+        assert np.array_equal(knn, g[f"knn_{t}"]), f"{case} step {t}: not the reference's rows"
+        assert unresolved == 0, f"{case} step {t}: {unresolved} rows with a tie that ATen's nth_element path decides"
+        eng.step(sampled)
+        assert np.abs(eng.get_positions() - g[f"pos_next_{t}"]).max() <= 1e-4
+    eng.close()
+
+
+def _positions(kind, n, D, rng):
+    if kind == "gauss":
+        return rng.standard_normal((n, D)).astype(np.float32)
+    if kind == "start":       # the reference's random start: 0.1 sigma
+        return (rng.standard_normal((n, D)) * 0.1).astype(np.float32)
+    if kind == "lattice":     # coordinates on a coarse lattice: equal distances everywhere, ties in every row
+        return (rng.integers(-6, 7, size=(n, D)) / 4.0).astype(np.float32)
+    if kind == "lattice_fine":
+        return (rng.integers(-40, 41, size=(n, D)) / 32.0).astype(np.float32)
+    if kind == "collapsed":   # a bulk of radius 1e-3 far from the origin: cdist's quantum exceeds the neighbour spacing
+        p = (rng.standard_normal((n, D)) * 1e-3 + 3.0).astype(np.float32)
+        p[: n // 50] = rng.standard_normal((n // 50, D)).astype(np.float32) * 50.0
+        return p
+    raise ValueError(kind)
+
+
+CASES = [
+    # n, degree, D, k, S, positions
+    (5000, 8, 3, 10, 256, "gauss"),
+    (5000, 8, 3, 10, 256, "lattice"),
+    (5000, 8, 2, 10, 256, "lattice_fine"),
+    (5000, 8, 3, 10, 256, "collapsed"),
+    (30000, 8, 3, 10, 256, "start"),
+    (30000, 8, 3, 10, 700, "lattice_fine"),
+    (30000, 8, 2, 5, 256, "gauss"),
+    (20000, 8, 4, 10, 256, "gauss"),
+    (20000, 8, 6, 32, 128, "lattice_fine"),
+    (20000, 8, 16, 32, 256, "gauss"),
+    (20000, 8, 12, 10, 256, "collapsed"),
+    (6000, 6, 3, 100, 64, "gauss"),        # K = 101
+    (6000, 6, 3, 126, 64, "lattice_fine"), # K + 1 = 128: the largest selection the scan path takes
+    (6000, 6, 3, 200, 64, "gauss"),        # past it: every row takes the full pass
+    (3000, 4, 3, 10, 256, "lattice"),      # E = 6000: too small for the scan, every row takes the full pass
+    (3000, 4, 20, 10, 256, "gauss"),       # generic dimension
+    (400, 4, 3, 10, 64, "lattice"),        # E = 800, K * 64 = 704 <= E: still partial_sort
+]
+
+
+@pytest.mark.parametrize("n,deg,D,k,S,kind", CASES)
+def test_cdist_rows_equal_atens_on_random_graphs(n, deg, D, k, S, kind):
+    import graphem_rapids_amd as gra
+    rng = np.random.default_rng(n * 7 + D * 131 + k)
+    edges = np.ascontiguousarray(gra.random_regular_edges(n, deg, seed=D + k), dtype=np.int32)
+    E = len(edges)
+    S = min(S, E)
+    pos = _positions(kind, n, D, rng)
+    eng = _engine(n, D, edges, k, S)
+    eng.set_positions(pos)
+    for rep in range(2):
+        sampled = rng.permutation(E)[:S].astype(np.int32) if S < E else np.arange(E, dtype=np.int32)
+        knn = eng.knn_midpoints(sampled)
+        full, unresolved = eng.knn_cdist_stats()
+        want = oracle.knn_midpoints_aten(pos, edges, sampled, k)
+        bad = np.nonzero(~(knn == want).all(axis=1))[0]
+        assert len(bad) == 0, (f"{len(bad)} rows differ (full-pass rows {full}); first: row {bad[0]}\n"
+                               f"  hip  {knn[bad[0]]}\n  aten {want[bad[0]]}")
+        assert unresolved == 0
+        if kind.startswith("lattice"):
+            assert full > 0          # the tie path was really taken
+    # and one whole step with these rows: the oracle in its ATen mode
+    eng.step(sampled)
+    ref = oracle.step_aten(pos, edges, sampled, k)
+    assert np.abs(eng.get_positions() - ref).max() <= 1e-4
+    eng.close()
+
+
+def test_tiny_graphs_where_aten_ranks_with_nth_element():
+    """K * 64 > E: ATen's topk takes std::nth_element + std::sort.  Without a tie the rows are the same; rows with a tie
+    are put in (value, id) order and COUNTED (gh_knn_cdist_stats) rather than reproduced."""
+    import graphem_rapids_amd as gra
+    n, k = 120, 10
+    edges = np.ascontiguousarray(gra.random_regular_edges(n, 4, seed=1), dtype=np.int32)   # E = 240 < 704
+    E = len(edges)
+    rng = np.random.default_rng(0)
+    pos = rng.standard_normal((n, 3)).astype(np.float32)
+    eng = _engine(n, 3, edges, k, E)
+    eng.set_positions(pos)
+    knn = eng.knn_midpoints(None)
+    full, unresolved = eng.knn_cdist_stats()
+    want = oracle.knn_midpoints_aten(pos, edges, np.arange(E, dtype=np.int32), k)
+    assert full == E and unresolved == 0 and np.array_equal(knn, want)
+    lat = (rng.integers(-2, 3, size=(n, 3)) / 2.0).astype(np.float32)
+    eng.set_positions(lat)
+    knn = eng.knn_midpoints(None)
+    full, unresolved = eng.knn_cdist_stats()
+    want = oracle.knn_midpoints_aten(lat, edges, np.arange(E, dtype=np.int32), k)
+    assert unresolved > 0
+    same = (knn == want).all(axis=1)
+    assert same.sum() >= E - unresolved     # every row without a tie is ATen's
+    eng.close()
+
+
+def test_cdist_engines_refuse_partitions():
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    n = 20000
+    edges = gra.random_regular_edges(n, 8, seed=1).astype(np.int32)
+    with pytest.raises(ValueError, match="whole graph"):
+        _native.Engine(n, 3, edges, 1.0, 0.2, 0.5, 10, 256, knn_distance="cdist",
+                       partition=(0, n // 2, 0, 0, _native.EDGES_HASHED))
+
+
+def test_public_api_defaults_to_cdist_with_the_torch_sampler():
+    import torch
+    import graphem_rapids_amd as gra
+    n = 4000
+    edges = gra.random_regular_edges(n, 8, seed=3).astype(np.int32)
+    adj = gra.edges_to_adjacency(n, edges)
+    emb = gra.create_graphem(adj, n_components=3, backend="hip", verbose=False, seed=0, init="random", sampler="torch")
+    assert emb.knn_distance == "cdist"
+    fast = gra.create_graphem(adj, n_components=3, backend="hip", verbose=False, seed=0, init="random", sampler="device")
+    assert fast.knn_distance == "exact"
+    pos = emb.positions
+    torch.manual_seed(5)
+    ids = torch.randperm(len(edges))[:256].numpy().astype(np.int32)
+    torch.manual_seed(5)
+    knn, used = emb._locate_knn_midpoints()
+    assert np.array_equal(used, ids)
+    assert np.array_equal(knn, oracle.knn_midpoints_aten(pos, emb._edges_np, ids, 10))
+    torch.manual_seed(5)
+    emb.update_positions()
+    assert np.abs(emb.positions - oracle.step_aten(pos, emb._edges_np, ids, 10)).max() <= 1e-4
