@@ -33,6 +33,7 @@
 
 namespace {
 
+#define GH_CD_TILE 4096   /* chunk minima staged in LDS at a time (cdist_sim_kernel) */
 struct cdist_args {
     const float *pos;          // (n, LD) rows
     const int32_t *edges;      // (E, 2)
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
             const double w = (double)gh_key_d2(best[Ks - 1]);   // the (K+1)-th smallest VALUE (a distance, not squared)
             if (!(w * w * (1.0 + 1e-6) <= cdist_lower_bound(a.qt[qi * a.QS + a.QT], qn, a.D))) bad |= 2;
         }
-        reason = __syncthreads_or(bad);
+        // 1: a tie among the K + 1 smallest values, 2: the list is not provably complete (3: both)
+        reason = (__syncthreads_or(bad & 1) ? 1 : 0) | (__syncthreads_or(bad & 2) ? 2 : 0);
     }
     if (reason) {
         if (threadIdx.x == 0) { rare[1 + atomicAdd(&rare[0], 1)] = (int32_t)qi; ovf[qi] = reason; }
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
 // ---- the full pass -----------------------------------------------------------------------------------------------
 // Values of the listed queries against ALL edges, in edge-id order: workgroup x takes the chunk of CH = 256 * NPT ids
 // [x * CH, (x + 1) * CH), gathers its midpoints once (registers) and loops over the rows of this round
-// (t = r0 + blockIdx.y, step gridDim.y); vbuf[slot][e] = value, cmin[slot][chunk] = the chunk's minimum.
+// (t = r0 + blockIdx.y, step gridDim.y); vbuf[slot][e] = value, cmin[slot][c] = the minimum over ids [256 c, 256 (c + 1)).
 template <int LDT, int NPT>
 __global__ __launch_bounds__(256) void cdist_rows_kernel(cdist_args a, const int32_t *__restrict__ rare, int all_rows, int r0, int R,
                                                          float *__restrict__ vbuf, int64_t vstride, float *__restrict__ cmin,
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void cdist_rows_kernel(cdist_args a, const int
     constexpr int CH = 256 * NPT;
     constexpr int LM = LDT > 0 ? LDT : 1;
     __shared__ float qsh[LDT > 0 ? 16 : 1];
-    __shared__ float wmin[4];
+    __shared__ float wmin[4][NPT];
     const int64_t e0 = (int64_t)blockIdx.x * CH;
     float m[NPT][LM], mn[NPT];
     if constexpr (LDT > 0) {   // midpoints of this thread's ids, and their norms
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void cdist_rows_kernel(cdist_args a, const int
     for (int t = r0 + (int)blockIdx.y; t < t_end; t += (int)gridDim.y) {
         const int64_t qi = all_rows ? t : rare[1 + t];
         const int slot = t - r0;
-        float vmin = INFINITY;
+        float vmin[NPT];
         if constexpr (LDT > 0) {
             __syncthreads();
             if (threadIdx.x < 16) qsh[threadIdx.x] = (int)threadIdx.x < a.D ? a.qt[qi * a.QS + threadIdx.x] : 0.0f;
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(256) void cdist_rows_kernel(cdist_args a, const int
                 if (a.mm_form) { acc = acc + qn; acc = acc + mn[j]; }
                 const float v = e < a.E ? sqrtf(fmaxf(acc, 0.0f)) + 0.0f : INFINITY;
                 vbuf[(int64_t)slot * vstride + e] = v;
-                vmin = fminf(vmin, v);
+                vmin[j] = v;
             }
         } else {   // any dimension: rows read from memory per pair
             const float *q = a.qt + qi * a.QS;
@@ -224,62 +226,94 @@ __global__ __launch_bounds__(256) void cdist_rows_kernel(cdist_args a, const int
                 const int64_t e = e0 + j * 256 + threadIdx.x;
                 const float v = e < a.E ? cdist_pair<0>(a, q, qn, e) : INFINITY;
                 vbuf[(int64_t)slot * vstride + e] = v;
-                vmin = fminf(vmin, v);
+                vmin[j] = v;
             }
         }
+        // minima per 256 consecutive ids (round j of this workgroup): the granularity cdist_sim_kernel skips at
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) vmin = fminf(vmin, __shfl_xor(vmin, off, 64));
+        for (int j = 0; j < NPT; ++j) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) vmin[j] = fminf(vmin[j], __shfl_xor(vmin[j], off, 64));
+        }
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = vmin;
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) wmin[threadIdx.x >> 6][j] = vmin[j];
+        }
         __syncthreads();
-        if (threadIdx.x == 0) cmin[(int64_t)slot * nchunks + blockIdx.x] = fminf(fminf(wmin[0], wmin[1]), fminf(wmin[2], wmin[3]));
+        if (threadIdx.x < NPT && (int)blockIdx.x * NPT + (int)threadIdx.x < nchunks)
+            cmin[(int64_t)slot * nchunks + blockIdx.x * NPT + threadIdx.x] =
+                fminf(fminf(wmin[0][threadIdx.x], wmin[1][threadIdx.x]), fminf(wmin[2][threadIdx.x], wmin[3][threadIdx.x]));
     }
 }
 
 // The comparator of ATen's topk on values (NaN last): "x before y".
 __device__ __forceinline__ bool cdist_less(float x, float y) { return (x == x && y != y) || x < y; }
 
-// Max-heap primitives with the tie behaviour of the textbook sift-down-to-a-leaf-then-up form std::partial_sort is
-// built on: the hole at `hole` sinks to the bottom along the larger child (the RIGHT one unless it is smaller than the
-// left), then `val` climbs while its parent is smaller.  hv / hid: values and ids, `len` elements.
-__device__ inline void cdist_heap_adjust(float *hv, int32_t *hid, int hole, int len, float val, int32_t vid) {
+// Max-heap with the tie behaviour of the textbook sift-down-to-a-leaf-then-up form std::partial_sort is built on: the
+// hole at `hole` sinks to the bottom along the larger child (the RIGHT one unless it is smaller than the left), then
+// `val` climbs while its parent is smaller.  Two homes for the heap, one algorithm (adjust() below):
+//   cdist_heap_reg  K <= 64: element i in lane i's registers, reads through v_readlane, writes by lane predicate --
+//                   every step of a sift is a few scalar-pipe cycles.  (The first version kept every heap in LDS with lane 0
+//                   walking it: ~12 DEPENDENT LDS round trips per entering element, ~140 entering elements per row:
+//                   140 us per row at 100 K vertices, most of the kernel.)
+//   cdist_heap_lds  any K: values and ids in LDS, lane 0 walks.
+struct cdist_heap_reg {
+    float v;
+    int32_t id;
+    int lane;
+    __device__ __forceinline__ float val(int i) const { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), i)); }
+    __device__ __forceinline__ int32_t idx(int i) const { return __builtin_amdgcn_readlane(id, i); }
+    __device__ __forceinline__ void set(int i, float x, int32_t xi) { if (lane == i) { v = x; id = xi; } }
+    __device__ __forceinline__ void sync() const {}
+};
+struct cdist_heap_lds {
+    float *hv;
+    int32_t *hid;
+    int lane;
+    __device__ __forceinline__ float val(int i) const { return hv[i]; }
+    __device__ __forceinline__ int32_t idx(int i) const { return hid[i]; }
+    __device__ __forceinline__ void set(int i, float x, int32_t xi) { if (lane == 0) { hv[i] = x; hid[i] = xi; } }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }   // one wave per workgroup: orders lane 0's writes before everybody's reads
+};
+template <class H>
+__device__ __forceinline__ void cdist_heap_adjust(H &h, int hole, int len, float val, int32_t vid) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
         child = 2 * (child + 1);
-        if (cdist_less(hv[child], hv[child - 1])) --child;
-        hv[hole] = hv[child]; hid[hole] = hid[child];
+        if (cdist_less(h.val(child), h.val(child - 1))) --child;
+        h.set(hole, h.val(child), h.idx(child));
         hole = child;
     }
     if ((len & 1) == 0 && child == (len - 2) / 2) {
         child = 2 * (child + 1);
-        hv[hole] = hv[child - 1]; hid[hole] = hid[child - 1];
+        h.set(hole, h.val(child - 1), h.idx(child - 1));
         hole = child - 1;
     }
     int parent = (hole - 1) / 2;
-    while (hole > top && cdist_less(hv[parent], val)) {
-        hv[hole] = hv[parent]; hid[hole] = hid[parent];
+    while (hole > top && cdist_less(h.val(parent), val)) {
+        h.set(hole, h.val(parent), h.idx(parent));
         hole = parent;
         parent = (hole - 1) / 2;
     }
-    hv[hole] = val; hid[hole] = vid;
+    h.set(hole, val, vid);
+    h.sync();
 }
 
 // One wave per listed query: std::partial_sort(first, first + K, last) over the (value, index) pairs of ALL edges in
 // index order, from the values of cdist_rows_kernel.  The first K pairs are heapified; then pair i enters (replacing
 // the maximum) iff value_i < maximum -- so a chunk whose minimum is not below the current maximum holds nothing that
-// would enter and is skipped; finally the heap is popped into ascending order.  The sequential steps are lane 0's, on
-// the heap in LDS; the lanes fetch and pre-test 64 values at a time.
+// would enter and is skipped; finally the heap is popped into ascending order.  The heap steps are uniform over the
+// wave; the lanes fetch and pre-test 64 values at a time.
 // nth_form (K * 64 > E): ATen ranks with std::nth_element + std::sort instead; the K smallest values are the same,
 // equal values are put in id order here and the row is counted in stat[0] when any tie is present.
-template <int NPL /* values per lane and chunk: CH / 64 */>
+template <int NPL /* values per lane and chunk: CH / 64 */, bool REG /* K <= 64: the heap in registers */>
 __global__ __launch_bounds__(64) void cdist_sim_kernel(const int32_t *__restrict__ rare, int all_rows, int r0, int R, int64_t E, int K,
                                                        const float *__restrict__ vbuf, int64_t vstride,
                                                        const float *__restrict__ cmin, int nchunks,
                                                        uint64_t *__restrict__ out_keys, int nth_form, int32_t *__restrict__ stat) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    float *hv = reinterpret_cast<float *>(smem_raw);
-    int32_t *hid = reinterpret_cast<int32_t *>(hv + K);
     constexpr int CH = 64 * NPL;
     const int nrare = all_rows ? all_rows : rare[0];
     const int t = r0 + (int)blockIdx.x;
@@ -288,84 +322,112 @@ __global__ __launch_bounds__(64) void cdist_sim_kernel(const int32_t *__restrict
     const float *v = vbuf + (int64_t)(t - r0) * vstride;
     const float *cm = cmin + (int64_t)(t - r0) * nchunks;
     const int lane = threadIdx.x;
-    for (int i = lane; i < K; i += 64) { hv[i] = v[i]; hid[i] = i; }
-    __syncthreads();
-    if (lane == 0 && K >= 2)
-        for (int parent = (K - 2) / 2; parent >= 0; --parent) {
-            const float val = hv[parent];
-            const int32_t vid = hid[parent];
-            cdist_heap_adjust(hv, hid, parent, K, val, vid);
-        }
-    __syncthreads();
-    float hmax = hv[0];
+    using heap_t = typename std::conditional<REG, cdist_heap_reg, cdist_heap_lds>::type;
+    heap_t h;
+    h.lane = lane;
+    if constexpr (REG) {
+        h.v = lane < K ? v[lane] : INFINITY;
+        h.id = lane;
+    } else {
+        h.hv = reinterpret_cast<float *>(smem_raw);
+        h.hid = reinterpret_cast<int32_t *>(h.hv + K);
+        for (int i = lane; i < K; i += 64) { h.hv[i] = v[i]; h.hid[i] = i; }
+        __syncthreads();
+    }
+    if (K >= 2)   // std::make_heap
+        for (int parent = (K - 2) / 2; parent >= 0; --parent) cdist_heap_adjust(h, parent, K, h.val(parent), h.idx(parent));
+    float hmax = h.val(0);
     float eq_out = -1.0f;   // nth_form: a value left outside the heap while equal to its maximum (boundary tie if it stays so)
-    for (int c0 = K / CH; c0 < nchunks; c0 += 64) {
-        const float mine = c0 + lane < nchunks ? cm[c0 + lane] : INFINITY;
-        unsigned long long cmask = __ballot(nth_form ? !cdist_less(hmax, mine) : cdist_less(mine, hmax));
-        while (cmask) {
-            const int cl = __builtin_ctzll(cmask);
-            cmask &= cmask - 1;
-            const float cmv = __shfl(mine, cl, 64);
-            if (!(nth_form ? !cdist_less(hmax, cmv) : cdist_less(cmv, hmax))) continue;   // the maximum has dropped since
-            const int64_t base = (int64_t)(c0 + cl) * CH;
-            float x[NPL];
+    // "may hold an element that enters": minimum below the maximum (nth_form: or equal to it, for the boundary-tie count)
+    auto live = [&](float mv) { return nth_form ? !cdist_less(hmax, mv) : cdist_less(mv, hmax); };
+    // one chunk, its values in x (lane l holds ids base + j * 64 + l): in index order, whatever still beats the maximum enters
+    auto process = [&](const float (&x)[NPL], int64_t base) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) x[j] = v[base + j * 64 + lane];
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-                const int64_t e = base + j * 64 + lane;
-                const bool in = e >= K && e < E;
-                if (nth_form) {
-                    const unsigned long long eqm = __ballot(in && x[j] == hmax);
-                    if (eqm) eq_out = hmax;
+        for (int j = 0; j < NPL; ++j) {
+            const int64_t e = base + j * 64 + lane;
+            const bool in = e >= K && e < E;
+            if (nth_form && __ballot(in && x[j] == hmax)) eq_out = hmax;
+            unsigned long long mask = __ballot(in && cdist_less(x[j], hmax));
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                const float val = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x[j]), l));
+                if (cdist_less(val, hmax)) {   // std::__pop_heap(first, middle, i): the maximum leaves, val sinks in from the root
+                    cdist_heap_adjust(h, 0, K, val, (int32_t)(base + j * 64 + l));
+                    const float old = hmax;
+                    hmax = h.val(0);
+                    if (nth_form && old == hmax) eq_out = hmax;   // one of several equal maxima was popped: it now waits outside
                 }
-                unsigned long long mask = __ballot(in && cdist_less(x[j], hmax));
-                while (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    const float val = __shfl(x[j], l, 64);
-                    if (cdist_less(val, hmax)) {
-                        if (lane == 0) cdist_heap_adjust(hv, hid, 0, K, val, (int32_t)(base + j * 64 + l));
-                        __syncthreads();
-                        const float old = hmax;
-                        hmax = hv[0];
-                        if (nth_form && old == hmax) eq_out = hmax;   // one of several equal maxima was popped: it now waits outside
-                        __syncthreads();
-                    }
-                    const unsigned long long later = l == 63 ? 0ull : ~((2ull << l) - 1ull);
-                    mask = __ballot(in && cdist_less(x[j], hmax)) & later;
-                    if (nth_form) {
-                        const unsigned long long eqm = __ballot(in && x[j] == hmax) & later;
-                        if (eqm) eq_out = hmax;
-                    }
+                const unsigned long long later = l == 63 ? 0ull : ~((2ull << l) - 1ull);
+                mask = __ballot(in && cdist_less(x[j], hmax)) & later;
+                if (nth_form && (__ballot(in && x[j] == hmax) & later)) eq_out = hmax;
+            }
+        }
+    };
+    // Chunk minima through LDS, GH_CD_TILE at a time (one round of parallel loads instead of a dependent load per 64
+    // chunks); the next P live chunks are fetched together and then processed in order, each re-tested against the maximum
+    // of its moment.
+    constexpr int P = 4;
+    __shared__ float cml[GH_CD_TILE];
+    for (int tile0 = (K / CH) / GH_CD_TILE * GH_CD_TILE; tile0 < nchunks; tile0 += GH_CD_TILE) {
+        const int nt = min(GH_CD_TILE, nchunks - tile0);
+        __syncthreads();
+        for (int i = lane; i < nt; i += 64) cml[i] = cm[tile0 + i];
+        __syncthreads();
+        int p = max(0, K / CH - tile0);   // next chunk of the tile to look at
+        while (p < nt) {
+            int ids[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                ids[q] = -1;
+                while (p < nt) {
+                    const int b = p & ~63;
+                    const float mv = b + lane < nt ? cml[b + lane] : INFINITY;
+                    const unsigned long long m = __ballot(b + lane < nt && live(mv)) & (~0ull << (p - b));
+                    if (!m) { p = b + 64; continue; }
+                    ids[q] = b + __builtin_ctzll(m);
+                    p = ids[q] + 1;
+                    break;
                 }
             }
+            float x[P][NPL];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                const int64_t base = (int64_t)(tile0 + max(ids[q], 0)) * CH;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) x[q][j] = ids[q] >= 0 ? v[base + j * 64 + lane] : INFINITY;
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+                if (ids[q] >= 0 && live(cml[ids[q]])) process(x[q], (int64_t)(tile0 + ids[q]) * CH);
         }
     }
     // pop the heap into ascending order (std::sort_heap)
-    if (lane == 0)
-        for (int last = K - 1; last > 0; --last) {
-            const float val = hv[last];
-            const int32_t vid = hid[last];
-            hv[last] = hv[0]; hid[last] = hid[0];
-            cdist_heap_adjust(hv, hid, 0, last, val, vid);
-        }
-    __syncthreads();
-    if (nth_form && lane == 0) {
-        bool tie = eq_out == hv[K - 1];
-        for (int i = 0; i + 1 < K; ++i) tie = tie || hv[i] == hv[i + 1];
+    for (int last = K - 1; last > 0; --last) {
+        const float val = h.val(last);
+        const int32_t vid = h.idx(last);
+        h.set(last, h.val(0), h.idx(0));
+        cdist_heap_adjust(h, 0, last, val, vid);
+    }
+    if (nth_form) {
+        bool tie = eq_out == h.val(K - 1);
+        for (int i = 0; i + 1 < K; ++i) tie = tie || h.val(i) == h.val(i + 1);
         if (tie) {
-            atomicAdd(&stat[0], 1);
+            if (lane == 0) atomicAdd(&stat[0], 1);
             for (int i = 1; i < K; ++i) {   // equal values in id order (insertion sort within runs)
-                const float val = hv[i];
-                const int32_t vid = hid[i];
+                const float val = h.val(i);
+                const int32_t vid = h.idx(i);
                 int j = i;
-                while (j > 0 && hv[j - 1] == val && hid[j - 1] > vid) { hv[j] = hv[j - 1]; hid[j] = hid[j - 1]; --j; }
-                hv[j] = val; hid[j] = vid;
+                while (j > 0 && h.val(j - 1) == val && h.idx(j - 1) > vid) { h.set(j, h.val(j - 1), h.idx(j - 1)); h.sync(); --j; }
+                h.set(j, val, vid);
+                h.sync();
             }
         }
     }
-    __syncthreads();
-    for (int i = lane; i < K; i += 64) out_keys[qi * K + i] = gh_key(hv[i], (uint32_t)hid[i]);
+    if constexpr (REG) {
+        if (lane < K) out_keys[qi * K + lane] = gh_key(h.v, (uint32_t)h.id);
+    } else {
+        for (int i = lane; i < K; i += 64) out_keys[qi * K + i] = gh_key(h.hv[i], (uint32_t)h.hid[i]);
+    }
 }
 
 cdist_args make_cdist_args(gh_engine *h) {
@@ -389,9 +451,10 @@ gh_status cdist_dev_alloc(gh_engine *h, T **p, size_t count) {
 // that take further rounds of the two kernels -- every round is launched, an empty one returns at once).
 gh_status gh_cdist_alloc(gh_engine *h) {
     if (!h->cdist || h->S == 0 || h->k == 0) return GH_OK;
-    h->cd_CH = h->E >= (1 << 16) ? 1024 : 256;
+    h->cd_CH = 256;   // ids per chunk minimum (the single wave of cdist_sim_kernel is instruction-bound: with 1024-id chunks it
+                      // tested 16 sub-blocks per live chunk, 1 M vertices: 228 us per iteration for the rows that come here)
     h->cd_nchunks = (int)((h->E + h->cd_CH - 1) / h->cd_CH);
-    const int64_t vstride = (int64_t)h->cd_nchunks * h->cd_CH;
+    const int64_t vstride = ((int64_t)h->cd_nchunks + 3) / 4 * 4 * h->cd_CH;   // whole workgroups of cdist_rows_kernel
     int64_t R = ((int64_t)1 << 30) / std::max<int64_t>(vstride, 1);
     if (R < 16) R = 16;
     if (R > h->S) R = h->S;
@@ -419,17 +482,19 @@ gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows) {
 #undef GH_CSEL
         GH_LAUNCH_CHECK();
     }
-    const int64_t vstride = (int64_t)h->cd_nchunks * h->cd_CH;
+    const int64_t vstride = ((int64_t)h->cd_nchunks + 3) / 4 * 4 * h->cd_CH;
     const int nth_form = (int64_t)h->K * 64 > h->E ? 1 : 0;
     const int all = all_rows ? (int)h->S : 0;
-    unsigned ys = (unsigned)std::max(1, std::min(h->cd_R, 1024 / std::max(h->cd_nchunks, 1)));
+    const int npt = h->E >= (1 << 16) ? 4 : 1;   // chunks per workgroup of cdist_rows_kernel
+    const unsigned nwg = (unsigned)((h->cd_nchunks + npt - 1) / npt);
+    unsigned ys = (unsigned)std::max(1, std::min(h->cd_R, 1024 / (int)std::max(nwg, 1u)));
     for (int r0 = 0; r0 < (int)h->S; r0 += h->cd_R) {
         {
             gh_scope t(h, "cdist_rows");
-            const dim3 grid((unsigned)h->cd_nchunks, ys);
+            const dim3 grid(nwg, ys);
 #define GH_CROWS(LL, NP) cdist_rows_kernel<LL, NP><<<grid, dim3(256), 0, h->stream>>>(a, h->d_rare, all, r0, h->cd_R, h->d_cd_vbuf, \
                                                                                      vstride, h->d_cd_cmin, h->cd_nchunks)
-            if (h->cd_CH == 1024) {
+            if (npt == 4) {
                 if (h->LD == 4) GH_CROWS(4, 4); else if (h->LD == 8) GH_CROWS(8, 4); else if (h->LD == 16) GH_CROWS(16, 4); else GH_CROWS(0, 4);
             } else {
                 if (h->LD == 4) GH_CROWS(4, 1); else if (h->LD == 8) GH_CROWS(8, 1); else if (h->LD == 16) GH_CROWS(16, 1); else GH_CROWS(0, 1);
@@ -438,13 +503,11 @@ gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows) {
             GH_LAUNCH_CHECK();
         }
         gh_scope t(h, "cdist_sim");
-        const size_t smem = (sizeof(float) + sizeof(int32_t)) * (size_t)h->K;
-        if (h->cd_CH == 1024)
-            cdist_sim_kernel<16><<<dim3((unsigned)h->cd_R), dim3(64), smem, h->stream>>>(h->d_rare, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride,
-                                                                                        h->d_cd_cmin, h->cd_nchunks, h->d_partial, nth_form, h->d_cd_stat);
-        else
-            cdist_sim_kernel<4><<<dim3((unsigned)h->cd_R), dim3(64), smem, h->stream>>>(h->d_rare, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride,
-                                                                                       h->d_cd_cmin, h->cd_nchunks, h->d_partial, nth_form, h->d_cd_stat);
+        const size_t smem = h->K <= 64 ? 0 : (sizeof(float) + sizeof(int32_t)) * (size_t)h->K;
+#define GH_CSIM(NPLv, REGv) cdist_sim_kernel<NPLv, REGv><<<dim3((unsigned)h->cd_R), dim3(64), smem, h->stream>>>( \
+        h->d_rare, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride, h->d_cd_cmin, h->cd_nchunks, h->d_partial, nth_form, h->d_cd_stat)
+        if (h->K <= 64) GH_CSIM(4, true); else GH_CSIM(4, false);
+#undef GH_CSIM
         GH_LAUNCH_CHECK();
     }
     h->intersect_done = false;
