@@ -114,6 +114,46 @@ def cpu_baseline(n, D, k, S, edges, pos, budget_s=24.0):
             "torch_cpu": legs["torch_cpu"]}
 
 
+def self_launch(args):
+    """One rank per GPU through torch.distributed.run, supervised: the child's JSON line is passed through; a native-loop
+    attempt that fails or hangs is ended (its whole process group) and repeated with the Python-driven loop."""
+    import signal
+    import socket
+    import subprocess
+
+    def attempt(loop, limit_s):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        argv = [a for a in sys.argv[1:]]
+        if "--loop" in argv:
+            i = argv.index("--loop")
+            del argv[i:i + 2]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv + ["--loop", loop]
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)   # the session this call started: torchrun and its ranks, nothing else
+            proc.wait()
+            return None, f"no result after {limit_s} s"
+        line = next((ln for ln in reversed(out.splitlines()) if ln.startswith("{")), None)
+        if proc.returncode != 0 or line is None:
+            return None, f"exit code {proc.returncode}"
+        return line, None
+
+    line, why = attempt(args.loop, 900)
+    if line is None and args.loop == "native":
+        sys.stderr.write(f"bench.py: native loop failed ({why}); repeating with the Python-driven loop\n")
+        line, why = attempt("python", 900)
+    if line is None:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed: {why}\n")
+        return 1
+    print(line)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +169,17 @@ def main():
     ap.add_argument("--dim", type=int, default=None, help="override the workload's number of components (experiments)")
     ap.add_argument("--dist", action="store_true",
                     help="use the multi-GPU driver (RCCL collectives) even for one rank: rehearsal of the N>1 path")
+    ap.add_argument("--loop", default="python", choices=["python", "native"],
+                    help="N > 1: 'python' drives each iteration's kernels and collectives through torch.distributed (RCCL); "
+                         "'native' = gh_run_partitioned, the loop inside the C library over its own RCCL communicator "
+                         "(opt-in until a world > 1 run has passed on hardware)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed passes of --steps iterations; the median is reported")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks here, as children, BEFORE anything of this process
+    # touches a GPU (a process that has initialised HIP must not be replaced or re-executed; torch is not even imported yet)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -157,7 +207,7 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, rank=rank, world=world,
-                                device_id=local_rank)
+                                device_id=local_rank, native=args.loop == "native")
         lay.set_positions(pos)
         run = lay.run
         sync = lay.sync
@@ -180,20 +230,24 @@ def main():
             return None
 
     run(args.warmup)
-    sync()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    sync()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    passes = []
+    for _ in range(max(1, args.repeats)):   # median of 3 repeats; every pass is exactly --steps iterations
+        sync()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        sync()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            import torch.distributed as dist
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        passes.append(dt)
+    dt = sorted(passes)[len(passes) // 2]
 
     # per-kernel durations with HIP events on the launching stream: a second pass of the same K steps
     eng.timing_enable(True)
@@ -249,6 +303,7 @@ def main():
         out = {
             "metric": "layout iterations/s", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "repeats": len(passes), "ms_per_step_passes": [1e3 * p / args.steps for p in passes],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "graph": WORKLOADS[args.workload][0], "n_vertices": n,
