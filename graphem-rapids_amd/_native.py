@@ -25,7 +25,7 @@ SYMBOLS = [
     "gh_step_finish_gathered", "gh_vertex_order", "gh_positions_unpadded_device", "gh_radial_topk",
     "gh_comm_unique_id", "gh_comm_init_rccl", "gh_loopback_group_create", "gh_loopback_group_destroy",
     "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error", "gh_debug_stamps",
-    "gh_knn_cdist_stats",
+    "gh_knn_cdist_stats", "gh_rank_layout", "gh_step_finish_own", "gh_comm_available",
 ]
 
 
@@ -89,6 +89,12 @@ def load():
     L.gh_positions_unpadded_device.restype = vp
     L.gh_gather_layout.argtypes = [vp, i32, i32, i64]
     L.gh_gather_layout.restype = ctypes.c_int
+    L.gh_rank_layout.argtypes = [vp, i32, i32, i64]
+    L.gh_rank_layout.restype = ctypes.c_int
+    L.gh_step_finish_own.argtypes = [vp, vp, i32]
+    L.gh_step_finish_own.restype = ctypes.c_int
+    L.gh_comm_available.argtypes = []
+    L.gh_comm_available.restype = i32
     L.gh_gather_buffer_device.argtypes = [vp]
     L.gh_gather_buffer_device.restype = vp
     L.gh_gather_slot_bytes.argtypes = [vp]
@@ -318,6 +324,12 @@ class Engine:
     def gather_layout(self, world, rank, chunk):
         self._chk(self.lib.gh_gather_layout(self.handle, int(world), int(rank), int(chunk)))
 
+    def rank_layout(self, world, rank, chunk):
+        self._chk(self.lib.gh_rank_layout(self.handle, int(world), int(rank), int(chunk)))
+
+    def step_finish_own(self, stats_all_ptr, world):
+        self._chk(self.lib.gh_step_finish_own(self.handle, ctypes.c_void_p(stats_all_ptr), int(world)))
+
     def gather_buffer_device_ptr(self):
         return self.lib.gh_gather_buffer_device(self.handle)
 
@@ -406,6 +418,11 @@ def comm_unique_id():
     if st != GH_OK:
         raise RuntimeError(load().gh_comm_last_error().decode())
     return buf.raw
+
+
+def comm_available():
+    """True when librccl.so opens with every entry point the native loop uses (no communicator is made)."""
+    return bool(load().gh_comm_available())
 
 
 def device_count():

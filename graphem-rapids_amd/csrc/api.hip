@@ -76,7 +76,7 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_rare, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_stats_comb, h->d_rare, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -504,8 +504,16 @@ static gh_status check_device_waits(gh_engine *h) {
     GH_HIP(hipMemcpyAsync(&failed, h->d_wait_failed, sizeof(failed), hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipStreamSynchronize(h->stream));
     if (failed) {
+        // reported once: the flag is cleared, the published-queries counter is put where the next launch expects it and
+        // the engine goes on with the thresholds as a launch of their own (no workgroup waits for another any more)
+        GH_HIP(hipMemsetAsync(h->d_wait_failed, 0, sizeof(int32_t), h->stream));
+        GH_HIP(hipMemcpyAsync(h->d_tau_flag, &h->tau_epoch, sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+        GH_HIP(hipStreamSynchronize(h->stream));
+        h->tau_embedded = false;
         h->err = "a workgroup of the fused spring+scan launch timed out waiting for the thresholds of its own launch; "
-                 "results since the last check are invalid (set GRAPHEM_HIP_TAU_SEPARATE=1 and report this)";
+                 "results since the last successful gh_sync / gh_get_positions are invalid -- set the positions again. "
+                 "The engine now computes the thresholds in a launch of their own (as GRAPHEM_HIP_TAU_SEPARATE=1 does); "
+                 "please report this";
         return GH_ERR_RUNTIME;
     }
     return GH_OK;
@@ -541,7 +549,7 @@ static bool whole_graph(gh_engine *h) {
 // gh_step / gh_run / the per-phase entry points merge with world = 1 and normalise with the own rows'
 // statistics: on a row partition that would silently corrupt the positions.
 static gh_status check_whole(gh_engine *h, const char *what) {
-    if (whole_graph(h) && !h->d_gbuf) return GH_OK;
+    if (whole_graph(h) && !h->d_gbuf && !h->g_world) return GH_OK;
     h->err = std::string(what) + " needs the whole graph on one rank; a partitioned engine runs gh_step_begin / "
              "gh_step_merge / gh_step_finish_gathered (or gh_run_partitioned)";
     return GH_ERR_INVALID;
@@ -730,7 +738,7 @@ extern "C" gh_status gh_gather_layout(gh_handle h, int32_t world, int32_t rank, 
         h->err = "gather layout does not match the engine's row partition";
         return GH_ERR_INVALID;
     }
-    if (h->d_gbuf) { h->err = "gather layout already set"; return GH_ERR_INVALID; }
+    if (h->d_gbuf || h->g_world) { h->err = "rank / gather layout already set"; return GH_ERR_INVALID; }
     if (h->cdist) { h->err = "GH_DIST_CDIST engines do not take a gather layout"; return GH_ERR_INVALID; }
     const int64_t stats_bytes = (int64_t)sizeof(double) * (2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
     const int64_t slot = (chunk * h->LD * (int64_t)sizeof(float) + stats_bytes + 15) / 16 * 16;
@@ -741,6 +749,27 @@ extern "C" gh_status gh_gather_layout(gh_handle h, int32_t world, int32_t rank, 
     h->d_new = reinterpret_cast<float *>(h->d_gbuf + rank * slot);
     h->d_stats = reinterpret_cast<double *>(h->d_gbuf + rank * slot + chunk * h->LD * (int64_t)sizeof(float));
     h->g_slot = slot; h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
+    return GH_OK;
+}
+extern "C" gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk) {
+    GH_TRY(check_handle(h));
+    if (world < 1 || rank < 0 || rank >= world || chunk < 1 || chunk * world < h->n || chunk * world > h->pos_rows ||
+        h->part.row_lo != std::min<int64_t>(h->n, rank * chunk) || h->part.row_hi != std::min<int64_t>(h->n, (rank + 1) * chunk)) {
+        h->err = "rank layout does not match the engine's row partition";
+        return GH_ERR_INVALID;
+    }
+    if (h->d_gbuf || h->g_world) { h->err = "rank / gather layout already set"; return GH_ERR_INVALID; }
+    if (h->cdist) { h->err = "GH_DIST_CDIST engines do not take a rank layout"; return GH_ERR_INVALID; }
+    GH_TRY(dev_alloc(h, &h->d_stats_comb, (size_t)2 * h->LD, true));
+    h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
+    return GH_OK;
+}
+extern "C" gh_status gh_step_finish_own(gh_handle h, const double *stats_all, int32_t world) {
+    GH_TRY(check_handle(h));
+    if (!h->d_stats_comb || h->d_gbuf) { h->err = "gh_rank_layout has not been called"; return GH_ERR_INVALID; }
+    if (!stats_all || world != h->g_world) { h->err = "bad statistics buffer / world size"; return GH_ERR_INVALID; }
+    GH_TRY(gh_launch_normalise_own(h, stats_all, world));
+    h->iter += 1;
     return GH_OK;
 }
 extern "C" void *gh_gather_buffer_device(gh_handle h) { return h ? h->d_gbuf : nullptr; }

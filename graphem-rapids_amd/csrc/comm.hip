@@ -1,7 +1,9 @@
 // The partitioned layout loop without the host language in it:
 // gh_run_partitioned enqueues, per iteration, part 1 (spring pull + KNN scan of the own rows / edges), the
-// all-gather of the ranks' S x (k+1) keys, part 2 (merge, intersection forces, integrate own rows), the
-// in-place all-gather of the ranks' slots (new rows + column statistics) and part 3 (normalise all n rows) --
+// all-gather of the ranks' S x (k+1) keys, part 2 (merge, intersection forces, integrate own rows) and then
+//   form C (gh_rank_layout):   all-gather of the ranks' column statistics (a few hundred bytes), normalise the OWN rows,
+//                              in-place all-gather of the finished position blocks;
+//   form B (gh_gather_layout): in-place all-gather of the ranks' slots (new rows + statistics), normalise all n rows --
 // kernels and collectives on ONE stream, no host synchronisation inside the loop.
 //
 // Collective backends behind one small interface:
@@ -71,17 +73,25 @@ struct gh_loop_group {
     std::vector<const void *> send;
     bool failed = false;
 
-    // every rank calls with the same sequence of collectives; returns after all ranks arrived
-    void barrier() {
+    // every rank calls with the same sequence of collectives; returns true after all ranks arrived, false once any rank
+    // has poisoned the group (a rank that failed will never arrive: the others must not wait for it)
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (failed) return false;
         const uint64_t gen = generation;
         if (++arrived == world) {
             arrived = 0;
             ++generation;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            cv.wait(lk, [&] { return generation != gen || failed; });
         }
+        return !failed;
+    }
+    void poison() {
+        std::lock_guard<std::mutex> lk(mu);
+        failed = true;
+        cv.notify_all();
     }
 };
 
@@ -90,6 +100,7 @@ struct gh_comm {
     ncclComm_t nccl = nullptr;          // RCCL backend
     gh_loop_group *loop = nullptr;      // loopback backend
     uint64_t *d_gathered = nullptr;     // (world, S, K) keys of all ranks
+    double *d_stats_all = nullptr;      // (world, stats rows, LD) statistics of all ranks (form C)
 };
 
 static gh_status comm_all_gather(gh_engine *h, const void *send, void *recv, size_t bytes, const char *what) {
@@ -103,23 +114,26 @@ static gh_status comm_all_gather(gh_engine *h, const void *send, void *recv, siz
     // loopback: what the ranks send must be complete before anybody copies it, and nobody may start
     // overwriting its send buffer (the next iteration) before everybody has copied
     gh_loop_group *g = c->loop;
-    GH_HIP(hipStreamSynchronize(h->stream));
+    auto fail = [&](const char *msg) { g->poison(); h->err = msg; return GH_ERR_RUNTIME; };
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("loopback all-gather: stream synchronisation failed");
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->send[(size_t)c->rank] = send;
     }
-    g->barrier();
+    if (!g->barrier()) { h->err = "loopback all-gather: another rank of the group failed"; return GH_ERR_RUNTIME; }
     for (int r = 0; r < c->world; ++r) {
         void *dst = static_cast<unsigned char *>(recv) + (size_t)r * bytes;
         const void *src = g->send[(size_t)r];
-        if (dst != src) GH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream));
+        if (dst != src && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return fail("loopback all-gather: copy failed");
     }
-    GH_HIP(hipStreamSynchronize(h->stream));
-    g->barrier();
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("loopback all-gather: stream synchronisation failed");
+    if (!g->barrier()) { h->err = "loopback all-gather: another rank of the group failed"; return GH_ERR_RUNTIME; }
     return GH_OK;
 }
 
 extern "C" const char *gh_comm_last_error(void) { return g_comm_error.c_str(); }
+
+extern "C" int32_t gh_comm_available(void) { return rccl()->err.empty() && rccl()->lib ? 1 : 0; }
 
 extern "C" gh_status gh_comm_unique_id(void *out128) {
     if (!out128) { g_comm_error = "out is NULL"; return GH_ERR_INVALID; }
@@ -134,17 +148,20 @@ extern "C" gh_status gh_comm_unique_id(void *out128) {
 
 static gh_status comm_common(gh_engine *h, int world, int rank) {
     if (h->comm) { h->err = "a communicator is already attached"; return GH_ERR_INVALID; }
-    if (!h->d_gbuf || h->g_world != world || h->g_rank != rank) {
-        h->err = "call gh_gather_layout(world, rank, chunk) first, with the same world and rank";
+    if (h->g_world != world || h->g_rank != rank) {
+        h->err = "call gh_rank_layout (or gh_gather_layout) with the same world and rank first";
         return GH_ERR_INVALID;
     }
     h->comm = new (std::nothrow) gh_comm();
     if (!h->comm) { h->err = "out of host memory"; return GH_ERR_NOMEM; }
     h->comm->world = world;
     h->comm->rank = rank;
-    if (hipMalloc(reinterpret_cast<void **>(&h->comm->d_gathered), sizeof(uint64_t) * (size_t)world * h->S * h->K + 16) != hipSuccess) {
+    const size_t stats_doubles = (size_t)world * (2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
+    if (hipMalloc(reinterpret_cast<void **>(&h->comm->d_gathered), sizeof(uint64_t) * (size_t)world * h->S * h->K + 16) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&h->comm->d_stats_all), sizeof(double) * stats_doubles + 16) != hipSuccess) {
+        if (h->comm->d_gathered) (void)hipFree(h->comm->d_gathered);
         delete h->comm; h->comm = nullptr;
-        h->err = "hipMalloc of the gathered key buffer failed";
+        h->err = "hipMalloc of the gather buffers failed";
         return GH_ERR_NOMEM;
     }
     return GH_OK;
@@ -163,6 +180,7 @@ extern "C" gh_status gh_comm_init_rccl(gh_handle h, int32_t world, int32_t rank,
     if (r != ncclSuccess) {
         h->err = std::string("ncclCommInitRank: ") + api->GetErrorString(r);
         (void)hipFree(h->comm->d_gathered);
+        (void)hipFree(h->comm->d_stats_all);
         delete h->comm; h->comm = nullptr;
         return GH_ERR_RUNTIME;
     }
@@ -192,6 +210,7 @@ void gh_comm_free(gh_engine *h) {
     if (!h->comm) return;
     if (h->comm->nccl) (void)rccl()->CommDestroy(h->comm->nccl);
     if (h->comm->d_gathered) (void)hipFree(h->comm->d_gathered);
+    if (h->comm->d_stats_all) (void)hipFree(h->comm->d_stats_all);
     delete h->comm;
     h->comm = nullptr;
 }
@@ -213,16 +232,30 @@ extern "C" gh_status gh_run_partitioned(gh_handle h, int32_t iters, const int32_
     const size_t key_bytes = sizeof(uint64_t) * (size_t)h->S * h->K;
     const int32_t *d_ids = nullptr;
     GH_TRY_ST(gh_upload_sample_stream(h, iters, sample_stream, &d_ids));   // nullptr: device sampler / arange on every rank
-    for (int32_t t = 0; t < iters; ++t) {
-        GH_TRY_ST(gh_step_begin_device_ids(h, d_ids ? d_ids + (size_t)t * h->S : nullptr));
-        if (h->S > 0 && h->k > 0) {
-            GH_TRY_ST(comm_all_gather(h, h->d_partial, c->d_gathered, key_bytes, "allgather_keys"));
-            GH_TRY_ST(gh_step_merge(h, c->d_gathered, c->world));
-        } else {
-            GH_TRY_ST(gh_step_merge(h, h->d_partial, 1));   // spring forces only: nothing to merge
+    // a rank that fails leaves the loop: the loopback group must not wait for it (RCCL has its own abort paths)
+    auto run = [&]() -> gh_status {
+        const size_t stats_bytes = sizeof(double) * (size_t)(2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
+        for (int32_t t = 0; t < iters; ++t) {
+            GH_TRY_ST(gh_step_begin_device_ids(h, d_ids ? d_ids + (size_t)t * h->S : nullptr));
+            if (h->S > 0 && h->k > 0) {
+                GH_TRY_ST(comm_all_gather(h, h->d_partial, c->d_gathered, key_bytes, "allgather_keys"));
+                GH_TRY_ST(gh_step_merge(h, c->d_gathered, c->world));
+            } else {
+                GH_TRY_ST(gh_step_merge(h, h->d_partial, 1));   // spring forces only: nothing to merge
+            }
+            if (h->d_gbuf) {   // form B
+                GH_TRY_ST(comm_all_gather(h, h->d_gbuf + (size_t)c->rank * h->g_slot, h->d_gbuf, (size_t)h->g_slot, "allgather_slots"));
+                GH_TRY_ST(gh_step_finish_gathered(h));
+            } else {           // form C
+                GH_TRY_ST(comm_all_gather(h, h->d_stats, c->d_stats_all, stats_bytes, "allgather_stats"));
+                GH_TRY_ST(gh_step_finish_own(h, c->d_stats_all, c->world));
+                const size_t block = sizeof(float) * (size_t)h->g_chunk * h->LD;
+                GH_TRY_ST(comm_all_gather(h, reinterpret_cast<unsigned char *>(h->d_pos) + (size_t)c->rank * block, h->d_pos, block, "allgather_rows"));
+            }
         }
-        GH_TRY_ST(comm_all_gather(h, h->d_gbuf + (size_t)c->rank * h->g_slot, h->d_gbuf, (size_t)h->g_slot, "allgather_slots"));
-        GH_TRY_ST(gh_step_finish_gathered(h));
-    }
-    return GH_OK;
+        return GH_OK;
+    };
+    const gh_status st = run();
+    if (st != GH_OK && c->loop) c->loop->poison();
+    return st;
 }

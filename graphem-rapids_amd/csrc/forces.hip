@@ -512,6 +512,24 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
     }
 }
 
+// Form C of a partitioned step: every rank's statistics rows (sum, sum of squares, then its correction row pairs),
+// all-gathered in rank order -> one (2, LD) record: per rank its rows in their fixed order, then the ranks in rank order,
+// so every rank derives the same mean / std bits.  One workgroup, thread = (base, column).
+__global__ __launch_bounds__(64) void stats_combine_kernel(const double *__restrict__ all, int world, int R /* rows per rank */,
+                                                          int LD, double *__restrict__ out) {
+    const int t = threadIdx.x;
+    if (t >= 2 * LD) return;
+    const int base = t / LD, col = t % LD;
+    double tot = 0.0;
+    for (int r = 0; r < world; ++r) {
+        const double *st = all + (int64_t)r * R * LD;
+        double v = st[base * LD + col];
+        for (int b = 2 + base; b < R; b += 2) v += st[b * LD + col];
+        tot += v;
+    }
+    out[t] = tot;
+}
+
 // pt.py:796-799 with given force arrays (per-phase entry point gh_integrate_normalise).
 __global__ __launch_bounds__(256) void integrate_given_kernel(const float *__restrict__ pos,
                                                              const float *__restrict__ Fs,
@@ -859,6 +877,32 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
         h->presetup_ids = next_mode == 0 ? next_ids : h->d_sampled;
         h->presetup_iter = h->iter + 1;
     }
+    return GH_OK;
+}
+
+// Form C: normalise the own rows into their block of d_pos from the ranks' gathered statistics; also zeroes what the
+// intersection phase touched.  No set-up for the next iteration here: the other ranks' rows arrive with the caller's
+// all-gather of the position blocks.
+gh_status gh_launch_normalise_own(gh_engine *h, const double *stats_all, int world) {
+    h->presetup_valid = false;
+    const int R = 2 + 2 * gh_fix_blocks(h->LD);
+    if (2 * h->LD > 64) { h->err = "row stride too large for the partitioned finish"; return GH_ERR_INVALID; }
+    {
+        gh_scope t(h, "stats_combine");
+        stats_combine_kernel<<<dim3(1), dim3(64), 0, h->stream>>>(stats_all, world, R, h->LD, h->d_stats_comb);
+        GH_LAUNCH_CHECK();
+    }
+    if (h->rows == 0) return gh_launch_inter_cleanup(h);
+    gh_scope t(h, "normalise_own");
+    const int64_t total = h->rows * h->LD / 4;
+    unsigned grid = grid_for(total, 1024);
+    if (grid > 2048) grid = 2048;
+    const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * (size_t)h->LD;
+    gh_setup_args sa{};
+    normalise_kernel<0><<<dim3(grid), dim3(256), smem, h->stream>>>(
+        h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats_comb, h->d_pos, h->d_acc, h->d_tflag, h->d_touched,
+        h->d_tcount, 0, (int)grid, 0, sa, h->d_qexact, nullptr);
+    GH_LAUNCH_CHECK();
     return GH_OK;
 }
 

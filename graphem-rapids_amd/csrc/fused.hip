@@ -1,11 +1,11 @@
 // Fused spring + KNN scan: the dominant kernel of an iteration.
 //
-// Why fused: the spring pull is bound by the chip's random-line fetch rate (8 neighbour rows
-// of 16 bytes per vertex, each a 128-byte line from the Infinity Cache: ~64 G lines/s), the
-// KNN scan by the fp32 VALU.  As separate kernels they run back to back (measured 166 + 153 us
-// on the 1M-vertex graph) and the midpoints make a round trip through HBM.  Here one workgroup
-// owns a range of vertices holding at most TILE owned edges (edge (u, v), u < v, is owned by
-// u; the edge list is sorted by first endpoint so the range is contiguous):
+// Why fused: the spring pull is bound by the chip's rate for random row requests (8 neighbour rows
+// of 16 bytes per vertex, ~65-73 G rows/s whatever the byte rate), the KNN scan by the matrix pipe /
+// the fp32 VALU.  As separate kernels they run back to back (146 + 110 us on the 1M-vertex graph) and
+// the midpoints make a round trip through memory.  Here one workgroup owns a range of consecutive own
+// rows holding at most TILE owned edges (an edge is owned by ONE of its endpoints -- by a hash of the
+// edge id, or by endpoint 0 for range partitions; bit 31 of a pull-list entry marks the edges a row owns):
 //   phase A  spring pull of its vertices (reference pt.py:595-636, summation order of the
 //            two index_add_ calls) -> Fs; the midpoints (pt.py:785) of the owned edges fall
 //            out of the gathered rows and are kept in LDS, never written to memory;
@@ -731,6 +731,7 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
     if (h->n_vblocks == 0) return GH_OK;
     GH_TRY_ST(gh_launch_spring_long(h, h->d_Fs, 0));  // hubs first: their rows' forces are read back in phase A
     gh_scope t(h, "spring_scan");
+    const unsigned epoch_before = h->tau_epoch;   // fused_tau_args() below moves it by S for the launch it prepares
     int nt, r;
     fused_cfg(h->LD, h->D, h->S, h->own_count, &nt, &r);
 #define GH_FUSED_D(NTT, RR)                                   \
@@ -789,7 +790,11 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
         return GH_ERR_RUNTIME;
     }
 #undef GH_FUSED_D
-    GH_LAUNCH_CHECK();
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+        h->tau_epoch = epoch_before;   // nothing was launched: the published-queries counter has not moved
+        h->err = std::string("kernel launch: ") + hipGetErrorString(e);
+        return GH_ERR_HIP;
+    }
     h->new0_ready = true;  // d_new = pos + Fs and d_blockstats[n_vblocks] are in place
     return GH_OK;
 }

@@ -13,22 +13,22 @@ most of the edges).  Every rank holds all n positions and the whole edge list.  
                       sampled midpoints among the OWN edges -> S x (k+1) keys
     gather  (RCCL)    all-gather of the keys                       S*(k+1)*8 B per rank
     part 2  (local)   merge keys -> global KNN; intersection forces (redundant on every rank,
-                      O(S*k)); integrate own rows; own column sums -- rows and sums land side
-                      by side in this rank's slot of the gather buffer
-    gather  (RCCL)    in-place all-gather of the slots    chunk*ld*4 B + 18*ld*8 B per rank
-    part 3  (local)   normalise ALL n rows from the gathered slots; the per-rank column sums are
-                      added in rank order, so every rank derives the same mean / std
+                      O(S*k)); integrate own rows; own column sums
+  finish="own" (default; nothing passes over all n rows):
+    gather  (RCCL)    all-gather of the ranks' column statistics          18*ld*8 B per rank
+    part 3  (local)   normalise the OWN rows into their block of the position array; the per-rank sums
+                      are added in rank order, so every rank derives the same mean / std
+    gather  (RCCL)    in-place all-gather of the finished position blocks     chunk*ld*4 B per rank
+  finish="gathered" (two collectives, every rank normalises all n rows -- 22-51 us per rank at 1 M vertices):
+    gather  (RCCL)    in-place all-gather of slots [un-normalised rows | statistics]
+    part 3  (local)   normalise ALL n rows from the gathered slots
 
-Two collectives per iteration: shipping the un-normalised rows together with the statistics
-spares the separate all-reduce (normalising n instead of n/world rows costs a few microseconds,
-a collective tens).
-
-With the product engine the loop itself runs in the C library (`native=True`, the default there):
-gh_run_partitioned (csrc/comm.hip) enqueues kernels and ncclAllGather calls of all iterations on one
-stream -- RCCL opened by the library itself, its communicator bootstrapped here by broadcasting rank 0's
-unique id through torch.distributed.  The Python-driven step below (three ctypes calls and two
-torch.distributed collectives per iteration: +100 us per iteration measured at world = 1) remains for
-injected engines and as a cross-check.
+The loop can also run inside the C library (`native=True`): gh_run_partitioned (csrc/comm.hip) enqueues kernels
+and ncclAllGather calls of all iterations on one stream -- RCCL opened by the library itself, its communicator
+bootstrapped here by broadcasting rank 0's unique id through torch.distributed (+14 us per iteration at world = 1
+against +100 us for the Python-driven step).  It is OPT-IN: ncclCommInitRank / ncclAllGather with more than one rank
+have not run on hardware yet (the development boxes have one GPU and RCCL refuses two ranks on one device); the
+Python-driven step below, on torch.distributed's own communicator, is the default.
 
 The sample ids are the same on every rank: either passed in, or drawn by the engine's counter
 based sampler from (seed, iteration).  The compute engine is injectable so that the collective
@@ -74,7 +74,7 @@ def long_degree(n, n_edges):
     return 16 if (n_edges <= (1 << 20) and 2 * n_edges >= 24 * n) else LONG_DEG
 
 
-def owned_edge_ids(edges, row_lo, row_hi, n=None):
+def owned_edge_ids(edges, row_lo, row_hi, n):
     """Ids of the edges a rank with rows [row_lo, row_hi) owns under the hashed rule (vertex numbers as
     given: an engine that reorders vertices internally partitions its internal rows the same way).
     An edge between a hub and a short row belongs to the short row, one between two hubs of different degree to the
@@ -83,7 +83,7 @@ def owned_edge_ids(edges, row_lo, row_hi, n=None):
     second = edge_owner_is_second(np.arange(len(edges)))
     if len(edges):
         deg = np.bincount(edges.ravel())
-        is_hub = deg > long_degree(len(deg) if n is None else n, len(edges))
+        is_hub = deg > long_degree(n, len(edges))   # n as the engine sees it (trailing isolated vertices count)
         hub_u, hub_v = is_hub[edges[:, 0]], is_hub[edges[:, 1]]
         if is_hub.any():
             du, dv = deg[edges[:, 0]], deg[edges[:, 1]]
@@ -94,8 +94,10 @@ def owned_edge_ids(edges, row_lo, row_hi, n=None):
 
 
 class HipShardEngine:
-    """The product engine of one rank: libgraphem_hip.so on this rank's GPU, torch tensor views
-    of its device buffers, all work on torch's current stream."""
+    """The product engine of one rank: libgraphem_hip.so on this rank's GPU and torch tensor views of its device
+    buffers.  Python-driven steps run on torch's current stream (stream-ordered with torch.distributed's collectives);
+    the native loop runs on the engine's own stream and run_partitioned() returns only when it has drained, so the
+    views are safe to read afterwards."""
 
     def __init__(self, n, D, edges, L_min, k_attr, k_inter, k, S, seed, partition, device_id):
         from . import _native
@@ -119,6 +121,17 @@ class HipShardEngine:
         e.gather_layout(world, rank, chunk)
         self.gbuf = device_view(e.gather_buffer_device_ptr(), (world, e.gather_slot_bytes()), torch.uint8, self.device, e)
         self.stats = device_view(e.stats_partial_device_ptr(), (e.stats_rows(), e.ld), torch.float64, self.device, e)
+
+    def rank_layout(self, world, rank, chunk):
+        """finish="own": per-rank statistics gathered into stats_all, position blocks gathered in place in pos."""
+        e = self.eng
+        e.rank_layout(world, rank, chunk)
+        self.world, self.rank, self.chunk = world, rank, chunk
+        self.stats_all = torch.zeros((world, e.stats_rows(), e.ld), dtype=torch.float64, device=self.device)
+        self.pos_blocks = self.pos[: world * chunk].view(world, chunk * e.ld)
+
+    def step_finish_own(self, stats_all):
+        self.eng.step_finish_own(stats_all.data_ptr(), self.world)
 
     def step_finish_gathered(self):
         self.eng.step_finish_gathered()
@@ -148,11 +161,13 @@ class HipShardEngine:
 
     def run_partitioned(self, iters, sample_stream=None):
         self.eng.run_partitioned(iters, sample_stream)
+        self.eng.sync()   # the engine's own stream: torch knows nothing of it, so nothing may be pending when we return
 
 
 class PartitionedLayout:
     def __init__(self, n, D, edges, L_min=1.0, k_attr=0.2, k_inter=0.5, n_neighbors=10, sample_size=256, seed=0,
-                 rank=None, world=None, device_id=0, engine_factory=None, group=None, edge_ownership="auto", native=None):
+                 rank=None, world=None, device_id=0, engine_factory=None, group=None, edge_ownership="auto", native=False,
+                 finish="own"):
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.group = group
@@ -172,12 +187,18 @@ class PartitionedLayout:
         factory = engine_factory or HipShardEngine
         self.engine = factory(self.n, self.D, edges, L_min, k_attr, k_inter, n_neighbors, min(sample_size, len(edges)),
                               seed, part, device_id)
-        self.engine.gather_layout(self.world, self.rank, self.chunk)
+        if finish not in ("own", "gathered"):
+            raise ValueError(f"finish must be 'own' or 'gathered', got {finish!r}")
+        self.finish = finish
+        if finish == "own":
+            self.engine.rank_layout(self.world, self.rank, self.chunk)
+        else:
+            self.engine.gather_layout(self.world, self.rank, self.chunk)
         self.K = n_neighbors + 1
         self.S = min(sample_size, len(edges))
         self.gathered = torch.empty((self.world, self.S, self.K), dtype=torch.int64, device=self.engine.pos.device)
-        # the loop in the C library over RCCL whenever the engine offers it (the product engine does)
-        self.native = hasattr(self.engine, "comm_init_rccl") if native is None else bool(native)
+        # the loop in the C library over its own RCCL communicator: opt-in (module docstring)
+        self.native = bool(native) and hasattr(self.engine, "comm_init_rccl")
         if self.native:
             self.native = self._init_native_comm()
 
@@ -199,12 +220,10 @@ class PartitionedLayout:
             src = 0 if self.group is None else dist.get_global_rank(self.group, 0)
             dist.broadcast(uid, src=src, group=self.group)
         host = uid.cpu().numpy()
-        # every rank must be able to open RCCL and make an id of its own BEFORE anybody enters the collective
-        # ncclCommInitRank (a rank that fails there would leave the others waiting inside it)
+        # every rank must be able to open RCCL BEFORE anybody enters the collective ncclCommInitRank (a rank that fails
+        # there would leave the others waiting inside it)
         ready = torch.ones(1, dtype=torch.int32, device=dev)
-        try:
-            _native.comm_unique_id()
-        except RuntimeError:
+        if not _native.comm_available():
             ready.zero_()
         if host[128] != 1:
             ready.zero_()
@@ -243,6 +262,12 @@ class PartitionedLayout:
         # output in concatenated form (world*S, K): accepted by both the RCCL and the gloo backend
         dist.all_gather_into_tensor(self.gathered.view(self.world * self.S, self.K), e.partial, group=self.group)
         e.step_merge(self.gathered, self.world)
+        if self.finish == "own":
+            dist.all_gather_into_tensor(e.stats_all.view(-1), e.stats.view(-1), group=self.group)   # concatenated form: RCCL and gloo
+            e.step_finish_own(e.stats_all)
+            # in-place all-gather of the finished blocks: rank r's rows are block r of the position array
+            dist.all_gather_into_tensor(e.pos_blocks.view(-1), e.pos_blocks[self.rank], group=self.group)
+            return
         # in-place all-gather of the slots: rank r's new rows + statistics sit in row r of gbuf
         dist.all_gather_into_tensor(e.gbuf.view(-1), e.gbuf[self.rank], group=self.group)
         e.step_finish_gathered()

@@ -196,10 +196,21 @@ void *gh_gather_buffer_device(gh_handle h);
 int64_t gh_gather_slot_bytes(gh_handle h);
 gh_status gh_step_finish_gathered(gh_handle h);
 
+/* Part 3, form C (the default of the drivers; no pass over all n rows): the rank keeps its un-normalised rows to itself,
+ * the caller all-gathers only the ranks' STATISTICS (gh_stats_rows * ld doubles each, rank order), every rank
+ * normalises ITS rows into its block of the position array -- per-rank sums added in rank order, so all ranks use the
+ * same mean / std bits -- and the caller then all-gathers the finished blocks IN PLACE in gh_positions_device():
+ * block r = rows [r*chunk, (r+1)*chunk), chunk * ld floats (gh_positions_rows_allocated() >= world * chunk).
+ *   gh_rank_layout(h, world, rank, chunk)   once after gh_create (instead of gh_gather_layout)
+ *   gh_step_finish_own(h, stats_all, world) stats_all: (world, gh_stats_rows, ld) doubles, device
+ * The position array is complete again only after the caller's all-gather. */
+gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk);
+gh_status gh_step_finish_own(gh_handle h, const double *stats_all, int32_t world);
+
 /* ---- the whole partitioned run as ONE call (no host language in the loop) ----------------------
- * After gh_create(partition) + gh_gather_layout(world, rank, chunk) + one of the communicator calls,
- * gh_run_partitioned enqueues `iters` iterations -- part 1, all-gather of the keys, part 2, in-place
- * all-gather of the slots, part 3 -- on the handle's stream; only the collective backend may block.
+ * After gh_create(partition) + gh_rank_layout(world, rank, chunk) (form C: all-gathers of the keys, of the statistics
+ * and, in place, of the finished position blocks) or gh_gather_layout (form B: keys, slots) + one of the communicator
+ * calls, gh_run_partitioned enqueues `iters` iterations on the handle's stream; only the collective backend may block.
  * Every rank must call it with the same iters and the same sample_stream ((iters, S) host ids, or NULL:
  * each rank's engine then draws identical ids from (seed, iteration)).
  *   gh_comm_unique_id        rank 0: 128 bytes to hand to every rank (ncclGetUniqueId)
@@ -210,6 +221,7 @@ gh_status gh_step_finish_gathered(gh_handle h);
  *                            the same loop on a single GPU (where RCCL refuses two ranks on one device)
  * Kernel and collective times appear under gh_timing_get as "allgather_keys" / "allgather_slots". */
 typedef struct gh_loop_group gh_loop_group;
+int32_t gh_comm_available(void);         /* 1 when librccl.so opens and has every entry point used here (no communicator made) */
 gh_status gh_comm_unique_id(void *out128);
 gh_status gh_comm_init_rccl(gh_handle h, int32_t world, int32_t rank, const void *unique_id128);
 gh_loop_group *gh_loopback_group_create(int32_t world);

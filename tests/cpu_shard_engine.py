@@ -18,7 +18,7 @@ class CpuShardEngine:
         self.row_lo, self.row_hi, edge_lo, edge_hi = partition[:4]
         if len(partition) > 4 and partition[4] == 1:  # hashed ownership (include/graphem_hip.h GH_EDGES_HASHED)
             from graphem_rapids_amd.distributed import owned_edge_ids
-            self.own_ids = owned_edge_ids(self.edges, self.row_lo, self.row_hi).astype(np.int64)
+            self.own_ids = owned_edge_ids(self.edges, self.row_lo, self.row_hi, n).astype(np.int64)
         else:
             self.own_ids = np.arange(edge_lo, edge_hi, dtype=np.int64)
         self.ld = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else (D + 3) // 4 * 4
@@ -33,6 +33,26 @@ class CpuShardEngine:
         self.world, self.rank, self.chunk = world, rank, chunk
         self.slot = (chunk * self.ld * 4 + 2 * self.ld * 8 + 15) // 16 * 16
         self.gbuf = torch.zeros((world, self.slot), dtype=torch.uint8)
+
+    def rank_layout(self, world, rank, chunk):
+        """finish="own": statistics of every rank in stats_all, position blocks gathered in place (HipShardEngine.rank_layout)."""
+        self.world, self.rank, self.chunk = world, rank, chunk
+        assert world * chunk <= self.pos.shape[0]
+        self.stats_all = torch.zeros((world, 2, self.ld), dtype=torch.float64)
+        self.pos_blocks = self.pos[: world * chunk].view(world, chunk * self.ld)
+
+    def step_finish_own(self, stats_all):
+        """The ranks' statistics added in rank order; own rows normalised into their block of pos."""
+        tot = np.zeros((2, self.ld))
+        for r in range(self.world):
+            tot += stats_all[r].numpy()
+        n = self.n
+        mean = tot[0, : self.D] / n
+        var = np.maximum((tot[1, : self.D] - tot[0, : self.D] * mean) / (n - 1), 0.0)
+        sd = np.sqrt(var).astype(np.float32) + np.float32(1e-6)
+        out = (self.new - mean.astype(np.float32)) / sd
+        self.pos[self.row_lo:self.row_hi, : self.D] = torch.from_numpy(out.astype(np.float32))
+        self.iter += 1
 
     def _slot_views(self, r):
         raw = self.gbuf[r].numpy()

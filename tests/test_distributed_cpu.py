@@ -32,7 +32,8 @@ def _worker(rank, world, port, case, out_dir):
     from cpu_shard_engine import CpuShardEngine
     n, D, edges, pos, stream, k, S = case[:7]
     lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=3, rank=rank, world=world,
-                            engine_factory=CpuShardEngine, edge_ownership=case[7] if len(case) > 7 else "auto")
+                            engine_factory=CpuShardEngine, edge_ownership=case[7] if len(case) > 7 else "auto",
+                            finish=case[8] if len(case) > 8 else "own")
     lay.set_positions(pos)
     lay.run(len(stream), stream)
     np.save(os.path.join(out_dir, f"pos_w{world}_r{rank}.npy"), lay.get_positions())
@@ -51,10 +52,11 @@ def _case(n=403, D=3, deg=6, k=6, S=40, iters=3):
     return n, D, edges, pos, stream, k, S
 
 
-@pytest.mark.parametrize("world,rule", [(2, "hashed"), (3, "hashed"), (2, "range")])
-def test_partitioned_layout_matches_single_rank_and_oracle(world, rule, tmp_path):
+@pytest.mark.parametrize("world,rule,finish", [(2, "hashed", "own"), (3, "hashed", "own"), (2, "range", "own"),
+                                               (3, "hashed", "gathered")])
+def test_partitioned_layout_matches_single_rank_and_oracle(world, rule, finish, tmp_path):
     import oracle
-    case = _case() + (rule,)
+    case = _case() + (rule, finish)
     n, D, edges, pos, stream, k, S = case[:7]
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
     mp.spawn(_worker, args=(1, _free_port(), case, str(tmp_path)), nprocs=1, join=True)
@@ -76,7 +78,7 @@ def test_hashed_ownership_partitions_the_edges_evenly():
     from graphem_rapids_amd.distributed import owned_edge_ids, partition_edges, partition_rows
     n, world = 20000, 4
     edges = gra.random_regular_edges(n, 8, seed=2)
-    ids = [owned_edge_ids(edges, *partition_rows(n, world, r)[1:]) for r in range(world)]
+    ids = [owned_edge_ids(edges, *partition_rows(n, world, r)[1:], n) for r in range(world)]
     allids = np.sort(np.concatenate(ids))
     assert np.array_equal(allids, np.arange(len(edges)))
     shares = np.array([len(x) for x in ids]) / len(edges)

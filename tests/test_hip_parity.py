@@ -261,7 +261,8 @@ def test_device_sampler():
                                             (2, "hashed", 9001, 5),     # D without a templated spring kernel
                                             (3, "hashed", 20001, 16),
                                             (3, "hashed-hubs", 30011, 3)])  # rows with thousands of neighbours
-def test_partitioned_engines_equal_single_engine(world, rule, n, D):
+@pytest.mark.parametrize("finish", ["own", "gathered"])
+def test_partitioned_engines_equal_single_engine(world, rule, n, D, finish):
     """The split step (gh_step_begin / gh_step_merge / gh_step_finish) with row partitions: `world`
     engines on ONE GPU, collectives emulated with device copies, must reproduce the unpartitioned
     engine (the oracle of the multi-GPU mode is the 1-GPU result), under both edge
@@ -295,14 +296,17 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D):
         chunk, lo, hi = partition_rows(n, world, r)
         if rule == "hashed":
             part = (lo, hi, 0, 0, _native.EDGES_HASHED)
-            owned += len(owned_edge_ids(edges, lo, hi))
+            owned += len(owned_edge_ids(edges, lo, hi, n))
         else:
             elo, ehi = partition_edges(edges, lo, hi)
             part = (lo, hi, elo, ehi, _native.EDGES_RANGE)
             owned += ehi - elo
         parts.append((lo, hi))
         shards.append(HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, part, 0))
-        shards[-1].gather_layout(world, r, chunk)
+        if finish == "own":
+            shards[-1].rank_layout(world, r, chunk)
+        else:
+            shards[-1].gather_layout(world, r, chunk)
         shards[-1].set_positions(pos)
     assert owned == len(edges)  # every edge searched by exactly one rank
     for t in range(3):
@@ -311,6 +315,14 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D):
         gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()
         for sh in shards:
             sh.step_merge(gathered, world)
+        if finish == "own":   # all-gather of the statistics, own rows normalised, in-place all-gather of the blocks
+            stats_all = torch.stack([sh.stats.clone() for sh in shards]).contiguous()
+            for sh in shards:
+                sh.step_finish_own(stats_all)
+            blocks = torch.stack([sh.pos_blocks[r].clone() for r, sh in enumerate(shards)])
+            for sh in shards:
+                sh.pos_blocks.copy_(blocks)
+            continue
         slots = torch.stack([sh.gbuf[r].clone() for r, sh in enumerate(shards)])   # the all-gather of the slots
         for sh in shards:
             sh.gbuf.copy_(slots)
@@ -363,24 +375,30 @@ def test_rccl_driver_single_rank():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         got = {}
-        for native in (True, False):   # the loop in the C library over the library's own RCCL communicator / driven from Python
-            lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=9, rank=0, world=1, device_id=0, native=native)
+        for native, finish in ((True, "own"), (False, "own"), (True, "gathered"), (False, "gathered")):
+            # the loop in the C library over the library's own RCCL communicator / driven from Python; both finishes
+            lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=9, rank=0, world=1, device_id=0, native=native,
+                                    finish=finish)
             assert lay.native == native
             lay.set_positions(pos)
             lay.run(3, stream)
             lay.run(2)
             lay.sync()
             torch.cuda.synchronize()
-            got[native] = lay.get_positions()
+            got[native, finish] = lay.get_positions()
             lay.engine.eng.close()
+        assert PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=9, rank=0, world=1, device_id=0).native is False  # opt-in
     finally:
         dist.destroy_process_group()
-    assert np.abs(got[True] - ref).max() <= 2e-6
-    assert np.array_equal(got[True], got[False])
+    for key, val in got.items():
+        assert np.abs(val - ref).max() <= 2e-6, key
+    assert np.array_equal(got[True, "own"], got[False, "own"])
+    assert np.array_equal(got[True, "gathered"], got[False, "gathered"])
 
 
-@pytest.mark.parametrize("world,n,D", [(2, 30011, 3), (3, 30011, 3), (4, 100003, 3), (3, 9001, 5), (2, 20001, 16)])
-def test_native_partitioned_loop_on_the_loopback_backend(world, n, D):
+@pytest.mark.parametrize("world,n,D,finish", [(2, 30011, 3, "own"), (3, 30011, 3, "own"), (4, 100003, 3, "own"), (3, 9001, 5, "own"),
+                                              (2, 20001, 16, "own"), (3, 30011, 3, "gathered"), (8, 100003, 3, "own")])
+def test_native_partitioned_loop_on_the_loopback_backend(world, n, D, finish):
     """gh_run_partitioned (csrc/comm.hip): the whole multi-rank run inside the C library.  `world` engines on this one
     GPU, one host thread each, collectives by the in-process loopback backend (RCCL refuses two ranks on one device):
     the same loop, the same buffers and counts as over RCCL.  Must reproduce the single engine, with a host id stream
@@ -406,7 +424,10 @@ def test_native_partitioned_loop_on_the_loopback_backend(world, n, D):
     for r in range(world):
         chunk, lo, hi = partition_rows(n, world, r)
         e = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=4, partition=(lo, hi, 0, 0, _native.EDGES_HASHED))
-        e.gather_layout(world, r, chunk)
+        if finish == "own":
+            e.rank_layout(world, r, chunk)
+        else:
+            e.gather_layout(world, r, chunk)
         e.comm_init_loopback(group, r)
         e.set_positions(pos)
         engines.append(e)

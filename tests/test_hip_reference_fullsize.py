@@ -194,7 +194,7 @@ def test_c4_rr4m_eight_row_partitions_equal_one_engine():
     for r in range(world):
         chunk, lo, hi = partition_rows(n, world, r)
         shards.append(HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, (lo, hi, 0, 0, _native.EDGES_HASHED), 0))
-        shards[-1].gather_layout(world, r, chunk)
+        shards[-1].rank_layout(world, r, chunk)
         shards[-1].set_positions(pos)
     for t in range(2):
         for sh in shards:
@@ -202,10 +202,12 @@ def test_c4_rr4m_eight_row_partitions_equal_one_engine():
         gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()   # all-gather of the keys
         for sh in shards:
             sh.step_merge(gathered, world)
-        slots = torch.stack([sh.gbuf[r].clone() for r, sh in enumerate(shards)])     # all-gather of the slots
+        stats_all = torch.stack([sh.stats.clone() for sh in shards]).contiguous()    # all-gather of the statistics
         for sh in shards:
-            sh.gbuf.copy_(slots)
-            sh.step_finish_gathered()
+            sh.step_finish_own(stats_all)
+        blocks = torch.stack([sh.pos_blocks[r].clone() for r, sh in enumerate(shards)])   # in-place all-gather of the blocks
+        for sh in shards:
+            sh.pos_blocks.copy_(blocks)
     torch.cuda.synchronize()
     first = shards[0].get_positions()
     assert np.abs(first - ref).max() <= 2e-6
