@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
                                                        const int32_t *__restrict__ touched,
                                                        const int32_t *__restrict__ tcount, int nfix, int g_norm,
                                                        int n_setup, gh_setup_args sa, int32_t *__restrict__ qexact,
-                                                       unsigned long long *__restrict__ stamps /* diagnostic, or null */) {
+                                                       unsigned long long *__restrict__ stamps /* diagnostic, or null */,
+                                                       int stat_world = 1) {
     if (stamps && (blockIdx.x >= GH_STAMP_EXTRA)) stamps = nullptr;
     if (stamps) stamps += (int64_t)blockIdx.x * 8;
 #define GH_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
@@ -357,17 +358,25 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
     // all statistics rows with one load per thread and round, then summed from LDS in the fixed order: a thread adding
     // its column's 2 nfix corrections straight from memory waited for them one after the other (LD = 16: 64 loads, 7.6 us
     // before any workgroup of this launch knew mean and std -- tools/stamp_probe.py)
+    // (stat_world > 1: form C of a partitioned step -- the statistics rows of every rank, all-gathered in rank order; each
+    // rank's rows in their fixed order, then the next rank's, so every rank derives the same mean / std bits)
     double *srow = reinterpret_cast<double *>(ms + 2 * LD);
-    for (int t = threadIdx.x; t < (2 + 2 * nfix) * LD; t += blockDim.x) srow[t] = stats[t];
+    const int R = 2 + 2 * nfix;
+    for (int t = threadIdx.x; t < stat_world * R * LD; t += blockDim.x) srow[t] = stats[t];
     __syncthreads();
     for (int d = threadIdx.x; d < LD; d += blockDim.x) {
         float mean = 0.0f, sd = 1.0f;
         if (d < D) {
-            double sum = srow[d], sq = srow[LD + d];
+            double sum = 0.0, sq = 0.0;
+            for (int r = 0; r < stat_world; ++r) {
+                const double *rr = srow + (int64_t)r * R * LD;
+                sum += rr[d];
+                sq += rr[LD + d];
 #pragma unroll 8
-            for (int b = 0; b < nfix; ++b) {  // corrections of the touched rows (zero when unused)
-                sum += srow[(2 + 2 * b) * LD + d];
-                sq += srow[(3 + 2 * b) * LD + d];
+                for (int b = 0; b < nfix; ++b) {  // corrections of the touched rows (zero when unused)
+                    sum += rr[(2 + 2 * b) * LD + d];
+                    sq += rr[(3 + 2 * b) * LD + d];
+                }
             }
             const double m = sum / (double)n;
             double var = (sq - sum * m) / (double)(n - 1);
@@ -886,22 +895,27 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
 gh_status gh_launch_normalise_own(gh_engine *h, const double *stats_all, int world) {
     h->presetup_valid = false;
     const int R = 2 + 2 * gh_fix_blocks(h->LD);
-    if (2 * h->LD > 64) { h->err = "row stride too large for the partitioned finish"; return GH_ERR_INVALID; }
-    {
+    int nfix = gh_fix_blocks(h->LD), sworld = world;
+    size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * (size_t)world * R * h->LD;
+    if (smem > 48 * 1024) {   // wide rows on many ranks: the rows do not fit the workgroup's LDS -- added up by a launch of their own
+        if (2 * h->LD > 64) { h->err = "row stride too large for the partitioned finish"; return GH_ERR_INVALID; }
         gh_scope t(h, "stats_combine");
         stats_combine_kernel<<<dim3(1), dim3(64), 0, h->stream>>>(stats_all, world, R, h->LD, h->d_stats_comb);
         GH_LAUNCH_CHECK();
+        stats_all = h->d_stats_comb;
+        nfix = 0;
+        sworld = 1;
+        smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * (size_t)h->LD;
     }
     if (h->rows == 0) return gh_launch_inter_cleanup(h);
     gh_scope t(h, "normalise_own");
     const int64_t total = h->rows * h->LD / 4;
     unsigned grid = grid_for(total, 1024);
     if (grid > 2048) grid = 2048;
-    const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * (size_t)h->LD;
     gh_setup_args sa{};
     normalise_kernel<0><<<dim3(grid), dim3(256), smem, h->stream>>>(
-        h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, h->d_stats_comb, h->d_pos, h->d_acc, h->d_tflag, h->d_touched,
-        h->d_tcount, 0, (int)grid, 0, sa, h->d_qexact, nullptr);
+        h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, stats_all, h->d_pos, h->d_acc, h->d_tflag, h->d_touched,
+        h->d_tcount, nfix, (int)grid, 0, sa, h->d_qexact, nullptr, sworld);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
