@@ -32,6 +32,9 @@ WORKLOADS = {
     "rr20k": ("rr", 20_000, 8, 3, 10, 256),        # quick self-test
     "rr1m_d6": ("rr", 1_000_000, 8, 6, 10, 256),   # wide rows at scale (8-float rows)
     "rr1m_d12": ("rr", 1_000_000, 8, 12, 10, 256), # (16-float rows, 32-deep contraction)
+    # SURVEY 8d's streaming point: a 256 MB position table (the size of the Infinity Cache), B_iter = 2.75 GB: the
+    # gathers of the spring phase come from HBM, not from cache
+    "rr16m": ("rr", 16_000_000, 8, 3, 10, 256),
 }
 HBM_PEAK = 8.0e12       # B/s  (MI355X_MICROARCH.md: HBM3E peak, spec)
 FP32_PEAK = 157.3e12    # FLOP/s (fp32 vector peak = dense fp32 MFMA peak)
@@ -40,11 +43,21 @@ FP32_PEAK = 157.3e12    # FLOP/s (fp32 vector peak = dense fp32 MFMA peak)
 def make_workload(name, seed=0):
     import graphem_rapids_amd as gra
     kind, n, prm, D, k, S = WORKLOADS[name]
-    if kind == "rr":
-        edges = gra.random_regular_edges(n, prm, seed=seed)
+    # (the big graphs take minutes to generate: kept in /tmp for the later passes of a profiling job on the same box)
+    cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"graphem_bench_{name}_seed{seed}.npy")
+    if n >= 4_000_000 and os.path.exists(cache):
+        edges = np.load(cache)
     else:
-        edges = gra.erdos_renyi_edges(n, prm, seed=12345)
-    edges = np.ascontiguousarray(edges, dtype=np.int32)
+        if kind == "rr":
+            edges = gra.random_regular_edges(n, prm, seed=seed)
+        else:
+            edges = gra.erdos_renyi_edges(n, prm, seed=12345)
+        edges = np.ascontiguousarray(edges, dtype=np.int32)
+        if n >= 4_000_000:
+            try:
+                np.save(cache, edges)
+            except OSError:
+                pass
     rng = np.random.default_rng(seed)
     pos = (rng.standard_normal((n, D)) * 0.1).astype(np.float32)  # the reference's own random start (pt.py:369)
     return n, D, k, S, edges, pos

@@ -76,9 +76,11 @@ static gh_status check_handle(gh_engine *h) {
 static void free_all(gh_engine *h) {
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_stats_comb, h->d_rare, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rare, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -432,6 +434,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     if ((st = gh_grid_alloc(h)) != GH_OK) return bail(st);
     if ((st = gh_cdist_alloc(h)) != GH_OK) return bail(st);
     GH_A2(d_tau_flag, 1);
+    GH_A2(d_iter, 1);
     GH_A2(d_wait_failed, 1);
     // Thresholds by the first workgroups of the fused launch (tau_core.h) where that launch is a single round of
     // workgroups or little more: there the iteration is a chain of launch latencies and this removes one (100 K vertices:
@@ -504,12 +507,12 @@ static gh_status check_device_waits(gh_engine *h) {
     GH_HIP(hipMemcpyAsync(&failed, h->d_wait_failed, sizeof(failed), hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipStreamSynchronize(h->stream));
     if (failed) {
-        // reported once: the flag is cleared, the published-queries counter is put where the next launch expects it and
-        // the engine goes on with the thresholds as a launch of their own (no workgroup waits for another any more)
+        // reported once: the flag is cleared and the engine goes on with the thresholds as a launch of their own (no
+        // workgroup waits for another any more)
         GH_HIP(hipMemsetAsync(h->d_wait_failed, 0, sizeof(int32_t), h->stream));
-        GH_HIP(hipMemcpyAsync(h->d_tau_flag, &h->tau_epoch, sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
         GH_HIP(hipStreamSynchronize(h->stream));
         h->tau_embedded = false;
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // captured with the other form
         h->err = "a workgroup of the fused spring+scan launch timed out waiting for the thresholds of its own launch; "
                  "results since the last successful gh_sync / gh_get_positions are invalid -- set the positions again. "
                  "The engine now computes the thresholds in a launch of their own (as GRAPHEM_HIP_TAU_SEPARATE=1 does); "
@@ -665,6 +668,80 @@ gh_status gh_upload_sample_stream(gh_engine *h, int32_t iters, const int32_t *sa
     return GH_OK;
 }
 
+// One iteration of a device-sampled run as the host enqueues it (set-up of the next iteration inside its normalise launch).
+static gh_status run_one_device_sampled(gh_engine *h) {
+    GH_TRY(set_sample(h, nullptr, nullptr));
+    GH_TRY(step_begin(h, true));
+    GH_TRY(step_merge(h, h->d_partial, 1));
+    return step_finish(h, h->S >= h->E ? 2 : 1);
+}
+
+// Iterations 2.. of a device-sampled run replayed from a hipGraph (OPT-IN: GRAPHEM_HIP_GRAPH=1).  In steady state an
+// iteration is the same four or five launches with the same arguments, except for the iteration number the sampler is
+// keyed with -- that lives in device memory while replaying (d_iter: moved on by stats_fix_kernel, read by the set-up
+// inside the following normalise launch).  Measured (round 3, bench.py, median of 3 passes of 50 iterations, same box):
+// one iteration per graph 172.2 us against 166.3 enqueued at 1 M vertices, 62.3 / 57.3 at 100 K, 121.8 / 117.3 on the
+// 16-component SNAP shape; ten iterations per graph 170.1 / 167.9, 58.6 / 57.6, 117.8 / 117.7 -- a graph launch costs
+// more than it saves on this runtime (the 1.9 - 2.8 us per replayed boundary of tools/micro/grid_barrier.hip did not
+// carry over to kernels with 200-byte argument blocks), so the enqueued loop stays the default.
+static bool graph_replay_applies(gh_engine *h) {
+    return whole_graph(h) && !h->d_gbuf && !h->g_world && !h->cdist && !h->timing && !h->d_stamps && h->fused_scan && !h->force_unfused &&
+           gh_knn_scan_path(h) && !gh_grid_path(h) && h->S > 0 && h->k > 0 && h->K <= 128 && h->LD <= 16 &&
+           getenv("GRAPHEM_HIP_GRAPH") && atoi(getenv("GRAPHEM_HIP_GRAPH")) != 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
+}
+static int graph_iters() {   // iterations per captured graph (a graph launch has a cost of its own: one iteration per graph
+                             // was SLOWER than enqueuing, 172.2 against 166.3 us per iteration at 1 M vertices)
+    static int g = 0;
+    if (g == 0) {
+        g = 10;
+        if (const char *e = getenv("GRAPHEM_HIP_GRAPH_ITERS")) g = std::max(1, atoi(e));
+    }
+    return g;
+}
+// Replays as many whole graphs (graph_iters() iterations each) as fit into `count`; *done = iterations replayed.
+static gh_status graph_replay(gh_engine *h, int32_t count, int32_t *done) {
+    *done = 0;
+    const int G = graph_iters();
+    if (count < G) return GH_OK;
+    if (!h->graph_exec) {
+        // captured from the steady state: the previous launch has done this iteration's set-up (presetup_valid)
+        if (!h->presetup_valid || h->presetup_iter != h->iter) return GH_ERR_RUNTIME;   // (caller falls back to enqueuing)
+        const bool pv = h->presetup_valid, trp = h->tcount_reset_pending;
+        const int pm = h->presetup_mode;
+        const int32_t *pi = h->presetup_ids;
+        const uint64_t it0 = h->iter, pit = h->presetup_iter;
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return GH_ERR_RUNTIME; }
+        h->graph_capturing = true;
+        gh_status st = GH_OK;
+        for (int g = 0; g < G && st == GH_OK; ++g) st = run_one_device_sampled(h);   // (iteration numbers: offsets to the device counter)
+        h->graph_capturing = false;
+        hipGraph_t g = nullptr;
+        const hipError_t e = hipStreamEndCapture(h->stream, &g);
+        // nothing ran: the host-side state goes back to where the captured iterations started
+        h->iter = it0; h->presetup_valid = pv; h->presetup_mode = pm; h->presetup_ids = pi; h->presetup_iter = pit;
+        h->tcount_reset_pending = trp;
+        h->new0_ready = false; h->stats_reduced = false; h->intersect_done = false; h->sample_pending = false;
+        if (st != GH_OK || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return GH_ERR_RUNTIME; }
+        if (hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGraphDestroy(g); (void)hipGetLastError(); h->graph_exec = nullptr;
+            return GH_ERR_RUNTIME;
+        }
+        h->graph = g;
+    }
+    GH_HIP(hipMemcpyAsync(h->d_iter, &h->iter, sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));   // (the source is a member of *h: the copy must not outlive this call's view of it)
+    const int32_t launches = count / G;
+    for (int32_t t = 0; t < launches; ++t) GH_HIP(hipGraphLaunch(h->graph_exec, h->stream));
+    *done = launches * G;
+    h->iter += (uint64_t)*done;
+    h->presetup_valid = true;          // the last replayed normalise launch set the next iteration up
+    h->presetup_iter = h->iter;
+    h->presetup_mode = h->S >= h->E ? 2 : 1;
+    h->presetup_ids = h->d_sampled;
+    h->tcount_reset_pending = false;
+    return GH_OK;
+}
+
 extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_stream) {
     GH_TRY(check_handle(h));
     if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
@@ -674,7 +751,14 @@ extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_st
     const int32_t *d_ids = nullptr;
     GH_TRY(gh_upload_sample_stream(h, iters, sample_stream, &d_ids));
     const bool use_stream = d_ids != nullptr;
-    for (int32_t t = 0; t < iters; ++t) {
+    int32_t t = 0;
+    if (!use_stream && iters > graph_iters() && graph_replay_applies(h)) {
+        GH_TRY(run_one_device_sampled(h));   // into the steady state (the set-up of iteration 2 rides in this one's normalise launch)
+        t = 1;
+        int32_t done = 0;
+        if (graph_replay(h, iters - 1, &done) == GH_OK) t += done;   // whole graphs; what is left is enqueued below
+    }
+    for (; t < iters; ++t) {
         GH_TRY(set_sample(h, nullptr, use_stream ? h->d_stream_ids + (size_t)t * h->S : nullptr));
         GH_TRY(step_begin(h, true));
         GH_TRY(step_merge(h, h->d_partial, 1));

@@ -6,6 +6,14 @@
 #include <stdint.h>
 
 #define GH_WAVE 64
+// Neighbour rows a thread of the spring pull has in flight (tuning: -DGH_DEPTH8=.. -DGH_DEPTH16=..)
+#ifndef GH_DEPTH8
+#define GH_DEPTH8 4
+#endif
+#ifndef GH_DEPTH16
+#define GH_DEPTH16 2
+#endif
+#define GH_GATHER_DEPTH(LD) ((LD) <= 4 ? 8 : (LD) <= 8 ? GH_DEPTH8 : GH_DEPTH16)
 
 // Row stride (floats) of the padded position array for an embedding dimension D:
 // rows are 16-byte aligned so a vertex is fetched with dwordx4 loads.
@@ -112,7 +120,7 @@ __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const
     // this vertex OWNS the edge to that neighbour: the midpoint (pt.py:785) of an owned edge costs
     // nothing here, both endpoints being in registers, and spares the KNN scan its own random
     // gathers; owned midpoints go to consecutive rows of `mid` starting at mid_row0.
-    constexpr int C = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;
+    constexpr int C = GH_GATHER_DEPTH(LD);
 #pragma unroll
     for (int d = 0; d < LD; ++d) F[d] = 0.0f;
     for (int base = beg; base < end; base += C) {
@@ -222,7 +230,7 @@ __device__ __forceinline__ void spring_row(const float *__restrict__ pos, const 
                 const int m = (lo + hi) >> 1;
                 if (la.rows[m] < i_local) lo = m + 1; else hi = m;
             }
-            constexpr int C = LD <= 4 ? 8 : LD <= 8 ? 4 : 2;   // neighbour rows in flight, as in spring_pull
+            constexpr int C = GH_GATHER_DEPTH(LD);   // neighbour rows in flight, as in spring_pull
             const int jend = la.ownptr[lo + 1];
             for (int base = la.ownptr[lo]; base < jend; base += C) {
                 float py[C][LD];

@@ -155,8 +155,12 @@ struct gh_engine {
     // timing
     // thresholds inside the fused launch (tau_core.h)
     bool tau_embedded = false;
-    unsigned *d_tau_flag = nullptr;      // queries published so far (wraps)
-    unsigned tau_epoch = 0;              // value of *d_tau_flag after the last launch issued
+    unsigned *d_tau_flag = nullptr;      // queries published so far by the current fused launch
+    // iterations replayed from a hipGraph (api.hip gh_run): one captured iteration, the iteration number on the device
+    uint64_t *d_iter = nullptr;
+    bool graph_capturing = false;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
     int32_t *d_wait_failed = nullptr;    // a consumer gave up waiting: reported by gh_sync / gh_get_positions
 
 #define GH_STAMP_EXTRA 8192

@@ -262,8 +262,10 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
                                                        const int32_t *__restrict__ touched,
                                                        const int32_t *__restrict__ tcount, int64_t row_lo,
                                                        int64_t rows, float *__restrict__ out_new,
-                                                       double *__restrict__ stats, int skip_reduce) {
+                                                       double *__restrict__ stats, int skip_reduce,
+                                                       uint64_t *__restrict__ iter_bump /* replayed iterations: the device's iteration counter, or null */) {
     __shared__ double red[4][2 * LD];
+    if (iter_bump && blockIdx.x == 0 && threadIdx.x == 0) *iter_bump += 1;   // read by the set-up inside the NEXT launch (normalise)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (!skip_reduce) {  // (the select launch of a single-rank step has done this part already)
         const int c = blockIdx.x;  // gridDim.x == 2 * LD
@@ -739,7 +741,7 @@ gh_status gh_launch_integrate(gh_engine *h) {
 #define GH_FIX_CASE(LL)                                                                                      \
     stats_fix_kernel<LL><<<dim3(gh_fix_blocks(LL)), dim3(256), 0, h->stream>>>(                                  \
         h->d_blockstats, h->n_vblocks, h->d_pos, h->d_Fs, h->d_acc, h->d_touched, h->d_tcount, h->part.row_lo, \
-        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0)
+        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0, h->graph_capturing ? h->d_iter : nullptr)
         if (h->LD == 4) GH_FIX_CASE(4);
         else if (h->LD == 8) GH_FIX_CASE(8);
         else GH_FIX_CASE(16);

@@ -642,9 +642,8 @@ gh_tau_args fused_tau_args(gh_engine *h, int nt) {
     gh_tau_args ta{};
     if (!h->tau_embedded) return ta;
     ta = gh_make_tau_args(h);
-    h->tau_epoch += (unsigned)h->S;
-    ta.flag = h->d_tau_flag;
-    ta.target = h->tau_epoch;
+    ta.flag = h->d_tau_flag;          // zeroed by this iteration's set-up (setup_core.h), S once the producers are through
+    ta.target = (unsigned)h->S;
     ta.nblocks = gh_tau_blocks((int)h->S, nt);
     ta.wait_failed = h->d_wait_failed;
     return ta;
@@ -731,7 +730,6 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
     if (h->n_vblocks == 0) return GH_OK;
     GH_TRY_ST(gh_launch_spring_long(h, h->d_Fs, 0));  // hubs first: their rows' forces are read back in phase A
     gh_scope t(h, "spring_scan");
-    const unsigned epoch_before = h->tau_epoch;   // fused_tau_args() below moves it by S for the launch it prepares
     int nt, r;
     fused_cfg(h->LD, h->D, h->S, h->own_count, &nt, &r);
 #define GH_FUSED_D(NTT, RR)                                   \
@@ -790,11 +788,7 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
         return GH_ERR_RUNTIME;
     }
 #undef GH_FUSED_D
-    if (hipError_t e = hipGetLastError(); e != hipSuccess) {
-        h->tau_epoch = epoch_before;   // nothing was launched: the published-queries counter has not moved
-        h->err = std::string("kernel launch: ") + hipGetErrorString(e);
-        return GH_ERR_HIP;
-    }
+    GH_LAUNCH_CHECK();
     h->new0_ready = true;  // d_new = pos + Fs and d_blockstats[n_vblocks] are in place
     return GH_OK;
 }

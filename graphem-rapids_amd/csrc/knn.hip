@@ -666,9 +666,12 @@ gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint6
         h->thr_M1 = scan ? (Mtot + h->thr_stride - 1) / h->thr_stride : 0;
     }
     const int tiles = (int)((h->thr_M1 + GH_THR_TILE - 1) / GH_THR_TILE);
-    return gh_setup_args{h->d_edges, sampled, mode, h->E, h->prm.seed, iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
+    // replayed iterations: the number of the iteration being set up = device counter + (iter - h->iter - 1): the counter
+    // was moved to "this iteration + 1" by stats_fix_kernel before the normalise launch that carries the set-up
+    const bool dev = h->graph_capturing;
+    return gh_setup_args{h->d_edges, sampled, mode, h->E, h->prm.seed, dev ? iter - h->iter - 1 : iter, h->S, h->D, h->LD, h->d_q, h->d_cnt,
                          h->d_ovf, h->part.edge_lo, h->d_own_eids, reinterpret_cast<const int2 *>(h->d_sub_uv), h->thr_M1, h->thr_stride, h->d_gmin,
-                         (int64_t)tiles * GH_THR_GROUPS, tiles};
+                         (int64_t)tiles * GH_THR_GROUPS, tiles, h->tau_embedded ? h->d_tau_flag : nullptr, dev ? h->d_iter : nullptr};
 }
 
 // Workgroups of 256 threads a set-up takes (knn_setup_kernel, or the head of a normalise launch).

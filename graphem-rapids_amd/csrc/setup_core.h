@@ -40,7 +40,11 @@ struct gh_setup_args {
     float *gmin;             // (S, Gpad) group minima as float bits
     int64_t Gpad;            // row stride of gmin = 16 * tiles
     int tiles;               // ceil(M1 / 256): workgroups of gh_setup_block
+    unsigned *tau_flag;      // thresholds inside the fused launch (tau_core.h): the published-queries counter, zeroed here
+    const uint64_t *iter_dev;  // replayed iterations (hipGraph, api.hip): the iteration number lives on the device and
+                               // `iter` above is an offset to it; null: `iter` is the number
 };
+__device__ __forceinline__ uint64_t gh_setup_iter(const gh_setup_args &a) { return a.iter_dev ? *a.iter_dev + a.iter : a.iter; }
 
 #define GH_THR_TILE 128    /* subset edges per set-up workgroup */
 #define GH_THR_GSIZE 64    /* subset edges per group */
@@ -49,9 +53,10 @@ struct gh_setup_args {
 // Sample id, query record and list reset of query t (every query exactly once per iteration).
 template <class P /* float(int64_t vertex, int d) */>
 __device__ __forceinline__ void gh_setup_item(const gh_setup_args &a, int64_t t, P getp) {
+    if (t == 0 && a.tau_flag) *a.tau_flag = 0;
     if (t >= a.S) return;
     int32_t e32;
-    if (a.mode == 1) { e32 = gh_sample_id(a.E, a.seed, a.iter, t); a.sampled[t] = e32; }
+    if (a.mode == 1) { e32 = gh_sample_id(a.E, a.seed, gh_setup_iter(a), t); a.sampled[t] = e32; }
     else if (a.mode == 2) { e32 = (int32_t)t; a.sampled[t] = e32; }
     else e32 = a.sampled[t];
     const int QS = gh_qs(a.D, a.LD);
@@ -95,8 +100,10 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
     __builtin_amdgcn_s_setprio(3);  // inside a normalise launch these waves sit among streaming ones: their chains go first
     // this lane's first query (every workgroup needs all of them; issued before the tile so that both chains of
     // dependent loads -- id -> edge -> rows here, endpoints -> rows below -- are in flight together)
+    if (blk == 0 && t == 0 && a.tau_flag) *a.tau_flag = 0;
+    const uint64_t iter = gh_setup_iter(a);
     auto query = [&](int64_t s, int32_t &e32, float (&q)[LD]) {
-        if (a.mode == 1) e32 = gh_sample_id(a.E, a.seed, a.iter, s);
+        if (a.mode == 1) e32 = gh_sample_id(a.E, a.seed, iter, s);
         else if (a.mode == 2) e32 = (int32_t)s;
         else e32 = a.sampled[s];
         const int2 uv = reinterpret_cast<const int2 *>(a.edges)[e32];

@@ -18,8 +18,8 @@ struct gh_tau_args {
     int32_t *qexact;          // [0] = count, then the queries outside the f16 range of that filter
     int32_t *tcount_reset;    // the touched-list counter to reset (set-up ran inside the previous normalise launch), or null
     // -- inside the fused launch only
-    unsigned *flag;           // queries published so far, over all launches of this engine (wraps)
-    unsigned target;          // value of *flag once this launch's S queries are out
+    unsigned *flag;           // queries published so far by THIS launch (zeroed by the iteration's set-up, setup_core.h)
+    unsigned target;          // value of *flag once this launch's S queries are out (= S)
     int nblocks;              // workgroups at the head of the grid that compute thresholds (0: a launch of their own did)
     int32_t *wait_failed;     // set when a consumer gave up waiting (cannot happen while workgroups start in index order)
 };

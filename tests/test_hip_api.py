@@ -307,3 +307,30 @@ def test_integration_md_binding_stub_runs():
     assert np.abs(out.std(axis=0, ddof=1) - 1).max() < 1e-3
     emb.update_positions()
     assert not np.array_equal(emb.get_positions(), out)
+
+
+def test_graph_replay_equals_the_enqueued_loop(monkeypatch):
+    """GRAPHEM_HIP_GRAPH=1: iterations 2.. of a device-sampled run replayed from a hipGraph (ten per graph, the iteration
+    number on the device) must give the bits of the enqueued loop, across runs of any length and after set_positions."""
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    n = 40000
+    edges = gra.random_regular_edges(n, 8, seed=2).astype(np.int32)
+    pos = (np.random.default_rng(1).standard_normal((n, 3)) * 0.1).astype(np.float32)
+
+    def sequence():
+        eng = _native.Engine(n, 3, edges, 1.0, 0.2, 0.5, 10, 256, seed=5)
+        eng.set_positions(pos)
+        eng.run(37)
+        eng.step(None)
+        eng.run(12)
+        a = eng.get_positions()
+        eng.set_positions(pos)
+        eng.run(25)
+        b = eng.get_positions()
+        eng.close()
+        return a, b
+    a0, b0 = sequence()
+    monkeypatch.setenv("GRAPHEM_HIP_GRAPH", "1")
+    a1, b1 = sequence()
+    assert np.array_equal(a0, a1) and np.array_equal(b0, b1)

@@ -6,6 +6,9 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "rr1m"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 mode = sys.argv[3] if len(sys.argv) > 3 else "knn"
 n, D, k, S, edges, pos = bench.make_workload(wl)
+if "--dim" in sys.argv:
+    D = int(sys.argv[sys.argv.index("--dim") + 1])
+    pos = (np.random.default_rng(0).standard_normal((n, D)) * 0.1).astype(np.float32)
 eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S)
 eng.set_positions(pos)
 eng.run(3)
