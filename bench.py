@@ -35,6 +35,10 @@ WORKLOADS = {
     # SURVEY 8d's streaming point: a 256 MB position table (the size of the Infinity Cache), B_iter = 2.75 GB: the
     # gathers of the spring phase come from HBM, not from cache
     "rr16m": ("rr", 16_000_000, 8, 3, 10, 256),
+    # a graph WITH structure (SNAP-like): 1000 communities of 1000 vertices, 8 neighbours inside + 2 anywhere, vertex numbers
+    # shuffled -- what an internal vertex order can and cannot do for the gathers (DESIGN.md "Vertex order")
+    "pp1m": ("pp", 1_000_000, (1000, 8, 2), 3, 10, 256),
+    "pp1m_sorted": ("pp", 1_000_000, (1000, 8, 2, 0, False), 3, 10, 256),   # the same graph in community order: what the best vertex order could give
 }
 HBM_PEAK = 8.0e12       # B/s  (MI355X_MICROARCH.md: HBM3E peak, spec)
 FP32_PEAK = 157.3e12    # FLOP/s (fp32 vector peak = dense fp32 MFMA peak)
@@ -50,6 +54,8 @@ def make_workload(name, seed=0):
     else:
         if kind == "rr":
             edges = gra.random_regular_edges(n, prm, seed=seed)
+        elif kind == "pp":
+            edges = gra.planted_partition_edges(n, *prm[:3], seed=seed, shuffle=(prm[4] if len(prm) > 4 else True))
         else:
             edges = gra.erdos_renyi_edges(n, prm, seed=12345)
         edges = np.ascontiguousarray(edges, dtype=np.int32)

@@ -8,7 +8,7 @@ from .backend_selection import BackendConfig, check_hip_availability, get_optima
 from .embedder_hip import GraphEmbedderHIP
 from .memory_management import (MemoryManager, cleanup_gpu_memory, get_gpu_memory_info, get_optimal_chunk_size,
                                 monitor_memory_usage)
-from .generators import (erdos_renyi_graph, generate_random_regular, erdos_renyi_edges, random_regular_edges,
+from .generators import (erdos_renyi_graph, generate_random_regular, erdos_renyi_edges, random_regular_edges, planted_partition_edges,
                          edges_to_adjacency, load_snap_edge_list)
 
 __version__ = "0.1.0"
@@ -50,6 +50,6 @@ def graphem_seed_selection(embedder, k, num_iterations=20):
 
 __all__ = ["create_graphem", "get_backend_info", "GraphEmbedderHIP", "BackendConfig", "get_optimal_backend",
            "check_hip_availability", "estimate_memory_usage", "erdos_renyi_graph", "generate_random_regular",
-           "erdos_renyi_edges", "random_regular_edges", "edges_to_adjacency", "load_snap_edge_list",
+           "erdos_renyi_edges", "random_regular_edges", "planted_partition_edges", "edges_to_adjacency", "load_snap_edge_list",
            "graphem_seed_selection", "MemoryManager", "cleanup_gpu_memory", "get_gpu_memory_info",
            "get_optimal_chunk_size", "monitor_memory_usage"]

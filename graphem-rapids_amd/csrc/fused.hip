@@ -138,7 +138,9 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
         return;
     }
     const bool coh = ta.nblocks > 0;
-    const int bx = (int)blockIdx.x - ta.nblocks, nbx = (int)gridDim.x - ta.nblocks;
+    const int nbx = ta.xcd_tiles > 0 ? ta.xcd_tiles : (int)gridDim.x - ta.nblocks;
+    const int bx = ta.xcd_tiles > 0 ? gh_fused_tile_index((int)blockIdx.x - ta.nblocks, nbx) : (int)blockIdx.x - ta.nblocks;
+    if (bx < 0) return;   // padding workgroup of the XCD-contiguous grid
 #define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + (k)] = wall_clock64(); } while (0)
     GH_STAMP(0);
     constexpr int QS = D <= 3 ? 4 : LD + 4;
@@ -245,7 +247,9 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
         return;
     }
     const bool coh = ta.nblocks > 0;
-    const int bx = (int)blockIdx.x - ta.nblocks, nbx = (int)gridDim.x - ta.nblocks;
+    const int nbx = ta.xcd_tiles > 0 ? ta.xcd_tiles : (int)gridDim.x - ta.nblocks;
+    const int bx = ta.xcd_tiles > 0 ? gh_fused_tile_index((int)blockIdx.x - ta.nblocks, nbx) : (int)blockIdx.x - ta.nblocks;
+    if (bx < 0) return;   // padding workgroup of the XCD-contiguous grid
     GH_STAMP(0);
     if (stamps && threadIdx.x == 0) { stamps[(int64_t)bx * 8 + 6] = vblock[bx + 1] - vblock[bx]; stamps[(int64_t)bx * 8 + 7] = first_edge[vblock[bx + 1]] - first_edge[vblock[bx]]; }
     static_assert(D <= 3, "one 16-deep contraction holds three split coordinates");
@@ -445,7 +449,9 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
         return;
     }
     const bool coh = ta.nblocks > 0;
-    const int bx = (int)blockIdx.x - ta.nblocks, nbx = (int)gridDim.x - ta.nblocks;
+    const int nbx = ta.xcd_tiles > 0 ? ta.xcd_tiles : (int)gridDim.x - ta.nblocks;
+    const int bx = ta.xcd_tiles > 0 ? gh_fused_tile_index((int)blockIdx.x - ta.nblocks, nbx) : (int)blockIdx.x - ta.nblocks;
+    if (bx < 0) return;   // padding workgroup of the XCD-contiguous grid
 #define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + (k)] = wall_clock64(); } while (0)
     GH_STAMP(0);
     __shared__ float4 tile[TILE * LD / 4];                 // fp32 midpoints of the owned edges
@@ -638,21 +644,33 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
 
 // The thresholds of this iteration: computed by the first workgroups of the fused launch itself (h->tau_embedded), or
 // already in place (knn_tau_kernel ran; nblocks = 0).
+// XCD-contiguous tile mapping (tau_core.h gh_fused_tile_index): GRAPHEM_HIP_XCD_MAP=0/1 overrides the default.
+static int fused_xcd_tiles(const gh_engine *h) {
+    static int mode = -1;
+    if (mode < 0) { const char *e = getenv("GRAPHEM_HIP_XCD_MAP"); mode = e ? (atoi(e) != 0 ? 1 : 0) : 0; }
+    return mode && h->n_vblocks >= 64 && !h->d_stamps ? h->n_vblocks : 0;   // (the diagnostic stamps index by workgroup)
+}
+static unsigned fused_grid(const gh_engine *h, const gh_tau_args &ta) {
+    return (unsigned)((ta.xcd_tiles > 0 ? ((ta.xcd_tiles + 7) / 8) * 8 : h->n_vblocks) + ta.nblocks);
+}
 gh_tau_args fused_tau_args(gh_engine *h, int nt) {
     gh_tau_args ta{};
+    ta.xcd_tiles = fused_xcd_tiles(h);
     if (!h->tau_embedded) return ta;
+    const int xt = ta.xcd_tiles;
     ta = gh_make_tau_args(h);
     ta.flag = h->d_tau_flag;          // zeroed by this iteration's set-up (setup_core.h), S once the producers are through
     ta.target = (unsigned)h->S;
     ta.nblocks = gh_tau_blocks((int)h->S, nt);
     ta.wait_failed = h->d_wait_failed;
+    ta.xcd_tiles = xt;
     return ta;
 }
 
 template <int D, int R, bool DEFER>
 void launch_mfma_d(gh_engine *h) {
     const gh_tau_args ta = fused_tau_args(h, 256);
-    spring_scan_mfma_kernel<D, R, DEFER><<<dim3((unsigned)(h->n_vblocks + ta.nblocks)), dim3(256), 0, h->stream>>>(
+    spring_scan_mfma_kernel<D, R, DEFER><<<dim3(fused_grid(h, ta)), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min,
         -h->prm.k_attr, h->d_Fs, h->d_new, h->d_blockstats, h->d_q, reinterpret_cast<const gh_h8 *>(h->d_qA),
         h->d_qexact, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta, h->d_stamps);
@@ -683,7 +701,7 @@ void launch_l(gh_engine *h) {
         if ((int64_t)ny > h->S) ny = 1;
     }
     const gh_tau_args ta = fused_tau_args(h, NT);
-    spring_scan_kernel<D, LD, R, NT, LONG><<<dim3((unsigned)(h->n_vblocks + ta.nblocks), ny), dim3(NT), 0, h->stream>>>(
+    spring_scan_kernel<D, LD, R, NT, LONG><<<dim3(fused_grid(h, ta), ny), dim3(NT), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
         h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta,
         h->d_stamps);
@@ -707,7 +725,7 @@ void launch_mfmaw_l(gh_engine *h) {
         if ((int64_t)ny * 64 > h->S) ny = 1;
     }
     const gh_tau_args ta = fused_tau_args(h, 256);
-    spring_scan_mfmaw_kernel<D, LD, LONG><<<dim3((unsigned)(h->n_vblocks + ta.nblocks), ny), dim3(256), 0, h->stream>>>(
+    spring_scan_mfmaw_kernel<D, LD, LONG><<<dim3(fused_grid(h, ta), ny), dim3(256), 0, h->stream>>>(
         h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
         h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S,
         h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta, h->d_stamps);

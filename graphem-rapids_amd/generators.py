@@ -107,6 +107,27 @@ def random_regular_edges(n, d, seed=0, max_rounds=200):
     raise RuntimeError("random_regular_edges did not converge")
 
 
+def planted_partition_edges(n, communities, deg_in, deg_out, seed=0, shuffle=True):
+    """A graph WITH structure for locality experiments (SNAP-like: dense communities, sparse links between them):
+    `communities` equal blocks; about n * deg_in / 2 random pairs inside blocks and n * deg_out / 2 random pairs anywhere;
+    loops and repeats dropped.  shuffle: vertex numbers permuted at random, so that the numbering says nothing about
+    the blocks (an engine has to find the locality itself).  Returns (E, 2) int64 with u < v, sorted by (u, v)."""
+    rng = np.random.default_rng(seed)
+    size = n // communities
+    m_in, m_out = int(n * deg_in / 2), int(n * deg_out / 2)
+    u = rng.integers(0, size * communities, size=m_in)
+    v = (u // size) * size + rng.integers(0, size, size=m_in)
+    a = np.concatenate([u, rng.integers(0, n, size=m_out)])
+    b = np.concatenate([v, rng.integers(0, n, size=m_out)])
+    if shuffle:
+        perm = rng.permutation(n)
+        a, b = perm[a], perm[b]
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    keep = lo != hi
+    key = np.unique(lo[keep] * n + hi[keep])
+    return np.column_stack([key // n, key % n])
+
+
 def generate_random_regular(n=100, d=3, seed=0):
     """Same signature as the reference's generate_random_regular (generators.py:235-252)."""
     return edges_to_adjacency(n, random_regular_edges(n, d, seed))
