@@ -25,7 +25,7 @@ SYMBOLS = [
     "gh_step_finish_gathered", "gh_vertex_order", "gh_positions_unpadded_device", "gh_radial_topk",
     "gh_comm_unique_id", "gh_comm_init_rccl", "gh_loopback_group_create", "gh_loopback_group_destroy",
     "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error", "gh_debug_stamps",
-    "gh_knn_cdist_stats", "gh_rank_layout", "gh_step_finish_own", "gh_comm_available",
+    "gh_knn_cdist_stats", "gh_rank_layout", "gh_step_finish_own", "gh_comm_available", "gh_selftest_arith",
 ]
 
 
@@ -93,6 +93,8 @@ def load():
     L.gh_rank_layout.restype = ctypes.c_int
     L.gh_step_finish_own.argtypes = [vp, vp, i32]
     L.gh_step_finish_own.restype = ctypes.c_int
+    L.gh_selftest_arith.argtypes = [ctypes.c_int, ctypes.c_uint64, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.gh_selftest_arith.restype = ctypes.c_int
     L.gh_comm_available.argtypes = []
     L.gh_comm_available.restype = i32
     L.gh_gather_buffer_device.argtypes = [vp]
@@ -423,6 +425,13 @@ def comm_unique_id():
 def comm_available():
     """True when librccl.so opens with every entry point the native loop uses (no communicator is made)."""
     return bool(load().gh_comm_available())
+
+
+def selftest_arith(samples, seed=1, device_id=0):
+    """(mismatches of the lean sqrt, of the lean division) against sqrtf and '/' on `samples` operand sets."""
+    a, b = ctypes.c_int64(-1), ctypes.c_int64(-1)
+    raise_for(load().gh_selftest_arith(int(device_id), int(seed), int(samples), ctypes.byref(a), ctypes.byref(b)), None)
+    return a.value, b.value
 
 
 def device_count():

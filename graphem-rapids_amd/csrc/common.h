@@ -103,6 +103,49 @@ __device__ __forceinline__ double gh_wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------
+// IEEE-correct square root and division with fewer instructions than the general sequences the compiler emits for
+// sqrtf() and '/' (17 and 11 per operation: they carry the scaling for denormal operands and results).  The spring phase
+// computes, per neighbour, sqrt(sum of squares) and D quotients diff[d] / dist BY THE SAME dist: phase A of the fused
+// kernel issued ~63 VALU instructions per neighbour, 50 of them these two operations, and the kernel is 56-66 % VALU-busy.
+//   gh_sqrt_ieee   x >= 2^-96 (else sqrtf): v_sqrt_f32 (1 ulp) and the compiler's own correction step -- the candidate one
+//                  ulp below / above wins when its residual x - c * s says so.
+//   gh_div_by<D>   d in [2^-40, 2^20] and every |n| in [2^-100, d] (else '/'): ONE reciprocal refined once (3 instructions,
+//                  shared), then per quotient q = n r; q += (n - d q) r twice (5 instructions) -- the hardware division's
+//                  steps without v_div_scale / v_div_fmas / v_div_fixup, which are identities on this domain: quotient and
+//                  reciprocal are normal, and the residual n - d q is exact (its last bit is >= 2^-147) so the final
+//                  fused step rounds the true quotient.
+// tests/test_hip_api.py::test_lean_sqrt_and_division_are_ieee compares both with sqrtf and '/' on 2^32 operand sets
+// including the domain edges; the sha1 of the spring forces at 1 M vertices pins them end to end.
+__device__ __forceinline__ float gh_sqrt_ieee(float x) {
+    if (__builtin_expect(!(x >= 0x1p-96f), 0)) return sqrtf(x);   // tiny, zero, negative, NaN: the general sequence
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);
+    float out = rm <= 0.0f ? sm : s;
+    out = rp > 0.0f ? sp : out;
+    return x == INFINITY ? x : out;
+}
+template <int D>
+__device__ __forceinline__ void gh_div_by(const float (&n)[D], float d, float (&q)[D]) {
+    uint32_t emin = 255;
+#pragma unroll
+    for (int i = 0; i < D; ++i) emin = min(emin, (__float_as_uint(n[i]) >> 23) & 0xFFu);   // (zero and denormal: exponent 0)
+    if (__builtin_expect(!(d >= 0x1p-40f && d <= 0x1p20f) || emin < 27u, 0)) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) q[i] = n[i] / d;
+        return;
+    }
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        float t = n[i] * r;
+        t = fmaf(fmaf(-d, t, n[i]), r, t);
+        q[i] = fmaf(fmaf(-d, t, n[i]), r, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // Spring force on one vertex, pull style (reference pt.py:595-636): the vertex walks its own
 // neighbour list, nobody else writes its row, so there are no atomics and the sum is
 // reproducible.  The list is stored in the reference's summation order (all edges where the
@@ -128,7 +171,9 @@ __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const
         bool own[C];
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            const uint32_t a = base + j < end ? (uint32_t)adj[base + j] : (uint32_t)self;
+            // past the end of the list: the last entry again (an unconditional load; its row is fetched a second time from
+            // the cache and ignored) -- a predicated load per slot was an exec-mask branch per slot
+            const uint32_t a = (uint32_t)adj[min(base + j, end - 1)];
             ys[j] = (int64_t)(a & 0x7FFFFFFFu);
             own[j] = base + j < end && (a >> 31) != 0;
         }
@@ -141,10 +186,12 @@ __device__ __forceinline__ void spring_pull(const float *__restrict__ pos, const
                 float diff[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) diff[d] = py[j][d] - px[d];
-                const float dist = sqrtf(gh_sumsq<D>(diff)) + 1e-6f;
+                const float dist = gh_sqrt_ieee(gh_sumsq<D>(diff)) + 1e-6f;
                 const float fm = neg_k * (dist - L_min);
+                float quot[D];
+                gh_div_by<D>(diff, dist, quot);   // diff[d] / dist, IEEE-correct, one reciprocal for all D
 #pragma unroll
-                for (int d = 0; d < D; ++d) F[d] = F[d] + fm * (diff[d] / dist);
+                for (int d = 0; d < D; ++d) F[d] = F[d] + fm * quot[d];
                 if (WRITE_MID && own[j]) {
                     float mrow[LD];
 #pragma unroll

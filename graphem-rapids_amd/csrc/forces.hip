@@ -638,6 +638,42 @@ __global__ void arange_kernel(int64_t S, int32_t *__restrict__ sampled) {
     if (t < S) sampled[t] = (int32_t)t;
 }
 
+// Self-test of common.h's lean square root and division against sqrtf and '/': pseudo-random operands over and beyond
+// their fast domain (exponents, zeros, values one ulp around exact squares, |n| up to d), mismatching bit patterns counted.
+__global__ __launch_bounds__(256) void arith_selftest_kernel(uint64_t seed, int64_t per_thread, unsigned long long *__restrict__ bad) {
+    uint64_t x = seed + 0x9E3779B97F4A7C15ull * (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x + 1);
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    auto rnd_float = [&](int emin, int emax) {   // random sign-less float with biased exponent in [emin, emax]
+        const uint64_t r = next();
+        const uint32_t e = (uint32_t)(emin + (int)((r >> 40) % (uint64_t)(emax - emin + 1)));
+        return __uint_as_float((e << 23) | (uint32_t)(r & 0x7FFFFFu));
+    };
+    unsigned long long bs = 0, bd = 0;
+    for (int64_t it = 0; it < per_thread; ++it) {
+        // square root: any magnitude; every 4th sample sits within 2 ulp of an exact square
+        float v = rnd_float(1, 254);
+        if ((it & 3) == 0) { const float t = rnd_float(64, 190); v = __uint_as_float(__float_as_uint(t * t) + (uint32_t)(next() % 5) - 2u); }
+        if ((it & 63) == 0) v = (it & 64) ? 0.0f : __uint_as_float((uint32_t)(next() & 0x7FFFFFu));   // zero, denormals
+        if (__float_as_uint(gh_sqrt_ieee(v)) != __float_as_uint(sqrtf(v))) ++bs;
+        // division: d around and beyond [2^-40, 2^20], numerators from 2^-110 d up to d, sometimes zero / denormal
+        const float d = rnd_float(127 - 44, 127 + 24);
+        float n[3], q[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint64_t r = next();
+            float m = rnd_float(1, 127) * d;                            // |n| <= d, down to denormal
+            if ((r & 7) == 0) m = d * __uint_as_float(0x3F000000u + (uint32_t)((r >> 8) & 0x7FFFFFu));   // same magnitude as d
+            if ((r & 255) == 1) m = 0.0f;
+            n[i] = (r >> 63) ? -m : m;
+        }
+        gh_div_by<3>(n, d, q);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) if (__float_as_uint(q[i]) != __float_as_uint(n[i] / d)) ++bd;
+    }
+    if (bs) atomicAdd(&bad[0], bs);
+    if (bd) atomicAdd(&bad[1], bd);
+}
+
 inline unsigned grid_for(int64_t total, int bs) { return (unsigned)((total + bs - 1) / bs); }
 
 bool spring_is_templated(int D) { return gh_dim_templated(D); }
@@ -988,4 +1024,25 @@ gh_status gh_ensure_sample(gh_engine *h) {
     if (!h->sample_pending) return GH_OK;
     h->sample_pending = false;
     return h->sample_mode == 2 ? gh_launch_arange(h) : gh_launch_sample(h);
+}
+
+// include/graphem_hip.h: self-test of the lean IEEE square root / division of the spring phase.
+extern "C" gh_status gh_selftest_arith(int device_id, uint64_t seed, int64_t samples, int64_t *bad_sqrt, int64_t *bad_div) {
+    if (!bad_sqrt || !bad_div || samples < 0) return GH_ERR_INVALID;
+    if (hipSetDevice(device_id) != hipSuccess) return GH_ERR_HIP;
+    unsigned long long *d_bad = nullptr, host[2] = {0, 0};
+    if (hipMalloc(reinterpret_cast<void **>(&d_bad), sizeof(host)) != hipSuccess) return GH_ERR_NOMEM;
+    gh_status st = GH_OK;
+    const unsigned blocks = 4096;
+    const int64_t per_thread = (samples + (int64_t)blocks * 256 - 1) / ((int64_t)blocks * 256);
+    if (hipMemset(d_bad, 0, sizeof(host)) != hipSuccess) st = GH_ERR_HIP;
+    if (st == GH_OK) {
+        arith_selftest_kernel<<<dim3(blocks), dim3(256)>>>(seed, per_thread, d_bad);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(host, d_bad, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) st = GH_ERR_HIP;
+    }
+    (void)hipFree(d_bad);
+    *bad_sqrt = (int64_t)host[0];
+    *bad_div = (int64_t)host[1];
+    return st;
 }

@@ -106,12 +106,19 @@ __device__ __forceinline__ void gh_phase_a(const float *__restrict__ pos, const 
 // Workgroup reduction of the per-thread column sums -> blockstats[entry][blockIdx.x], entry < 2*LD (fixed order).
 template <int LD, int NT>
 __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const double (&sxx)[LD], double *red /* [NT/64][2*LD] */,
-                                               double *__restrict__ blockstats, int bx, int nbx) {
+                                               double *__restrict__ blockstats, int bx, int nbx, int nrows) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // a wave none of whose threads had a row (a tile of 512 owned edges is ~128 rows for 256 threads) holds zeros: it
+    // stores them and skips the 2 LD shuffle trees -- 240 instructions, half of them LDS permutes, per idle wave (round 3:
+    // the trees of all four waves were 4 M of the kernel's 42 M VALU instructions and most of its LDS instructions)
+    if (w * 64 >= nrows) {
+        if (lane < 2 * LD) red[w * 2 * LD + lane] = 0.0;
+    } else {
 #pragma unroll
-    for (int d = 0; d < LD; ++d) {
-        const double a = gh_wave_sum(sx[d]), b = gh_wave_sum(sxx[d]);
-        if (lane == 0) { red[w * 2 * LD + d] = a; red[w * 2 * LD + LD + d] = b; }
+        for (int d = 0; d < LD; ++d) {
+            const double a = gh_wave_sum(sx[d]), b = gh_wave_sum(sxx[d]);
+            if (lane == 0) { red[w * 2 * LD + d] = a; red[w * 2 * LD + LD + d] = b; }
+        }
     }
     __syncthreads();
     if (threadIdx.x < 2 * LD && blockstats) {
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(NT) void spring_scan_kernel(
         gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, store ? Fs : nullptr,
                                     store ? out_new : nullptr, mids, sx, sxx, la, Fs);
         GH_STAMP(1);
-        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr, bx, nbx);  // contains the barrier that ends phase A
+        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr, bx, nbx, v1 - v0);  // contains the barrier that ends phase A
     }
     GH_STAMP(2);
 
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
         double sx[LD], sxx[LD];
         gh_phase_a<D, LD, NT, true>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, Fs, out_new, mids, sx, sxx, la);
         GH_STAMP(1);
-        gh_block_stats<LD, NT>(sx, sxx, red, blockstats, bx, nbx);  // contains the barrier that ends phase A
+        gh_block_stats<LD, NT>(sx, sxx, red, blockstats, bx, nbx, v1 - v0);  // contains the barrier that ends phase A
     }
     GH_STAMP(2);
 
@@ -490,7 +497,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
         gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, store ? Fs : nullptr,
                                     store ? out_new : nullptr, mids, sx, sxx, la, Fs);
         GH_STAMP(1);
-        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr, bx, nbx);  // contains the barrier that ends phase A
+        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr, bx, nbx, v1 - v0);  // contains the barrier that ends phase A
     }
     GH_STAMP(2);
 

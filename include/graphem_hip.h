@@ -282,6 +282,11 @@ gh_status gh_spmv_symnorm(void *hip_stream, int64_t n, const int64_t *indptr, co
                           const double *inv_sqrt_deg, const double *x, double *y);
 const char *gh_spectral_last_error(void);
 
+/* Self-test (no reference counterpart): the spring phase computes sqrt and its D divisions by one distance with leaner
+ * instruction sequences than the compiler's general ones; this compares them bit for bit with sqrtf and '/' on `samples`
+ * pseudo-random operand sets over and beyond their fast domain.  Both counts must come back 0.  Blocking. */
+gh_status gh_selftest_arith(int device_id, uint64_t seed, int64_t samples, int64_t *bad_sqrt, int64_t *bad_div);
+
 /* Device / build facts for the host mirror's get_backend_info(). */
 int32_t gh_device_count(void);
 const char *gh_version(void);

@@ -334,3 +334,13 @@ def test_graph_replay_equals_the_enqueued_loop(monkeypatch):
     monkeypatch.setenv("GRAPHEM_HIP_GRAPH", "1")
     a1, b1 = sequence()
     assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
+
+
+def test_lean_sqrt_and_division_are_ieee():
+    """common.h gh_sqrt_ieee / gh_div_by (the spring phase's square root and its D divisions by one distance, with the
+    reciprocal shared) must be bit-identical to sqrtf and '/': 2^32 pseudo-random operand sets over and beyond the fast
+    domain -- exponents across the range, zeros, denormals, values within 2 ulp of exact squares, |n| up to d."""
+    from graphem_rapids_amd import _native
+    for seed in (1, 2):
+        bad_sqrt, bad_div = _native.selftest_arith(1 << 31, seed=seed)
+        assert (bad_sqrt, bad_div) == (0, 0)
