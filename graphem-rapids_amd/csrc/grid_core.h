@@ -1,6 +1,11 @@
-// Sub-quadratic exact KNN of the sampled midpoints for D <= 3 (the reference reaches for
-// cuVS IVF indexes here, embedder_cuvs.py:255-313): a uniform grid over this iteration's midpoints.  Included at
-// the end of knn.hip (it uses that file's K-smallest extraction).
+// Sub-quadratic exact KNN of the sampled midpoints (the reference reaches for cuVS IVF
+// indexes here, embedder_cuvs.py:255-313): a grid over this iteration's midpoints -- for D <= 3 over the midpoints
+// themselves, for 4 <= D <= 16 over their PROJECTION onto the first three coordinates.  Dropping coordinates can only
+// shorten a distance, so the projected ball of radius sqrt(tau) holds every midpoint within sqrt(tau) in all D
+// coordinates: the cells it touches are a complete candidate set and the search stays EXACT (distances, thresholds and
+// the final decision are always taken in all D coordinates); what the projection costs is selectivity -- at D = 4..6 the
+// three coordinates carry most of a distance, at D = 16 a fifth of it.  Included at the end of knn.hip (it uses that
+// file's K-smallest extraction).
 //
 // The filtered brute-force scan (fused.hip) costs S * E pre-filter evaluations per iteration and its thresholds
 // S * E / stride exact distances: quadratic, fine up to a thousand queries or so (hidden under the spring phase's
@@ -53,7 +58,7 @@ __device__ __forceinline__ int grid_coord(float x, float med, float inv_s, int s
 
 // Frame from (up to 1024 of) the query midpoints: per-coordinate median and inter-quartile range by a bitonic
 // sort in LDS.  One 256-thread workgroup.
-__global__ __launch_bounds__(256) void grid_frame_kernel(const float *__restrict__ qt, int64_t S, int D, int half, int shift,
+__global__ __launch_bounds__(256) void grid_frame_kernel(const float *__restrict__ qt, int QS, int64_t S, int D, int half, int shift,
                                                         grid_frame *__restrict__ frame, int32_t *__restrict__ tcount_reset) {
     // set-up done inside the previous normalise launch: the touched-list counter is reset here (as knn_tau_kernel does)
     if (tcount_reset && threadIdx.x == 0) *tcount_reset = 0;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(256) void grid_frame_kernel(const float *__restrict
             if (threadIdx.x == 0) { frame->med[d] = 0.0f; frame->inv_s[d] = 1.0f; }
             continue;
         }
-        for (int i = threadIdx.x; i < 1024; i += 256) v[i] = i < ns ? qt[(i * step) * 4 + d] : INFINITY;  // D <= 3: records of 4 floats
+        for (int i = threadIdx.x; i < 1024; i += 256) v[i] = i < ns ? qt[(i * step) * QS + d] : INFINITY;
         __syncthreads();
         for (int k = 2; k <= 1024; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -89,14 +94,14 @@ __global__ __launch_bounds__(256) void grid_frame_kernel(const float *__restrict
     if (threadIdx.x == 0) { frame->shift = shift; frame->half = half; }
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void grid_cell_kernel(const float *__restrict__ mid, int64_t M,
+template <int D /* grid dimensions: min(n_components, 3) */>
+__global__ __launch_bounds__(256) void grid_cell_kernel(const float *__restrict__ mid, int LD, int64_t M,
                                                        const grid_frame *__restrict__ frame,
                                                        uint32_t *__restrict__ keys, uint32_t *__restrict__ rows) {
     const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= M) return;
     const grid_frame f = *frame;
-    const float4 m = reinterpret_cast<const float4 *>(mid)[j];
+    const float4 m = *reinterpret_cast<const float4 *>(mid + j * LD);   // the first coordinates of the row
     const float c[3] = {m.x, m.y, m.z};
     uint32_t key = 0;
 #pragma unroll
@@ -118,20 +123,29 @@ __device__ __forceinline__ int grid_lower_bound(const uint32_t *__restrict__ ske
     return lo;
 }
 
-// midpoints and edge ids in cell order
-__global__ __launch_bounds__(256) void grid_gather_kernel(const float *__restrict__ mid, const uint32_t *__restrict__ srows,
-                                                         int64_t M, int64_t e_lo, const int32_t *__restrict__ own_eids,
-                                                         float4 *__restrict__ smid, uint32_t *__restrict__ sid) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= M) return;
+// midpoints (whole rows of LD floats) and edge ids in cell order
+__global__ __launch_bounds__(256) void grid_gather_kernel(const float *__restrict__ mid, int LD4 /* float4 per row */,
+                                                         const uint32_t *__restrict__ srows, int64_t M, int64_t e_lo,
+                                                         const int32_t *__restrict__ own_eids, float4 *__restrict__ smid,
+                                                         uint32_t *__restrict__ sid) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= M * LD4) return;
+    const int64_t i = t / LD4;
+    const int part = (int)(t % LD4);
     const uint32_t j = srows[i];
-    smid[i] = reinterpret_cast<const float4 *>(mid)[j];
-    sid[i] = own_eids ? (uint32_t)own_eids[j] : (uint32_t)(e_lo + j);
+    smid[t] = reinterpret_cast<const float4 *>(mid)[(int64_t)j * LD4 + part];
+    if (part == 0) sid[i] = own_eids ? (uint32_t)own_eids[j] : (uint32_t)(e_lo + j);
 }
 
-template <int D>
-__device__ __forceinline__ float grid_d2(const float (&q)[3], const float4 m) {
-    const float mm[3] = {m.x, m.y, m.z};
+// Squared distance in all D coordinates: the exact fma chain in coordinate order (the oracle's go_d2); row i of smid.
+template <int D, int LD>
+__device__ __forceinline__ float grid_d2(const float (&q)[LD], const float4 *__restrict__ smid, int64_t i) {
+    float mm[LD];
+#pragma unroll
+    for (int p = 0; p < LD / 4; ++p) {
+        const float4 v = smid[i * (LD / 4) + p];
+        mm[4 * p] = v.x; mm[4 * p + 1] = v.y; mm[4 * p + 2] = v.z; mm[4 * p + 3] = v.w;
+    }
     float d2 = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -140,33 +154,46 @@ __device__ __forceinline__ float grid_d2(const float (&q)[3], const float4 m) {
     }
     return d2;
 }
+// query record -> coordinates (LD floats, pad 0) and the offset of tau in it (knn.hip gh_qs / gh_qtau)
+template <int D, int LD>
+__device__ __forceinline__ void grid_query(const float *__restrict__ qt, int qi, float (&q)[LD]) {
+    constexpr int QS = D <= 3 ? 4 : LD + 4;
+#pragma unroll
+    for (int p = 0; p < LD / 4; ++p) {
+        const float4 v = reinterpret_cast<const float4 *>(qt + (int64_t)qi * QS)[p];
+        q[4 * p] = v.x; q[4 * p + 1] = v.y; q[4 * p + 2] = v.z; q[4 * p + 3] = v.w;
+    }
+    if constexpr (D <= 3) q[3] = 0.0f;   // (x, y, z|0, tau): slot 3 is tau, not a coordinate
+}
 
 // tau of one query: K-th smallest exact distance among the midpoints of the cells within r of its own cell,
 // the smallest r in 1 .. GH_GRID_RMAX whose block holds K midpoints (else tau = inf: exact fallback in the select
 // kernel).  One workgroup; chunks of 2048 keys through the K-smallest extraction of knn.hip.
 #define GH_GRID_RMAX 6
-template <int D>
+template <int D, int LD>
 __global__ __launch_bounds__(256) void grid_tau_kernel(const float4 *__restrict__ smid, const uint32_t *__restrict__ skeys, int M,
                                                       const grid_frame *__restrict__ frame, float *__restrict__ qt, int K) {
+    constexpr int GD = D < 3 ? D : 3;                 // dimensions of the grid
+    constexpr int QS = D <= 3 ? 4 : LD + 4, QT = D <= 3 ? 3 : LD;
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
     __shared__ int run_beg[(2 * GH_GRID_RMAX + 1) * (2 * GH_GRID_RMAX + 1)], run_len[(2 * GH_GRID_RMAX + 1) * (2 * GH_GRID_RMAX + 1)];
     __shared__ int total;
     const int qi = blockIdx.x;
     const grid_frame f = *frame;
-    const float4 qr = reinterpret_cast<const float4 *>(qt)[qi];
-    const float q[3] = {qr.x, qr.y, qr.z};
+    float q[LD];
+    grid_query<D, LD>(qt, qi, q);
     int c[3] = {0, 0, 0};
     const int G = 2 * f.half;
 #pragma unroll
-    for (int d = 0; d < D; ++d) c[d] = grid_coord(q[d], f.med[d], f.inv_s[d], f.shift, f.half);
+    for (int d = 0; d < GD; ++d) c[d] = grid_coord(q[d], f.med[d], f.inv_s[d], f.shift, f.half);
     constexpr int NPT = 8;
     float tau = INFINITY;
     for (int r = 1; r <= GH_GRID_RMAX; ++r) {
         int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
 #pragma unroll
-        for (int d = 0; d < D; ++d) { lo[d] = max(c[d] - r, 0); hi[d] = min(c[d] + r, G - 1); }
-        const int ny = hi[1] - lo[1] + 1, nz = D == 3 ? hi[2] - lo[2] + 1 : 1, nrun = ny * nz;
+        for (int d = 0; d < GD; ++d) { lo[d] = max(c[d] - r, 0); hi[d] = min(c[d] + r, G - 1); }
+        const int ny = hi[1] - lo[1] + 1, nz = GD == 3 ? hi[2] - lo[2] + 1 : 1, nrun = ny * nz;
         __syncthreads();
         if (threadIdx.x == 0) total = 0;
         __syncthreads();
@@ -196,7 +223,7 @@ __global__ __launch_bounds__(256) void grid_tau_kernel(const float4 *__restrict_
                     int t = 0;
                     while (p >= run_len[t]) { p -= run_len[t]; ++t; }   // a handful of runs
                     const int i = run_beg[t] + p;
-                    key = gh_key(grid_d2<D>(q, smid[i]), (uint32_t)i);
+                    key = gh_key(grid_d2<D, LD>(q, smid, i), (uint32_t)i);
                     if (key < tk) any = 1; else key = GH_KEY_INF;
                 }
                 keys[j] = key;
@@ -210,58 +237,60 @@ __global__ __launch_bounds__(256) void grid_tau_kernel(const float4 *__restrict_
         tau = gh_key_d2(best[K - 1]);
         break;
     }
-    if (threadIdx.x == 0) qt[qi * 4 + 3] = tau;
+    if (threadIdx.x == 0) qt[qi * QS + QT] = tau;
 }
 
 // Queries in regions so sparse that GH_GRID_RMAX rings hold fewer than K midpoints (far outliers of the layout)
 // still need a finite tau: the K-th smallest of the workgroup's 1024 per-thread minima over every `stride`-th midpoint of
 // the cell-sorted array -- the group-minima bound of setup_core.h over a global subset.  Workgroups of queries that
 // already have their tau leave at once.
+template <int D, int LD>
 __global__ __launch_bounds__(1024) void grid_tau_fallback_kernel(const float4 *__restrict__ smid, int64_t M, int64_t stride,
-                                                                int D, float *__restrict__ qt, int K) {
+                                                                float *__restrict__ qt, int K) {
+    constexpr int QS = D <= 3 ? 4 : LD + 4, QT = D <= 3 ? 3 : LD;
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[16 * GH_EXTRACT_MAX_K];
     const int qi = blockIdx.x;
-    const float4 qr = reinterpret_cast<const float4 *>(qt)[qi];
-    if (qr.w < INFINITY) return;
-    const float q[3] = {qr.x, qr.y, qr.z};
+    if (qt[(int64_t)qi * QS + QT] < INFINITY) return;
+    float q[LD];
+    grid_query<D, LD>(qt, qi, q);
     float mn = INFINITY;
-    for (int64_t j = threadIdx.x; j * stride < M; j += 1024) {
-        const float d2 = D == 2 ? grid_d2<2>(q, smid[j * stride]) : grid_d2<3>(q, smid[j * stride]);
-        mn = fminf(mn, d2);
-    }
+    for (int64_t j = threadIdx.x; j * stride < M; j += 1024) mn = fminf(mn, grid_d2<D, LD>(q, smid, j * stride));
     uint64_t keys[1] = {mn < INFINITY ? gh_key(mn, threadIdx.x) : GH_KEY_INF};
     block_extract_smallest<1, 1024>(keys, K, best, red);
-    if (threadIdx.x == 0 && best[K - 1] != GH_KEY_INF) qt[qi * 4 + 3] = gh_key_d2(best[K - 1]);
+    if (threadIdx.x == 0 && best[K - 1] != GH_KEY_INF) qt[(int64_t)qi * QS + QT] = gh_key_d2(best[K - 1]);
 }
 
 // Candidates of one query: every run of cells its box touches, exact distance, keys within tau appended.  The runs are
 // dealt over gridDim.y workgroups: an outlier's box can cover the whole bulk, and one workgroup would read it alone.
-template <int D>
+template <int D, int LD>
 __global__ __launch_bounds__(256) void grid_scan_kernel(const float4 *__restrict__ smid, const uint32_t *__restrict__ sid,
                                                        const uint32_t *__restrict__ skeys, int M,
                                                        const grid_frame *__restrict__ frame,
                                                        const float *__restrict__ qt, uint64_t *__restrict__ cand,
                                                        int32_t *__restrict__ cnt) {
+    constexpr int GD = D < 3 ? D : 3;
+    constexpr int QS = D <= 3 ? 4 : LD + 4, QT = D <= 3 ? 3 : LD;
     const int qi = blockIdx.x;
     const grid_frame f = *frame;
-    const float4 qr = reinterpret_cast<const float4 *>(qt)[qi];   // D <= 3: (q_0, q_1, q_2, tau)
-    const float q[3] = {qr.x, qr.y, qr.z};
-    const float tau = qr.w;
+    float q[LD];
+    grid_query<D, LD>(qt, qi, q);
+    const float tau = qt[(int64_t)qi * QS + QT];
     if (!(tau < INFINITY)) {   // fewer than K midpoints in reach of any bound: mark the list as overflowed, the select
         if (blockIdx.y == 0 && threadIdx.x == 0) cnt[qi * GH_CNT_STRIDE] = GH_CAND_CAP + 1;   // kernel searches this query exactly
         return;
     }
-    // sqrt rounded up a little: the box must contain the ball of the EXACT test below (d2 <= tau)
+    // sqrt rounded up a little: the box must contain the ball of the EXACT test below (d2 <= tau); in the grid's
+    // coordinates alone a midpoint within sqrt(tau) in all D coordinates is within sqrt(tau) too
     const float rad = sqrtf(tau) * 1.000001f + 1e-30f;
     int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < GD; ++d) {
         lo[d] = grid_coord(q[d] - rad, f.med[d], f.inv_s[d], f.shift, f.half);
         hi[d] = grid_coord(q[d] + rad, f.med[d], f.inv_s[d], f.shift, f.half);
     }
     const int G = 2 * f.half;
-    const int ny = hi[1] - lo[1] + 1, nz = D == 3 ? hi[2] - lo[2] + 1 : 1;
+    const int ny = hi[1] - lo[1] + 1, nz = GD == 3 ? hi[2] - lo[2] + 1 : 1;
     // rows of cells along x: one contiguous run each; 256 runs at a time, their ends found by 256 lanes side by side
     __shared__ int rbeg[256], rend[256];
     const int nrun = ny * nz;
@@ -278,7 +307,7 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(const float4 *__restrict
         const int nr = min(256, nrun - r0);
         for (int t = 0; t < nr; ++t)
             for (int i = rbeg[t] + (int)threadIdx.x; i < rend[t]; i += 256) {
-                const float d2 = grid_d2<D>(q, smid[i]);
+                const float d2 = grid_d2<D, LD>(q, smid, i);
                 if (d2 <= tau) gh_append_candidate(cand, cnt, qi, gh_key(d2, sid[i]));
             }
     }
@@ -287,17 +316,17 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(const float4 *__restrict
 }  // namespace
 
 bool gh_grid_path(const gh_engine *h) {
-    return h->prm.knn_method == GH_KNN_GRID && h->D >= 2 && h->D <= 3 && gh_knn_scan_path(h);
+    return h->prm.knn_method == GH_KNN_GRID && h->D >= 2 && h->D <= 16 && gh_knn_scan_path(h);
 }
 
 gh_status gh_grid_alloc(gh_engine *h) {
     if (!gh_grid_path(h)) return GH_OK;
     // cells per binade and axis: 16 (3-D: a central cell holds ~60 of 4M midpoints of a Gaussian core) / 128 (2-D)
-    const int P = h->D == 3 ? 16 : 128;
+    const int P = h->D >= 3 ? 16 : 128;
     const int G = 2 * P * GH_GRID_OCTAVES;
     h->grid_G = G;
     int64_t ncells = 1;
-    for (int d = 0; d < h->D; ++d) ncells *= G;
+    for (int d = 0; d < std::min(h->D, 3); ++d) ncells *= G;
     h->grid_cells = ncells;
     const size_t M = (size_t)h->own_count;
     size_t temp = 0;
@@ -312,7 +341,7 @@ gh_status gh_grid_alloc(gh_engine *h) {
     h->grid_temp_bytes = temp;
     const size_t words = 4 * M + M + 16;   // keys, rows (in + out), edge ids, frame
     if (hipMalloc(reinterpret_cast<void **>(&h->d_grid_u32), sizeof(uint32_t) * words) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&h->d_grid_smid), sizeof(float4) * (M + 1)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&h->d_grid_smid), sizeof(float) * ((size_t)h->LD * M + 4)) != hipSuccess ||
         hipMalloc(&h->d_grid_temp, temp + 16) != hipSuccess) {
         h->err = "hipMalloc of the grid buffers failed";
         return GH_ERR_NOMEM;
@@ -328,29 +357,33 @@ gh_status gh_grid_search(gh_engine *h) {
     grid_frame *frame = reinterpret_cast<grid_frame *>(sid + M);
     float4 *smid = reinterpret_cast<float4 *>(h->d_grid_smid);
     const unsigned gridM = (unsigned)((M + 255) / 256);
+    const int QS = gh_qs(h->D, h->LD), LD4 = h->LD / 4;
     {
         gh_scope t(h, "grid_build");
-        grid_frame_kernel<<<dim3(1), dim3(256), 0, h->stream>>>(h->d_q, h->S, h->D, h->grid_G / 2, h->D == 3 ? 23 - 4 : 23 - 7, frame,
+        grid_frame_kernel<<<dim3(1), dim3(256), 0, h->stream>>>(h->d_q, QS, h->S, std::min(h->D, 3), h->grid_G / 2, h->D >= 3 ? 23 - 4 : 23 - 7, frame,
                                                                   h->tcount_reset_pending ? h->d_tcount : nullptr);
-        if (h->D == 2) grid_cell_kernel<2><<<dim3(gridM), dim3(256), 0, h->stream>>>(h->d_mid, M, frame, keys, rows);
-        else grid_cell_kernel<3><<<dim3(gridM), dim3(256), 0, h->stream>>>(h->d_mid, M, frame, keys, rows);
+        if (h->D == 2) grid_cell_kernel<2><<<dim3(gridM), dim3(256), 0, h->stream>>>(h->d_mid, h->LD, M, frame, keys, rows);
+        else grid_cell_kernel<3><<<dim3(gridM), dim3(256), 0, h->stream>>>(h->d_mid, h->LD, M, frame, keys, rows);
         size_t temp = h->grid_temp_bytes;
         GH_HIP(hipcub::DeviceRadixSort::SortPairs(h->d_grid_temp, temp, keys, skeys, rows, srows, (int)M, 0, h->grid_bits, h->stream));
-        grid_gather_kernel<<<dim3(gridM), dim3(256), 0, h->stream>>>(h->d_mid, srows, M, h->part.edge_lo, h->d_own_eids, smid, sid);
+        grid_gather_kernel<<<dim3((unsigned)((M * LD4 + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, LD4, srows, M, h->part.edge_lo,
+                                                                                               h->d_own_eids, smid, sid);
         GH_LAUNCH_CHECK();
     }
     gh_scope t(h, "grid_tau_scan");
     const int64_t fb_stride = M >= 8 * 64 * (int64_t)h->K ? 8 : 1;   // sparse queries only: a tight bound keeps their boxes small
     const dim3 sgrid((unsigned)h->S, h->S <= 2048 ? 32 : h->S <= 16384 ? 16 : 4);   // an outlier's box can hold the whole bulk: its runs over several workgroups
-    if (h->D == 2) {
-        grid_tau_kernel<2><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(smid, skeys, (int)M, frame, h->d_q, h->K);
-        grid_tau_fallback_kernel<<<dim3((unsigned)h->S), dim3(1024), 0, h->stream>>>(smid, M, fb_stride, h->D, h->d_q, h->K);
-        grid_scan_kernel<2><<<sgrid, dim3(256), 0, h->stream>>>(smid, sid, skeys, (int)M, frame, h->d_q, h->d_cand, h->d_cnt);
-    } else {
-        grid_tau_kernel<3><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(smid, skeys, (int)M, frame, h->d_q, h->K);
-        grid_tau_fallback_kernel<<<dim3((unsigned)h->S), dim3(1024), 0, h->stream>>>(smid, M, fb_stride, h->D, h->d_q, h->K);
-        grid_scan_kernel<3><<<sgrid, dim3(256), 0, h->stream>>>(smid, sid, skeys, (int)M, frame, h->d_q, h->d_cand, h->d_cnt);
+#define GH_GRID_ONE(DD, LL)                                                                                                              \
+    case DD:                                                                                                                              \
+        grid_tau_kernel<DD, LL><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(smid, skeys, (int)M, frame, h->d_q, h->K);                 \
+        grid_tau_fallback_kernel<DD, LL><<<dim3((unsigned)h->S), dim3(1024), 0, h->stream>>>(smid, M, fb_stride, h->d_q, h->K);               \
+        grid_scan_kernel<DD, LL><<<sgrid, dim3(256), 0, h->stream>>>(smid, sid, skeys, (int)M, frame, h->d_q, h->d_cand, h->d_cnt);          \
+        break;
+    switch (h->D) {
+        GH_FOR_EACH_DIM(GH_GRID_ONE)
+        default: h->err = "grid KNN: unsupported dimension"; return GH_ERR_RUNTIME;
     }
+#undef GH_GRID_ONE
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

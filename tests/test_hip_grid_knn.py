@@ -1,7 +1,8 @@
-"""Sub-quadratic KNN: the uniform-grid search of csrc/grid.hip against the exact filtered scan and
-the oracle.  It is an exact method (every midpoint within the threshold ball lies in a visited cell), so "recall against
-the exact kernel" must be 1 and the ids identical, at S in {256, 1024, 4096} and beyond, in 2 and 3 dimensions, for
-states with outliers outside the gridded cube and for a partitioned engine.  Needs a real MI355X."""
+"""Sub-quadratic KNN: the grid search of csrc/grid_core.h against the exact filtered scan and
+the oracle.  It is an exact method (every midpoint within the threshold ball lies in a visited cell -- for
+n_components > 3 the cells are those of the projection onto three coordinates, which can only shorten a distance), so
+"recall against the exact kernel" must be 1 and the ids identical, at S in {256, 1024, 4096} and beyond, for 2 to 16
+components, for states with outliers outside the gridded cube and for a partitioned engine.  Needs a real MI355X."""
 import numpy as np
 import pytest
 
@@ -21,6 +22,8 @@ def _graph(n, deg, seed):
     (60000, 3, 1024, "start"),       # the reference's random start: everything inside a few central cells
     (60000, 3, 1024, "outliers"),    # vertices far outside the gridded cube (border cells are unbounded)
     (200000, 3, 16384, "unit"),      # the regime the method is for
+    (60000, 4, 1024, "unit"), (60000, 5, 4096, "unit"), (60000, 6, 1024, "outliers"), (60000, 8, 1024, "start"),
+    (40000, 12, 1024, "unit"), (40000, 16, 2048, "unit"),   # grid over the first three coordinates, distances in all
 ])
 def test_grid_knn_equals_the_exact_scan_and_the_oracle(n, D, S, state):
     from graphem_rapids_amd import _native
@@ -78,6 +81,26 @@ def test_grid_path_is_taken_and_runs_a_layout():
     assert out.shape == (n, 3) and np.isfinite(out).all()
     with pytest.raises(ValueError):
         gra.create_graphem(gra.edges_to_adjacency(n, edges), n_components=3, backend="hip", verbose=False, knn_method="ivf")
+
+
+def test_grid_knn_at_16_components_on_the_snap_shape():
+    """BASELINE configs[4]'s shape (D = 16, k = 32) with the projected grid: E = 88 K own edges, 4096 queries."""
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    n, D, k, S = 4039, 16, 32, 4096
+    edges = np.ascontiguousarray(gra.erdos_renyi_edges(n, 0.0108, seed=12345), dtype=np.int32)
+    rng = np.random.default_rng(2)
+    pos = rng.standard_normal((n, D)).astype(np.float32)
+    sampled = rng.permutation(len(edges))[:S].astype(np.int32)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_method="grid")
+    eng.set_positions(pos)
+    eng.timing_enable(True)
+    knn = eng.knn_midpoints(sampled)
+    assert "grid_build" in eng.timings()
+    assert np.array_equal(knn, oracle.knn_midpoints(pos, edges, sampled, k))
+    eng.step(sampled)
+    assert np.abs(eng.get_positions() - oracle.step(pos, edges, sampled, k)).max() <= 1e-4
+    eng.close()
 
 
 def test_grid_knn_on_row_partitions_and_auto_choice():
