@@ -3,9 +3,12 @@
 // themselves, for 4 <= D <= 16 over their PROJECTION onto the first three coordinates.  Dropping coordinates can only
 // shorten a distance, so the projected ball of radius sqrt(tau) holds every midpoint within sqrt(tau) in all D
 // coordinates: the cells it touches are a complete candidate set and the search stays EXACT (distances, thresholds and
-// the final decision are always taken in all D coordinates); what the projection costs is selectivity -- at D = 4..6 the
-// three coordinates carry most of a distance, at D = 16 a fifth of it.  Included at the end of knn.hip (it uses that
-// file's K-smallest extraction).
+// the final decision are always taken in all D coordinates); what the projection costs is selectivity, and it costs
+// everything: on the 1 M-vertex bench state the shadow of the threshold ball holds more than the 8192 candidates a list
+// takes and every query falls back to the exhaustive search -- 85 ms per iteration at D = 6, S = 4096 against 1.6 ms for
+// the scan (profiles/r03/knn_method_sweep.log).  Hence D > 3 only with GRAPHEM_HIP_GRID_WIDE=1 (tests, measurements);
+// the matrix-pipe scan is the search for wide rows at every S tried (up to 65536).  Included at the end of knn.hip (it
+// uses that file's K-smallest extraction).
 //
 // The filtered brute-force scan (fused.hip) costs S * E pre-filter evaluations per iteration and its thresholds
 // S * E / stride exact distances: quadratic, fine up to a thousand queries or so (hidden under the spring phase's
@@ -316,7 +319,11 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(const float4 *__restrict
 }  // namespace
 
 bool gh_grid_path(const gh_engine *h) {
-    return h->prm.knn_method == GH_KNN_GRID && h->D >= 2 && h->D <= 16 && gh_knn_scan_path(h);
+    // 4..16 components (grid over three coordinates) only on request: exact, but measured 50-80x SLOWER than the scan on the
+    // 1 M-vertex graph (profiles/r03/knn_method_sweep.log) -- the three-coordinate shadow of a 6- or 16-dimensional
+    // threshold ball holds more midpoints than a candidate list takes, and every query ends in the exhaustive fallback
+    const bool wide = getenv("GRAPHEM_HIP_GRID_WIDE") != nullptr;
+    return h->prm.knn_method == GH_KNN_GRID && h->D >= 2 && h->D <= (wide ? 16 : 3) && gh_knn_scan_path(h);
 }
 
 gh_status gh_grid_alloc(gh_engine *h) {

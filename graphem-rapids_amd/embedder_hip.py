@@ -63,11 +63,11 @@ class GraphEmbedderHIP:
             global CPU generator exactly as the reference's CPU backend does (pt.py:409);
             'device' uses the engine's on-GPU sampler (no host work in the loop);
             'auto' = 'torch' up to 2**20 edges, 'device' above.
-        knn_method : 'scan' (exact filtered brute-force scan fused with the spring phase), 'grid' (n_components <= 16:
-            exact search through a grid over the midpoints -- over their first three coordinates when there are more --
-            rebuilt every iteration: sub-quadratic, pays from several thousand sampled midpoints on; the counterpart of
-            the reference's cuVS indexes, embedder_cuvs.py:255-313), or 'auto' = 'grid' when n_components <= 3 and
-            sample_size >= 12288.
+        knn_method : 'scan' (exact filtered brute-force scan fused with the spring phase), 'grid' (n_components <= 3:
+            exact search through a grid over the midpoints rebuilt every iteration -- sub-quadratic, pays from
+            several thousand sampled midpoints on; the counterpart of the reference's cuVS indexes,
+            embedder_cuvs.py:255-313; with more components the scan is taken), or 'auto' = 'grid' when
+            n_components <= 3 and sample_size >= 12288.
         knn_distance : 'cdist' ranks the neighbours on the value torch.cdist gives (ATen's matmul form, fp32) and orders
             equal values as torch.topk does, i.e. the neighbour ids of the reference's PyTorch-CPU backend row for row
             (pt.py:580-583); 'exact' ranks on the exact-difference squared distance, ties on the smaller id (what the

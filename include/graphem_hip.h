@@ -70,10 +70,10 @@ typedef struct {
  * embedder_cuvs.py:255-313).  Every method returns the EXACT k+1 nearest midpoints, identical ids.
  *   GH_KNN_SCAN  filtered brute-force scan fused with the spring phase: S * E pre-filter evaluations on the matrix
  *                pipe, hidden under the spring phase's gathers up to a few thousand queries;
- *   GH_KNN_GRID  n_components <= 16: a grid over the midpoints (over their first three coordinates when there are
- *                more: a projection can only shorten a distance, so the cells the projected threshold ball touches
- *                still hold every candidate) rebuilt every iteration (O(E)), then per query only those cells:
- *                sub-quadratic, pays from several thousand queries on (n_components <= 3; later with more);
+ *   GH_KNN_GRID  n_components <= 3: a grid over the midpoints rebuilt every iteration (O(E)), then per query only the
+ *                cells its threshold ball touches: sub-quadratic, pays from several thousand queries on.  (With more
+ *                components the same search over the first three coordinates stays exact but does not pay -- measured
+ *                50-80x slower than the scan at a million vertices -- and is refused unless GRAPHEM_HIP_GRID_WIDE is set.)
  *   GH_KNN_AUTO  SCAN, or GRID when n_components <= 3 and sample_size >= 12288. */
 #define GH_KNN_AUTO 0
 #define GH_KNN_SCAN 1

@@ -25,8 +25,9 @@ def _graph(n, deg, seed):
     (60000, 4, 1024, "unit"), (60000, 5, 4096, "unit"), (60000, 6, 1024, "outliers"), (60000, 8, 1024, "start"),
     (40000, 12, 1024, "unit"), (40000, 16, 2048, "unit"),   # grid over the first three coordinates, distances in all
 ])
-def test_grid_knn_equals_the_exact_scan_and_the_oracle(n, D, S, state):
+def test_grid_knn_equals_the_exact_scan_and_the_oracle(n, D, S, state, monkeypatch):
     from graphem_rapids_amd import _native
+    monkeypatch.setenv("GRAPHEM_HIP_GRID_WIDE", "1")   # 4..16 components: exact too, but slower than the scan, off by default
     k = 10
     edges = _graph(n, 8, seed=3)
     rng = np.random.default_rng(5)
@@ -83,10 +84,11 @@ def test_grid_path_is_taken_and_runs_a_layout():
         gra.create_graphem(gra.edges_to_adjacency(n, edges), n_components=3, backend="hip", verbose=False, knn_method="ivf")
 
 
-def test_grid_knn_at_16_components_on_the_snap_shape():
+def test_grid_knn_at_16_components_on_the_snap_shape(monkeypatch):
     """BASELINE configs[4]'s shape (D = 16, k = 32) with the projected grid: E = 88 K own edges, 4096 queries."""
     import graphem_rapids_amd as gra
     from graphem_rapids_amd import _native
+    monkeypatch.setenv("GRAPHEM_HIP_GRID_WIDE", "1")
     n, D, k, S = 4039, 16, 32, 4096
     edges = np.ascontiguousarray(gra.erdos_renyi_edges(n, 0.0108, seed=12345), dtype=np.int32)
     rng = np.random.default_rng(2)

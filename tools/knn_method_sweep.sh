@@ -1,13 +1,11 @@
 #!/bin/bash
-# scan vs grid KNN over the number of sampled midpoints.  Usage: tools/knn_method_sweep.sh out_prefix workload S...
-out=$1; wl=$2; shift 2
+# Iteration time of the filtered scan against the grid KNN over the number of sampled midpoints.
+# Usage: tools/knn_method_sweep.sh <workload> <dim or 0> S1 S2 ...
+wl=${1:-rr1m}; dim=${2:-0}; shift 2
+extra=""; [ "$dim" != "0" ] && extra="--dim $dim"
 for S in "$@"; do
   for m in scan grid; do
-    python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --sample-size $S --knn $m > ${out}_${wl}_S${S}_${m}.json 2>/dev/null || { echo "S=$S $m failed"; continue; }
-    python - <<PY
-import json
-d=json.loads(open("${out}_${wl}_S${S}_${m}.json").read().strip().splitlines()[-1])
-print("S=$S $m", "%.1f us" % (1e3*d["ms_per_step"]), {k: round(v["avg_us"],1) for k,v in d["kernels"].items()})
-PY
+    python bench.py --workload $wl $extra --sample-size $S --knn $m --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$wl dim=$dim S=$S $m: %9.1f us/iter ' % (1e3*d['ms_per_step']), {k: round(v['avg_us'],1) for k,v in d['kernels'].items()})"
   done
 done
