@@ -26,6 +26,8 @@ SYMBOLS = [
     "gh_comm_unique_id", "gh_comm_init_rccl", "gh_loopback_group_create", "gh_loopback_group_destroy",
     "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error", "gh_debug_stamps",
     "gh_knn_cdist_stats", "gh_rank_layout", "gh_step_finish_own", "gh_comm_available", "gh_selftest_arith",
+    "gh_create_f64", "gh_set_positions_f64", "gh_get_positions_f64", "gh_positions_device_f64", "gh_spring_forces_f64",
+    "gh_intersection_forces_f64",
 ]
 
 
@@ -93,6 +95,16 @@ def load():
     L.gh_rank_layout.restype = ctypes.c_int
     L.gh_step_finish_own.argtypes = [vp, vp, i32]
     L.gh_step_finish_own.restype = ctypes.c_int
+    L.gh_create_f64.argtypes = [ctypes.POINTER(vp), ctypes.c_int, i64, i32, i64, vp, ctypes.POINTER(GhParams),
+                                ctypes.c_double, ctypes.c_double, ctypes.c_double]
+    L.gh_create_f64.restype = ctypes.c_int
+    for name in ("gh_set_positions_f64", "gh_get_positions_f64", "gh_spring_forces_f64"):
+        getattr(L, name).argtypes = [vp, vp]
+        getattr(L, name).restype = ctypes.c_int
+    L.gh_positions_device_f64.argtypes = [vp]
+    L.gh_positions_device_f64.restype = vp
+    L.gh_intersection_forces_f64.argtypes = [vp, vp, vp, vp]
+    L.gh_intersection_forces_f64.restype = ctypes.c_int
     L.gh_selftest_arith.argtypes = [ctypes.c_int, ctypes.c_uint64, i64, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.gh_selftest_arith.restype = ctypes.c_int
     L.gh_comm_available.argtypes = []
@@ -186,10 +198,18 @@ class Engine:
     """Thin RAII wrapper over a gh_handle."""
 
     def __init__(self, n, D, edges, L_min, k_attr, k_inter, n_neighbors, sample_size, seed=0, device_id=0,
-                 partition=None, reorder="auto", knn_method="auto", knn_distance="exact"):
+                 partition=None, reorder="auto", knn_method="auto", knn_distance="exact", dtype="float32"):
+        """dtype='float64': the engine of csrc/f64.hip -- every phase in double; positions, spring and intersection forces
+        cross the boundary as float64 arrays (whole graph only; reorder / knn_method / knn_distance do not apply)."""
         self.lib = load()
         self.handle = ctypes.c_void_p()
         self.n, self.D = int(n), int(D)
+        if dtype not in ("float32", "float64"):
+            raise ValueError(f"dtype must be 'float32' or 'float64', got {dtype!r}")
+        self.f64 = dtype == "float64"
+        self.np_dtype = np.float64 if self.f64 else np.float32
+        if self.f64 and partition is not None:
+            raise ValueError("the float64 engine takes the whole graph (no partition)")
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
         self.E = edges.shape[0]
         prm = GhParams(float(L_min), float(k_attr), float(k_inter), int(n_neighbors), int(sample_size),
@@ -198,8 +218,12 @@ class Engine:
         if partition is not None:
             vals = [int(x) for x in partition]  # (row_lo, row_hi, edge_lo, edge_hi[, edge_rule])
             part = ctypes.pointer(GhPartition(*(vals + [EDGES_RANGE] * (5 - len(vals)))))
-        st = self.lib.gh_create(ctypes.byref(self.handle), int(device_id), self.n, self.D, self.E, ptr(edges),
-                                ctypes.byref(prm), part)
+        if self.f64:
+            st = self.lib.gh_create_f64(ctypes.byref(self.handle), int(device_id), self.n, self.D, self.E, ptr(edges),
+                                        ctypes.byref(prm), float(L_min), float(k_attr), float(k_inter))
+        else:
+            st = self.lib.gh_create(ctypes.byref(self.handle), int(device_id), self.n, self.D, self.E, ptr(edges),
+                                    ctypes.byref(prm), part)
         if st != GH_OK:
             self.handle = ctypes.c_void_p()
             raise_for(st, None)
@@ -222,14 +246,14 @@ class Engine:
         raise_for(st, self.handle)
 
     def set_positions(self, pos):
-        pos = np.ascontiguousarray(pos, dtype=np.float32)
+        pos = np.ascontiguousarray(pos, dtype=self.np_dtype)
         if pos.shape != (self.n, self.D):
             raise ValueError(f"positions must have shape {(self.n, self.D)}, got {pos.shape}")
-        self._chk(self.lib.gh_set_positions(self.handle, ptr(pos)))
+        self._chk((self.lib.gh_set_positions_f64 if self.f64 else self.lib.gh_set_positions)(self.handle, ptr(pos)))
 
     def get_positions(self):
-        out = np.empty((self.n, self.D), dtype=np.float32)
-        self._chk(self.lib.gh_get_positions(self.handle, ptr(out)))
+        out = np.empty((self.n, self.D), dtype=self.np_dtype)
+        self._chk((self.lib.gh_get_positions_f64 if self.f64 else self.lib.gh_get_positions)(self.handle, ptr(out)))
         return out
 
     def _ids(self, sampled):
@@ -256,8 +280,8 @@ class Engine:
         self._chk(self.lib.gh_sync(self.handle))
 
     def spring_forces(self):
-        F = np.empty((self.n, self.D), dtype=np.float32)
-        self._chk(self.lib.gh_spring_forces(self.handle, ptr(F)))
+        F = np.empty((self.n, self.D), dtype=self.np_dtype)
+        self._chk((self.lib.gh_spring_forces_f64 if self.f64 else self.lib.gh_spring_forces)(self.handle, ptr(F)))
         return F
 
     def knn_midpoints(self, sampled=None):
@@ -271,8 +295,8 @@ class Engine:
         knn = np.ascontiguousarray(knn, dtype=np.int32)
         if knn.shape != (self.S, self.k):
             raise ValueError(f"knn must have shape {(self.S, self.k)}, got {knn.shape}")
-        F = np.empty((self.n, self.D), dtype=np.float32)
-        self._chk(self.lib.gh_intersection_forces(self.handle, ptr(s), ptr(knn), ptr(F)))
+        F = np.empty((self.n, self.D), dtype=self.np_dtype)
+        self._chk((self.lib.gh_intersection_forces_f64 if self.f64 else self.lib.gh_intersection_forces)(self.handle, ptr(s), ptr(knn), ptr(F)))
         return F
 
     def integrate_normalise(self, Fs, Fi):
@@ -362,7 +386,7 @@ class Engine:
         self._chk(self.lib.gh_run_partitioned(self.handle, int(iters), ptr(ss)))
 
     def positions_device_ptr(self):
-        return self.lib.gh_positions_device(self.handle)
+        return (self.lib.gh_positions_device_f64 if self.f64 else self.lib.gh_positions_device)(self.handle)
 
     def knn_partial_device_ptr(self):
         return self.lib.gh_knn_partial_device(self.handle)

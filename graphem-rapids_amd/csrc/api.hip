@@ -9,6 +9,7 @@
 #include <string.h>
 
 static thread_local std::string g_create_error;
+void gh_set_create_error(const std::string &msg) { g_create_error = msg; }
 
 // ---- timing ------------------------------------------------------------------------
 gh_scope::gh_scope(gh_engine *h_, const char *name) : h(h_) {
@@ -73,7 +74,15 @@ static gh_status check_handle(gh_engine *h) {
     return GH_OK;
 }
 
+// Entry points of the float32 engine's internals have no meaning on a float64 engine (f64.hip).
+static gh_status reject_f64(gh_engine *h, const char *what) {
+    if (!h->f64) return GH_OK;
+    h->err = std::string(what) + " is not available on a float64 engine";
+    return GH_ERR_INVALID;
+}
+
 static void free_all(gh_engine *h) {
+    gh_f64_free(h);
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
                     h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rare, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
@@ -484,6 +493,7 @@ extern "C" const char *gh_last_error(gh_handle h) { return h ? h->err.c_str() : 
 // ---- positions ---------------------------------------------------------------------
 extern "C" gh_status gh_set_positions(gh_handle h, const float *pos) {
     GH_TRY(check_handle(h));
+    if (h->f64) return pos ? gh_f64_set_positions_f32(h, pos) : GH_ERR_INVALID;
     if (!pos) { h->err = "positions is NULL"; return GH_ERR_INVALID; }
     h->presetup_valid = false;
     GH_HIP(hipMemcpyAsync(h->d_io, pos, sizeof(float) * (size_t)h->n * h->D, hipMemcpyHostToDevice, h->stream));
@@ -524,12 +534,13 @@ static gh_status check_device_waits(gh_engine *h) {
 
 extern "C" gh_status gh_get_positions(gh_handle h, float *pos) {
     GH_TRY(check_handle(h));
+    if (h->f64) return pos ? gh_f64_get_positions_f32(h, pos) : GH_ERR_INVALID;
     if (!pos) { h->err = "positions is NULL"; return GH_ERR_INVALID; }
     GH_TRY(check_device_waits(h));
     return download_padded(h, h->d_pos, pos);
 }
 
-extern "C" float *gh_positions_device(gh_handle h) { return h ? h->d_pos : nullptr; }
+extern "C" float *gh_positions_device(gh_handle h) { return h && !h->f64 ? h->d_pos : nullptr; }
 extern "C" gh_status gh_vertex_order(gh_handle h, int32_t *order) {
     GH_TRY(check_handle(h));
     if (!order) { h->err = "order is NULL"; return GH_ERR_INVALID; }
@@ -537,7 +548,7 @@ extern "C" gh_status gh_vertex_order(gh_handle h, int32_t *order) {
     return GH_OK;
 }
 extern "C" const float *gh_positions_unpadded_device(gh_handle h) {
-    if (!h || hipSetDevice(h->device) != hipSuccess) return nullptr;
+    if (!h || h->f64 || hipSetDevice(h->device) != hipSuccess) return nullptr;
     if (gh_launch_unpad(h, h->d_pos, h->d_io) != GH_OK) return nullptr;
     if (hipStreamSynchronize(h->stream) != hipSuccess) return nullptr;
     return h->d_io;
@@ -640,6 +651,7 @@ static gh_status step_finish(gh_engine *h, int next_mode = -1, int32_t *next_ids
 
 extern "C" gh_status gh_step(gh_handle h, const int32_t *sampled) {
     GH_TRY(check_handle(h));
+    if (h->f64) return gh_f64_step(h, sampled);
     GH_TRY(check_whole(h, "gh_step"));
     GH_TRY(check_k(h));
     GH_TRY(set_sample(h, sampled, nullptr));
@@ -744,6 +756,7 @@ static gh_status graph_replay(gh_engine *h, int32_t count, int32_t *done) {
 
 extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_stream) {
     GH_TRY(check_handle(h));
+    if (h->f64) return iters < 0 ? GH_ERR_INVALID : gh_f64_run(h, iters, sample_stream);
     if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
     if (iters == 0) return GH_OK;
     GH_TRY(check_whole(h, "gh_run"));
@@ -781,6 +794,7 @@ extern "C" gh_status gh_sync(gh_handle h) {
 // ---- multi-GPU split step ----------------------------------------------------------
 extern "C" gh_status gh_step_begin(gh_handle h, const int32_t *sampled) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_step_begin"));
     GH_TRY(check_k(h));
     h->last_step_own_ids = sampled == nullptr;
     GH_TRY(set_sample(h, sampled, nullptr));
@@ -796,6 +810,7 @@ gh_status gh_step_begin_device_ids(gh_engine *h, const int32_t *dev_ids) {
 }
 extern "C" gh_status gh_set_stream(gh_handle h, void *hip_stream, int32_t use_own) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_set_stream"));
     GH_HIP(hipStreamSynchronize(h->stream));
     resolve_timers(h);
     h->stream = use_own ? h->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
@@ -805,6 +820,7 @@ extern "C" int64_t gh_positions_rows_allocated(gh_handle h) { return h ? h->pos_
 extern "C" uint64_t *gh_knn_partial_device(gh_handle h) { return h ? h->d_partial : nullptr; }
 extern "C" gh_status gh_step_merge(gh_handle h, const uint64_t *gathered, int32_t world) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_step_merge"));
     if (!gathered || world < 1) { h->err = "bad gathered buffer / world size"; return GH_ERR_INVALID; }
     return step_merge(h, gathered, world);
 }
@@ -812,11 +828,13 @@ extern "C" double *gh_stats_partial_device(gh_handle h) { return h ? h->d_stats 
 extern "C" int32_t gh_stats_rows(gh_handle h) { return h ? 2 + 2 * gh_fix_blocks(h->LD) : 0; }
 extern "C" gh_status gh_step_finish(gh_handle h) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_step_finish"));
     return step_finish(h);
 }
 
 extern "C" gh_status gh_gather_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_gather_layout"));
     if (world < 1 || rank < 0 || rank >= world || chunk < 1 || chunk * world < h->n ||
         h->part.row_lo != std::min<int64_t>(h->n, rank * chunk) || h->part.row_hi != std::min<int64_t>(h->n, (rank + 1) * chunk)) {
         h->err = "gather layout does not match the engine's row partition";
@@ -837,6 +855,7 @@ extern "C" gh_status gh_gather_layout(gh_handle h, int32_t world, int32_t rank, 
 }
 extern "C" gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_rank_layout"));
     if (world < 1 || rank < 0 || rank >= world || chunk < 1 || chunk * world < h->n || chunk * world > h->pos_rows ||
         h->part.row_lo != std::min<int64_t>(h->n, rank * chunk) || h->part.row_hi != std::min<int64_t>(h->n, (rank + 1) * chunk)) {
         h->err = "rank layout does not match the engine's row partition";
@@ -869,6 +888,7 @@ extern "C" gh_status gh_step_finish_gathered(gh_handle h) {
 
 extern "C" gh_status gh_radial_topk(gh_handle h, int32_t k, int32_t *ids) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_radial_topk"));
     if (!ids) { h->err = "ids is NULL"; return GH_ERR_INVALID; }
     if (k < 1 || k > 64 || k > h->n) { h->err = "gh_radial_topk: k must be in [1, min(n, 64)]"; return GH_ERR_INVALID; }
     int nparts = (int)((h->n + 2047) / 2048);
@@ -892,6 +912,7 @@ extern "C" gh_status gh_radial_topk(gh_handle h, int32_t k, int32_t *ids) {
 
 extern "C" gh_status gh_spring_forces(gh_handle h, float *F) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_spring_forces (use gh_spring_forces_f64)"));
     if (!F) { h->err = "F is NULL"; return GH_ERR_INVALID; }
     GH_TRY(gh_launch_spring_only(h, h->d_tmpF));
     return download_padded(h, h->d_tmpF, F);
@@ -899,6 +920,7 @@ extern "C" gh_status gh_spring_forces(gh_handle h, float *F) {
 
 extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32_t *knn) {
     GH_TRY(check_handle(h));
+    if (h->f64) return knn ? gh_f64_knn_midpoints(h, sampled, knn) : GH_ERR_INVALID;
     if (!knn) { h->err = "knn is NULL"; return GH_ERR_INVALID; }
     GH_TRY(check_whole(h, "gh_knn_midpoints"));
     GH_TRY(check_k(h));
@@ -915,6 +937,7 @@ extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32
 
 extern "C" gh_status gh_intersection_forces(gh_handle h, const int32_t *sampled, const int32_t *knn, float *F) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_intersection_forces (use gh_intersection_forces_f64)"));
     if (!knn || !F) { h->err = "NULL argument"; return GH_ERR_INVALID; }
     GH_TRY(check_whole(h, "gh_intersection_forces"));
     if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
@@ -936,6 +959,7 @@ extern "C" gh_status gh_intersection_forces(gh_handle h, const int32_t *sampled,
 
 extern "C" gh_status gh_integrate_normalise(gh_handle h, const float *Fs, const float *Fi, float *out) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_integrate_normalise"));
     if (!Fs || !Fi || !out) { h->err = "NULL argument"; return GH_ERR_INVALID; }
     GH_TRY(check_whole(h, "gh_integrate_normalise"));
     const size_t bytes = sizeof(float) * (size_t)h->n * h->D;
@@ -1000,6 +1024,7 @@ extern "C" gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64
 
 extern "C" gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final_counts, int32_t *overflow) {
     GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_knn_last_counts"));
     const size_t bytes = sizeof(int32_t) * (size_t)h->S;
     if (subset_counts) GH_HIP(hipMemcpyAsync(subset_counts, h->d_dbg_cnt, bytes, hipMemcpyDeviceToHost, h->stream));
     if (final_counts) GH_HIP(hipMemcpyAsync(final_counts, h->d_dbg_cnt + h->S, bytes, hipMemcpyDeviceToHost, h->stream));

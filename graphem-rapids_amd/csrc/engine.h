@@ -29,10 +29,12 @@ struct gh_timer_slot {
 };
 
 struct gh_comm;   // comm.hip: collective backend of the native partitioned loop
+struct gh_f64;    // f64.hip: state of a float64 engine (gh_create_f64)
 
 struct gh_engine {
     int device = 0;
     gh_comm *comm = nullptr;
+    gh_f64 *f64 = nullptr;    // non-null: a float64 engine -- only this, the sizes, the parameters and the stream are in use
     int64_t n = 0, E = 0;
     int D = 0, LD = 0, k = 0, K = 0;
     int64_t S = 0;
@@ -182,6 +184,14 @@ struct gh_scope {
 gh_status gh_upload_sample_stream(gh_engine *h, int32_t iters, const int32_t *sample_stream, const int32_t **d_ids);
 gh_status gh_step_begin_device_ids(gh_engine *h, const int32_t *dev_ids);
 void gh_comm_free(gh_engine *h);
+// f64.hip
+void gh_set_create_error(const std::string &msg);   // (api.hip) message gh_last_error(NULL) returns
+void gh_f64_free(gh_engine *h);
+gh_status gh_f64_set_positions_f32(gh_engine *h, const float *pos);
+gh_status gh_f64_get_positions_f32(gh_engine *h, float *pos);
+gh_status gh_f64_step(gh_engine *h, const int32_t *sampled);
+gh_status gh_f64_run(gh_engine *h, int32_t iters, const int32_t *sample_stream);
+gh_status gh_f64_knn_midpoints(gh_engine *h, const int32_t *sampled, int32_t *knn);
 // knn.hip
 gh_status gh_knn_local(gh_engine *h, bool fuse_intersect);  // d_sampled, d_mid -> d_partial (unfused)
 bool gh_knn_scan_path(const gh_engine *h);

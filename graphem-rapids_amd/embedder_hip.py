@@ -102,12 +102,11 @@ class GraphEmbedderHIP:
         self.n_components = n_components
         if dtype not in (torch.float32, torch.float64, torch.float16):
             raise ValueError(f"unsupported dtype {dtype}")
-        self.dtype = dtype  # storage dtype of the tensor views; the kernels compute in float32
-        if dtype != torch.float32:
-            # the reference computes in whatever dtype it is given (pt.py:56); this backend's kernels are float32
-            # only, so say it instead of silently accepting (positions are still returned / exposed in `dtype`)
-            self._dtype_note = (f"GraphEmbedderHIP computes in float32; dtype={dtype} only sets the dtype of the "
-                                "positions it returns")
+        # pt.py:56: the reference computes in the dtype it is given.  float32: the fused engine; float64: the float64
+        # engine (csrc/f64.hip, every phase in double); float16: computed in float32, returned in float16 (logged)
+        self.dtype = dtype
+        if dtype == torch.float16:
+            self._dtype_note = "GraphEmbedderHIP computes in float32; dtype=torch.float16 only sets the dtype of the positions it returns"
             logging.getLogger(__name__).warning(self._dtype_note)
         self.L_min = L_min
         self.k_attr = k_attr
@@ -157,7 +156,9 @@ class GraphEmbedderHIP:
             self._engine_seed = 0
         self._engine = _native.Engine(
             self.n, n_components, self._edges_np, L_min, k_attr, k_inter, n_neighbors, self.sample_size,
-            seed=self._engine_seed, device_id=self.device.index, knn_method=knn_method, knn_distance=knn_distance)
+            seed=self._engine_seed, device_id=self.device.index, knn_method=knn_method,
+            knn_distance="exact" if dtype == torch.float64 else knn_distance,
+            dtype="float64" if dtype == torch.float64 else "float32")
         if self.verbose:
             self.logger.info("Initialized GraphEmbedderHIP on %s", self.device)
             self.logger.info("Graph: %d vertices, %d edges, %dD", self.n, self.n_edges, self.n_components)
@@ -178,7 +179,7 @@ class GraphEmbedderHIP:
             p0 = (np.random.randn(self.n, self.n_components) * 0.1).astype(np.float32)
         else:
             raise ValueError(f"Invalid init: {init}")
-        self._engine.set_positions(p0)
+        self._engine.set_positions(p0)   # (a float64 engine takes the start as float64: pt.py:372-376 casts it to dtype)
 
     # ---- construction helpers (boundary, host side) -----------------------------------
     @staticmethod
@@ -226,19 +227,22 @@ class GraphEmbedderHIP:
     @property
     def positions(self):
         """Host numpy copy of the positions, shape (n, D)."""
-        out = self._engine.get_positions()
-        return out if self.dtype == torch.float32 else out.astype(
-            {torch.float64: np.float64, torch.float16: np.float16}[self.dtype])
+        out = self._engine.get_positions()   # float64 from a float64 engine
+        return out.astype(np.float16) if self.dtype == torch.float16 else out
 
     @positions.setter
     def positions(self, value):
         if isinstance(value, torch.Tensor):
-            value = value.detach().to("cpu", torch.float32).numpy()
-        self._engine.set_positions(np.asarray(value, dtype=np.float32))
+            value = value.detach().to("cpu", torch.float64 if self._engine.f64 else torch.float32).numpy()
+        self._engine.set_positions(np.asarray(value, dtype=self._engine.np_dtype))
 
     @property
     def _positions(self):
         """Device tensor of the positions (callers and tests read .device / .dtype / values)."""
+        if self._engine.f64:
+            self._engine.sync()
+            return device_view(self._engine.positions_device_ptr(), (self.n, self.n_components), torch.float64,
+                               self.device, self._engine).clone()
         view = device_view(self._engine.positions_unpadded_device_ptr(), (self.n, self.n_components), torch.float32,
                            self.device, self._engine).clone()  # the engine reuses that buffer
         return view if self.dtype == torch.float32 else view.to(self.dtype)

@@ -120,6 +120,24 @@ void gh_destroy(gh_handle h);
 /* Message of the last failure on h (h may be NULL for a failed gh_create). */
 const char *gh_last_error(gh_handle h);
 
+/* ---- float64 engine (pt.py:56: the reference computes in the dtype it is created with; tests/test_pytorch_backend.py:
+ *      169-181) --------------------------------------------------------------------------------------------------
+ * gh_create_f64 makes an engine whose every phase runs in double: positions (n, D) doubles, spring forces, the exact
+ * KNN ranked on double distances (ties on the smaller id), intersection forces, means and unbiased std in double.
+ * Plain kernels, one per phase (csrc/f64.hip): what this mode is for is the reference's fp64 numbers, not speed.
+ * On such a handle: gh_set_positions / gh_get_positions convert from / to float32, the *_f64 accessors below move
+ * doubles; gh_step, gh_run, gh_sync, gh_knn_midpoints, gh_destroy, gh_last_error work as on a float32 engine; every
+ * other entry point (partitions, collectives, float32 per-phase calls, instrumentation of the fused kernels) returns
+ * GH_ERR_INVALID.  gh_params.reorder / knn_method / knn_distance are ignored.  Up to 32 components, 255 neighbours. */
+gh_status gh_create_f64(gh_handle *out, int device_id, int64_t n, int32_t n_components, int64_t n_edges,
+                        const int32_t *edges, const gh_params *params /* its three float constants are NOT used: */,
+                        double L_min, double k_attr, double k_inter /* pt.py:57-59 as the doubles Python holds */);
+gh_status gh_set_positions_f64(gh_handle h, const double *pos /* (n, D) host */);
+gh_status gh_get_positions_f64(gh_handle h, double *pos /* (n, D) host, blocking */);
+double *gh_positions_device_f64(gh_handle h);                 /* (n, D) doubles, caller's vertex order, no padding */
+gh_status gh_spring_forces_f64(gh_handle h, double *F);      /* _compute_spring_forces (pt.py:595-636) in double */
+gh_status gh_intersection_forces_f64(gh_handle h, const int32_t *sampled, const int32_t *knn, double *F);   /* pt.py:638-774 */
+
 /* ---- positions accessors: `positions` property / setter, get_positions
  *      (pt.py:324-335, 835-844) ------------------------------------------------ */
 gh_status gh_set_positions(gh_handle h, const float *pos /* (n, D) host */);

@@ -38,6 +38,12 @@ CASES = {
                        iters=4, steps=[0, 1, 3]),
     "d4_rr300": dict(graph=("rr", 300, 6, 11), D=4, kw=dict(n_neighbors=10, sample_size=128, seed=6),
                      iters=4, steps=[0, 3]),
+    # the reference computing in float64 (pt.py:56 dtype; tests/test_pytorch_backend.py:169-181): fixtures of the float64 engine
+    "c1_er1000_f64": dict(graph=("er", 1000, 0.01, 0), D=3, kw=dict(seed=0, dtype="float64"),
+                          iters=6, steps=[0, 1, 2, 5]),
+    "d16_er2000_f64": dict(graph=("er", 2000, 0.005, 5), D=16,
+                           kw=dict(n_neighbors=32, sample_size=256, seed=5, dtype="float64"),
+                           iters=3, steps=[0, 2]),
 }
 
 
@@ -70,8 +76,11 @@ def worker(name):
     else:
         raise ValueError(g)
 
+    kw = dict(spec["kw"])
+    if kw.get("dtype") == "float64":
+        kw["dtype"] = torch.float64
     emb = gr.create_graphem(adj, n_components=spec["D"], backend="pytorch", device="cpu",
-                            verbose=False, **spec["kw"])
+                            verbose=False, **kw)
     out = {}
     edges = emb.edges.numpy()
     out["edges"] = edges.astype(np.int32)

@@ -1,0 +1,77 @@
+"""The float64 engine (csrc/f64.hip, gh_create_f64; dtype=torch.float64 on the public class) against fixtures the REFERENCE
+produced computing in float64 (tests/golden/make_golden.py cases *_f64: create_graphem(..., dtype=torch.float64), pt.py:56;
+the reference's own test of this is tests/test_pytorch_backend.py:169-181).  Needs a real MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["c1_er1000_f64", "d16_er2000_f64"])
+def test_every_phase_and_one_step_in_float64(case):
+    from graphem_rapids_amd import _native
+    g = np.load(os.path.join(GOLDEN_DIR, case + ".npz"))
+    n, D, k, S = int(g["n"]), int(g["D"]), int(g["k"]), int(g["S"])
+    Lm, ka, ki = (float(x) for x in g["params"])
+    eng = _native.Engine(n, D, g["edges"], Lm, ka, ki, k, S, dtype="float64")
+    worst = {}
+    for t in g["steps"]:
+        pos, sampled = g[f"pos_{t}"], g[f"sampled_{t}"]
+        assert pos.dtype == np.float64
+        eng.set_positions(pos)
+        assert np.array_equal(eng.get_positions(), pos)
+        F = eng.spring_forces()
+        ref = g[f"F_spring_{t}"]
+        worst["spring"] = max(worst.get("spring", 0.0), float(np.abs(F - ref).max() / max(1.0, np.abs(ref).max())))
+        knn = eng.knn_midpoints(sampled)
+        assert np.array_equal(knn, g[f"knn_{t}"]), f"{case} step {t}: neighbour ids"
+        Fi = eng.intersection_forces(sampled, g[f"knn_{t}"])
+        ref = g[f"F_inter_{t}"]
+        worst["inter"] = max(worst.get("inter", 0.0), float(np.abs(Fi - ref).max() / max(1.0, np.abs(ref).max())))
+        eng.step(sampled)
+        out = eng.get_positions()
+        assert out.dtype == np.float64
+        worst["p2"] = max(worst.get("p2", 0.0), float(np.abs(out - g[f"pos_next_{t}"]).max()))
+    eng.close()
+    print(f"\n{case}: float64 engine vs the reference in float64:", worst)
+    assert worst["spring"] <= 1e-13 and worst["inter"] <= 1e-12 and worst["p2"] <= 1e-10, worst
+
+
+def test_float64_trajectory_and_public_api():
+    """Three iterations with the reference's sample stream stay within 1e-9 of its float64 trajectory; the public class
+    with dtype=torch.float64 computes in float64 (tests/test_pytorch_backend.py:169-181 checks dtype plumbing only)."""
+    import torch
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    g = np.load(os.path.join(GOLDEN_DIR, "c1_er1000_f64.npz"))
+    n, D, k, S = int(g["n"]), int(g["D"]), int(g["k"]), int(g["S"])
+    eng = _native.Engine(n, D, g["edges"], 1.0, 0.2, 0.5, k, S, dtype="float64")
+    eng.set_positions(g["p0"])
+    eng.run(3, g["sample_stream"][:3])
+    assert np.abs(eng.get_positions() - g["pos_next_2"]).max() <= 1e-9
+    eng.run(2)            # device sampler
+    assert np.isfinite(eng.get_positions()).all()
+    eng.close()
+    adj = gra.edges_to_adjacency(n, g["edges"])
+    emb = gra.create_graphem(adj, n_components=3, backend="hip", verbose=False, seed=0, dtype=torch.float64, sampler="torch")
+    assert emb.dtype == torch.float64 and emb._positions.dtype == torch.float64 and emb.positions.dtype == np.float64
+    emb.positions = g["pos_0"]
+    torch.manual_seed(7)
+    ids = torch.randperm(len(g["edges"]))[:S].numpy()
+    torch.manual_seed(7)
+    emb.update_positions()
+    eng = _native.Engine(n, D, g["edges"], 1.0, 0.2, 0.5, k, S, dtype="float64")
+    eng.set_positions(g["pos_0"])
+    eng.step(ids.astype(np.int32))
+    np.testing.assert_allclose(emb.positions, eng.get_positions(), rtol=0, atol=1e-12)   # (double atomics: the order of the handful of terms a vertex receives varies)
+    out = emb.run_layout(4)
+    assert out.dtype == np.float64 and np.isfinite(out).all()
+    np.testing.assert_allclose(out.std(0, ddof=1), 1.0, atol=1e-5)
+    with pytest.raises(ValueError):
+        eng.lib  # noqa: B018
+        _native.Engine(n, D, g["edges"], 1.0, 0.2, 0.5, k, S, dtype="float64", partition=(0, n // 2, 0, 0, 1))
+    eng.close()
