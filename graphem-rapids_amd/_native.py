@@ -27,7 +27,7 @@ SYMBOLS = [
     "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error", "gh_debug_stamps",
     "gh_knn_cdist_stats", "gh_rank_layout", "gh_step_finish_own", "gh_comm_available", "gh_selftest_arith",
     "gh_create_f64", "gh_set_positions_f64", "gh_get_positions_f64", "gh_positions_device_f64", "gh_spring_forces_f64",
-    "gh_intersection_forces_f64",
+    "gh_intersection_forces_f64", "gh_trlan_sweep",
 ]
 
 
@@ -141,6 +141,8 @@ def load():
     L.gh_positions_rows_allocated.restype = i64
     L.gh_spmv_symnorm.argtypes = [vp, i64, vp, vp, vp, vp, vp]
     L.gh_spmv_symnorm.restype = ctypes.c_int
+    L.gh_trlan_sweep.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.gh_trlan_sweep.restype = ctypes.c_int
     L.gh_spectral_last_error.argtypes = []
     L.gh_spectral_last_error.restype = ctypes.c_char_p
     L.gh_stats_rows.argtypes = [vp]

@@ -6,10 +6,10 @@ regular mode on the small end of the spectrum, which is what makes it the domina
 (37.6 s at n = 100 K) and impractical at a million vertices.
 
 Here: Lanczos with full reorthogonalisation on B = 2I - L, whose LARGEST eigenpairs are the wanted
-ones (theta = 2 - lambda).  The sparse operator is the hand-written HIP kernel behind
-gh_spmv_symnorm (csrc/spectral.hip); the dense Gram-Schmidt / Ritz steps are plain fp64 library
-GEMVs on device tensors; the small tridiagonal eigenproblem is solved on the host.  No restart is
-needed: the basis (steps x n fp64) fits HBM with room to spare (n = 1 M, 400 steps: 3.2 GB).
+ones (theta = 2 - lambda).  Thick-restart Lanczos in a basis of ~80 vectors; the steps between two
+restarts run inside the library (gh_trlan_sweep, csrc/spectral.hip): sparse operator and classical Gram-Schmidt twice as
+hand-written fp64 kernels, no host synchronisation; the small projected eigenproblem and the restart (one GEMM) are
+solved on the host / with torch at every restart.
 
 Like the reference's result, the embedding is defined up to the sign of each eigenvector and up to a
 rotation inside a degenerate eigenspace; tests compare eigenvalues and subspaces, not entries.
@@ -31,11 +31,13 @@ def symmetrised_csr(adjacency):
     csgraph.laplacian(normed=True) (pt.py:355) leaves self-loops out of the degree and overwrites the
     diagonal of L, so they must not reach the operator either."""
     a = sp.csr_matrix(adjacency + adjacency.transpose())
-    a.data = np.ones_like(a.data)
-    a.setdiag(0)
-    a.eliminate_zeros()
     a.sort_indices()
-    return a
+    rows = np.repeat(np.arange(a.shape[0], dtype=a.indices.dtype), np.diff(a.indptr))
+    keep = rows != a.indices                       # (setdiag(0) + eliminate_zeros costs 0.3 s at 100 K vertices)
+    counts = np.bincount(rows[keep], minlength=a.shape[0])
+    indptr = np.concatenate([[0], np.cumsum(counts)]).astype(a.indptr.dtype)
+    idx = a.indices[keep]
+    return sp.csr_matrix((np.ones(len(idx), dtype=np.float64), idx, indptr), shape=a.shape)
 
 
 def _lanczos(apply_b, n, want, dev, locked, tol, max_steps, check_every, gen, stop_below=None):
@@ -91,20 +93,30 @@ def _lanczos(apply_b, n, want, dev, locked, tol, max_steps, check_every, gen, st
     return theta, X, resid, steps, converged
 
 
-def _trlan(apply_b, n, want, dev, locked, tol, max_steps, check_every, gen, stop_below=None, basis=None):
+def _trlan(apply_b, n, want, dev, locked, tol, max_steps, check_every, gen, stop_below=None, basis=None, sweep=None):
     """Thick-restart Lanczos (Wu & Simon) with full reorthogonalisation inside a SMALL basis.
 
     Same contract as _lanczos.  The basis holds at most m vectors; when it is full the Rayleigh-Ritz
     problem of the projected matrix T = V^T B V (m x m, built column by column from the
     reorthogonalisation coefficients) is solved on the host, the `keep` best Ritz vectors plus the
     residual direction become the new basis, and the iteration continues.  Per step the dense work
-    is two (<= m) x n GEMVs instead of two (steps) x n ones, which is what made the unrestarted
-    version spend its time in Gram-Schmidt (n = 1 M: 12 s for 800 steps)."""
+    is two passes over a (<= m) x n basis instead of a (steps) x n one, which is what made the unrestarted
+    version spend its time in Gram-Schmidt (n = 1 M: 12 s for 800 steps).
+
+    sweep: the library's gh_trlan_sweep bound to the graph (laplacian_embedding_hip): all steps between two restarts in
+    ONE call -- matvec and classical Gram-Schmidt twice as hand-written kernels, seven launches per step, no host
+    synchronisation (before: ~ten torch launches and a device-to-host copy per step).  None: the same steps with torch
+    GEMVs (kept as the cross-check, method='trlan_torch')."""
     nl = 0 if locked is None else locked.shape[0]
     m = int(basis) if basis else max(4 * want + 40, 80)
     m = max(min(m, n - nl), 1)
+    if nl + m + 1 > 256:
+        sweep = None                          # (the kernels stage <= 256 coefficients)
     keep = min(want + max(8, want), max(m - 2, 1))
-    V = torch.empty((m + 1, n), dtype=torch.float64, device=dev)
+    Vall = torch.empty((nl + m + 1, n), dtype=torch.float64, device=dev)   # the locked vectors, then the basis
+    if nl:
+        Vall[:nl] = locked
+    V = Vall[nl:]
     v0 = torch.randn(n, dtype=torch.float64, generator=gen).to(dev)
     if nl:
         v0 -= locked.t() @ (locked @ v0)
@@ -112,11 +124,24 @@ def _trlan(apply_b, n, want, dev, locked, tol, max_steps, check_every, gen, stop
     V[0] = v0 / torch.linalg.vector_norm(v0)
     w = torch.empty(n, dtype=torch.float64, device=dev)
     Td = torch.zeros((m, m), dtype=torch.float64, device=dev)   # upper triangle of T, column by column
+    if sweep is not None:
+        work = torch.empty(n + 2 * (nl + m + 1) + ((n + 511) // 512) * (nl + m + 1), dtype=torch.float64, device=dev)
+        bh = torch.zeros((2, m), dtype=torch.float64, device=dev)   # beta, max |h| of every step
     k, steps, converged = 0, 0, False
     theta = S = resid = None
     while True:
         j, beta, exhausted = k, 0.0, False
-        while j < m:
+        if sweep is not None:
+            sweep(Vall, nl, m, k, Td, work, bh[0], bh[1])
+            host = bh.cpu().numpy()
+            j = m
+            for jj in range(k, m):
+                steps += 1
+                if not np.isfinite(host[0, jj]) or host[0, jj] < 1e-13 * max(1.0, host[1, jj]):   # invariant subspace at step jj
+                    exhausted, j = True, jj + 1
+                    break
+            beta = float(host[0, j - 1])
+        while sweep is None and j < m:
             apply_b(V[j], w)
             steps += 1
             if nl:
@@ -205,10 +230,23 @@ def laplacian_embedding_hip(adjacency, n_components, device="cuda:0", tol=1e-6, 
         if st != 0:
             raise RuntimeError(lib.gh_spectral_last_error().decode())
 
-    if method not in ("trlan", "lanczos"):
-        raise ValueError("method must be 'trlan' (thick restart, small basis) or 'lanczos' (no restart)")
-    solve = _trlan if method == "trlan" else _lanczos
-    if method == "trlan" and max_steps_given is None:
+    def sweep(Vall, nl, m, k, Td, work, beta, hmax):
+        st = lib.gh_trlan_sweep(ctypes.c_void_p(stream_ptr), n, ctypes.c_void_p(indptr.data_ptr()), ctypes.c_void_p(indices.data_ptr()),
+                                ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(Vall.data_ptr()), int(nl), int(m), int(k),
+                                ctypes.c_void_p(Td.data_ptr()), ctypes.c_void_p(work.data_ptr()), ctypes.c_void_p(beta.data_ptr()),
+                                ctypes.c_void_p(hmax.data_ptr()))
+        if st != 0:
+            raise RuntimeError(lib.gh_spectral_last_error().decode())
+
+    if method not in ("trlan", "trlan_torch", "lanczos"):
+        raise ValueError("method must be 'trlan' (thick restart, the library's sweep kernels), 'trlan_torch' (the same with "
+                         "torch GEMVs) or 'lanczos' (no restart)")
+    if method == "trlan":
+        def solve(*a, **kw):
+            return _trlan(*a, sweep=sweep, **kw)
+    else:
+        solve = _trlan if method == "trlan_torch" else _lanczos
+    if method in ("trlan", "trlan_torch") and max_steps_given is None:
         max_steps = int(min(max(10 * max_steps, 8000), 50 * n))   # matvecs are cheap here, the basis is what costs
     gen = torch.Generator(device="cpu").manual_seed(int(seed))
     theta, X, resid, steps, converged = solve(apply_b, n, want, dev, None, tol, max_steps, check_every, gen)

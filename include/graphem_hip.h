@@ -300,6 +300,14 @@ gh_status gh_radial_topk(gh_handle h, int32_t k, int32_t *ids);
  * gh_spectral_last_error() has the message of a failed call. */
 gh_status gh_spmv_symnorm(void *hip_stream, int64_t n, const int64_t *indptr, const int32_t *indices,
                           const double *inv_sqrt_deg, const double *x, double *y);
+/* Steps k .. m-1 of a Lanczos sweep on B (thick-restart form: the first k columns of the projected matrix are given):
+ * matvec, classical Gram-Schmidt twice against the nl locked vectors and the basis so far, coefficients into column j of
+ * Td, beta[j] = |w|, hmax[j] = max |coefficient|, next basis vector -- seven launches per step on hip_stream, no host
+ * synchronisation.  V (nl + m + 1, n), Td (m, m) row-major, work: n + 2 (nl + m + 1) + ceil(n / 512) (nl + m + 1)
+ * doubles, beta / hmax (m); all DEVICE pointers; nl + m + 1 <= 256. */
+gh_status gh_trlan_sweep(void *hip_stream, int64_t n, const int64_t *indptr, const int32_t *indices,
+                         const double *inv_sqrt_deg, double *V, int32_t nl, int32_t m, int32_t k, double *Td,
+                         double *work, double *beta, double *hmax);
 const char *gh_spectral_last_error(void);
 
 /* Self-test (no reference counterpart): the spring phase computes sqrt and its D divisions by one distance with leaner

@@ -135,3 +135,20 @@ def test_spans_the_references_own_eigsh_start_at_100k():
     sv = np.linalg.svd(Qa.T @ Qb, compute_uv=False)
     print(f"\nlaplacian_hip at n = 100 K: {took:.2f} s, {info.get('matvecs')} matvecs; smallest singular value of Qa^T Qb = {sv.min():.8f}")
     assert sv.min() >= 1.0 - 1e-5, sv
+
+
+@pytest.mark.gpu
+def test_sweep_kernels_equal_the_torch_steps():
+    """gh_trlan_sweep (csrc/spectral.hip: matvec + classical Gram-Schmidt twice as kernels) against the same solver with
+    torch GEMVs: same eigenvalues and subspace on a graph with isolated vertices and a degenerate spectrum."""
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd.spectral import laplacian_embedding_hip
+    n = 30000
+    edges = gra.erdos_renyi_edges(n, 4.0 / n, seed=5)     # mean degree 4: isolated vertices, small components
+    adj = gra.edges_to_adjacency(n, edges)
+    out = {}
+    for method in ("trlan", "trlan_torch"):
+        emb, info = laplacian_embedding_hip(adj, 4, return_info=True, tol=1e-9, method=method)
+        assert info["converged"]
+        out[method] = (np.sort(np.asarray(info["eigenvalues"])[:5]), emb.astype(np.float64))
+    np.testing.assert_allclose(out["trlan"][0], out["trlan_torch"][0], atol=1e-8)
