@@ -118,9 +118,9 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
                                                                int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
                                                                int32_t *__restrict__ rare) {
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t best2[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
     __shared__ float qs[16];
-    constexpr int NPT = GH_CAND_CAP / 256;
     const int Ks = K + 1;
     const int64_t qi = blockIdx.x;
     const int c = cnt[qi * GH_CNT_STRIDE];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
             list[i] = gh_key(cdist_pair<LDT>(a, qs, qn, id), id);
         }
         __syncthreads();
-        block_extract_adaptive<NPT>(list, c, Ks, best, red);
+        block_extract_list(list, c, Ks, best, best2, red);
         int bad = 0;
         for (int i = threadIdx.x; i + 1 < Ks; i += 256) bad |= (uint32_t)(best[i] >> 32) == (uint32_t)(best[i + 1] >> 32) ? 1 : 0;
         if (threadIdx.x == 0) {

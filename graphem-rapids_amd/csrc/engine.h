@@ -8,7 +8,7 @@
 #include "../../include/graphem_hip.h"
 
 // Candidate-list capacity per query in the filtered KNN scan, and the LDS sort size.
-#define GH_CAND_CAP 8192
+#define GH_CAND_CAP 16384   /* (8192 until round 3: one query of a 16 M-vertex run reached 8777 candidates and its exhaustive fallback cost 0.5 s) */
 #define GH_SEL_BUF 4096
 #define GH_SEL_CHUNK 2048
 // Candidate counters are padded to one per 128-byte line: adjacent counters serialise their

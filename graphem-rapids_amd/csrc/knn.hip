@@ -236,6 +236,29 @@ __device__ __forceinline__ void block_extract_adaptive(const uint64_t *src, int 
     else run(std::integral_constant<int, MAXNPT>{});
 }
 
+// K smallest of a candidate list of up to 2 * GH_LIST_HALF keys in memory: the register extraction takes GH_LIST_HALF keys
+// (32 per thread); a longer list is taken in two halves -- ONE call site in a loop, so the common path's code does not
+// grow -- and the two results are merged by rank counting.  (Raising the per-thread key count instead made the select
+// kernel use scratch: +2.7 us per launch at 1 M vertices.)  best, best2: K keys of LDS each; red: 4 * GH_EXTRACT_MAX_K.
+#define GH_LIST_HALF 8192
+template <int NT = 256>
+__device__ __forceinline__ void block_extract_list(const uint64_t *list, int c, int K, uint64_t *best, uint64_t *best2, uint64_t *red) {
+    const int nh = c > GH_LIST_HALF ? 2 : 1;
+    for (int hh = 0; hh < nh; ++hh)
+        block_extract_adaptive<GH_LIST_HALF / NT, NT>(list + hh * GH_LIST_HALF, min(GH_LIST_HALF, c - hh * GH_LIST_HALF), K, hh == 0 ? best : best2, red);
+    if (nh == 2) {
+        for (int i = threadIdx.x; i < 2 * K; i += NT) red[i] = i < K ? best[i] : best2[i - K];
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * K; i += NT) {
+            const uint64_t key = red[i];
+            int rank = 0;
+            for (int j = 0; j < 2 * K; ++j) rank += (red[j] < key || (red[j] == key && j < i)) ? 1 : 0;   // equal keys: GH_KEY_INF fillers only
+            if (rank < K) best[rank] = key;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // One workgroup per query: exact K smallest (dist2, id) keys over the reference edges
 // e_lo + j*stride, j < M.  Any D (runtime).  Chunks of 2048 references: every thread
@@ -461,8 +484,9 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats (exact search only)
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t best2[GH_EXTRACT_MAX_K];
     __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
-    constexpr int NPT = GH_CAND_CAP / 256;
+    static_assert(GH_CAND_CAP <= 2 * GH_LIST_HALF, "block_extract_list takes two halves");
     const int64_t qi = blockIdx.x;
     if (qi >= S) {
         // Workgroups past the queries (single-rank fused steps): column qi - S of the fused kernel's per-workgroup
@@ -500,7 +524,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
         for (int j = 0; j < 4; ++j) pre[j] = j * 256 + (int)threadIdx.x < c ? pre[j] : GH_KEY_INF;
         block_extract_smallest<4>(pre, K, best, red);
     } else {
-        block_extract_adaptive<NPT>(cand + qi * GH_CAND_CAP, c, K, best, red);
+        block_extract_list(cand + qi * GH_CAND_CAP, c, K, best, best2, red);
     }
     if (final_level) {
         for (int i = threadIdx.x; i < K; i += blockDim.x) out_keys[qi * K + i] = best[i];

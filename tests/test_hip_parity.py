@@ -784,3 +784,26 @@ def test_random_partitioned_configurations(seed):
     assert np.abs(outs[0] - ref).max() <= 5e-6, (world, n, len(edges), D, k, S)
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+
+
+def test_candidate_lists_between_one_and_two_extraction_halves():
+    """A candidate list longer than the 8192 keys the register extraction takes (but within the list's 16384) is selected
+    in two halves and merged: a dense cluster of midpoints around the queries makes such lists; ids must stay the oracle's."""
+    from graphem_rapids_amd import _native
+    import graphem_rapids_amd as gra
+    n, D, k, S = 60000, 3, 10, 64
+    edges = np.ascontiguousarray(gra.random_regular_edges(n, 8, seed=9), dtype=np.int32)
+    rng = np.random.default_rng(4)
+    pos = rng.standard_normal((n, D)).astype(np.float32)
+    dense = rng.permutation(n)[:13400]                      # 22 % of the vertices in ONE point: ~12 K coincident midpoints
+    pos[dense] = np.float32(3.0)
+    inside = np.nonzero(np.isin(edges[:, 0], dense) & np.isin(edges[:, 1], dense))[0]
+    sampled = np.concatenate([inside[:32], rng.permutation(len(edges))[:S - 32]]).astype(np.int32)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S)
+    eng.set_positions(pos)
+    knn = eng.knn_midpoints(sampled)
+    _, fin, ovf = eng.knn_last_counts()
+    assert np.array_equal(knn, oracle.knn_midpoints(pos, edges, sampled, k))
+    print("\nlongest candidate lists:", np.sort(fin)[-5:], "overflowed:", int(ovf.sum()))
+    assert fin.max() > 8192 and fin.max() <= 16384 and ovf.sum() == 0     # the two-halves path was taken, nothing fell back
+    eng.close()
