@@ -36,6 +36,8 @@ def lib():
         L.go_midpoints.restype = None
         L.go_knn_midpoints.argtypes = [_f32p, i32, _i32p, i64, _i32p, i64, i32, _i32p, ctypes.c_void_p]
         L.go_knn_midpoints.restype = i32
+        L.go_knn_midpoints_tiled.argtypes = [_f32p, i32, _i32p, i64, _i32p, i64, i32, _i32p]
+        L.go_knn_midpoints_tiled.restype = i32
         L.go_knn_midpoints_cdist_mm.argtypes = [_f32p, i32, _i32p, i64, _i32p, i64, i32, _i32p]
         L.go_knn_midpoints_cdist_mm.restype = i32
         L.go_knn_midpoints_aten.argtypes = [_f32p, i32, _i32p, i64, _i32p, i64, i32, _i32p, ctypes.c_void_p]
@@ -86,12 +88,16 @@ def midpoints(pos, edges):
     return mid
 
 
-def knn_midpoints(pos, edges, sampled, k, return_dist=False, cdist_mm=False):
-    """(S, k) int32 neighbour edge ids; RuntimeError when k+1 > E like torch.topk (pt.py:583)."""
+def knn_midpoints(pos, edges, sampled, k, return_dist=False, cdist_mm=False, tiled=False):
+    """(S, k) int32 neighbour edge ids; RuntimeError when k+1 > E like torch.topk (pt.py:583).
+    tiled=True: the blocked all-cores search of bench.py's baseline (go_knn_midpoints_tiled), same result."""
     pos, edges, sampled = _c(pos, np.float32), _c(edges, np.int32), _c(sampled, np.int32)
     S = sampled.shape[0]
     knn = np.empty((S, k), dtype=np.int32)
-    if cdist_mm:
+    if tiled:
+        err = lib().go_knn_midpoints_tiled(pos, pos.shape[1], edges, edges.shape[0], sampled, S, k, knn)
+        dist = None
+    elif cdist_mm:
         err = lib().go_knn_midpoints_cdist_mm(pos, pos.shape[1], edges, edges.shape[0], sampled, S, k, knn)
         dist = None
     else:

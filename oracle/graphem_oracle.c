@@ -445,6 +445,104 @@ void go_spring_forces_pull(const float *pos, int64_t n, int D, const int64_t *ro
     }
 }
 
+/* The same exact search with the loops the other way round (bench.py's all-cores baseline; the per-query scan above
+ * streams all E midpoints once per query, S * E * D * 4 bytes per iteration).  Here a thread takes a block of
+ * GO_KNN_BLOCK consecutive edges, computes its midpoints once, coordinate-major (they stay in its L1) and runs ALL S
+ * queries over the block, keeping per query its own K best (d2, id) pairs; the threads' lists are merged at the end.
+ * Blocks are contiguous id ranges and a thread's blocks ascend, so "ties keep the smaller id" holds inside a list; the
+ * merge orders by (d2, id).  Same result as go_knn_midpoints (tests/test_oracle_golden.py). */
+#define GO_KNN_BLOCK 2048   /* a multiple of 16 */
+int go_knn_midpoints_tiled(const float *pos, int D, const int32_t *edges, int64_t E, const int32_t *sampled, int64_t S, int k,
+                           int32_t *knn_out) {
+    const int K = k + 1;
+    if ((int64_t)K > E) return GO_ERR_K_TOO_LARGE;
+    float *q = (float *)malloc(sizeof(float) * (size_t)S * D);
+    if (!q) return GO_ERR_NOMEM;
+    for (int64_t r = 0; r < S; ++r)
+        for (int d = 0; d < D; ++d)
+            q[(size_t)r * D + d] = (pos[(size_t)edges[2 * (size_t)sampled[r]] * D + d] + pos[(size_t)edges[2 * (size_t)sampled[r] + 1] * D + d]) / 2.0f;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    float *bd_all = (float *)malloc(sizeof(float) * (size_t)nthreads * S * K);
+    int32_t *bi_all = (int32_t *)malloc(sizeof(int32_t) * (size_t)nthreads * S * K);
+    int *cnt_all = (int *)calloc((size_t)nthreads * S, sizeof(int));
+    if (!bd_all || !bi_all || !cnt_all) { free(q); free(bd_all); free(bi_all); free(cnt_all); return GO_ERR_NOMEM; }
+    const int64_t nblocks = (E + GO_KNN_BLOCK - 1) / GO_KNN_BLOCK;
+#pragma omp parallel num_threads(nthreads)
+    {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        float *bd = bd_all + (size_t)tid * S * K;
+        int32_t *bi = bi_all + (size_t)tid * S * K;
+        int *cnt = cnt_all + (size_t)tid * S;
+        float *mid = (float *)malloc(sizeof(float) * (size_t)GO_KNN_BLOCK * D);
+        float *d2 = (float *)malloc(sizeof(float) * GO_KNN_BLOCK);
+#pragma omp for schedule(static)   /* contiguous, ascending block ranges per thread */
+        for (int64_t b = 0; b < nblocks; ++b) {
+            const int64_t e0 = b * GO_KNN_BLOCK, m = (E - e0 < GO_KNN_BLOCK) ? E - e0 : GO_KNN_BLOCK, mpad = (m + 15) & ~(int64_t)15;
+            for (int64_t j = 0; j < m; ++j)   /* coordinate-major inside the block: the distance loop below is unit-stride */
+                for (int d = 0; d < D; ++d)
+                    mid[(size_t)d * GO_KNN_BLOCK + j] = (pos[(size_t)edges[2 * (e0 + j)] * D + d] + pos[(size_t)edges[2 * (e0 + j) + 1] * D + d]) / 2.0f;
+            for (int64_t j = m; j < mpad; ++j) d2[j] = INFINITY;
+            for (int64_t r = 0; r < S; ++r) {
+                const float *qq = q + (size_t)r * D;
+                for (int64_t j = 0; j < m; ++j) d2[j] = 0.0f;
+                for (int d = 0; d < D; ++d) {   /* go_d2's fma chain per j, coordinates in order */
+                    const float qd = qq[d];
+                    const float *md = mid + (size_t)d * GO_KNN_BLOCK;
+                    for (int64_t j = 0; j < m; ++j) { const float t = qd - md[j]; d2[j] = fmaf(t, t, d2[j]); }
+                }
+                float *rd = bd + (size_t)r * K;
+                int32_t *ri = bi + (size_t)r * K;
+                int c = cnt[r];
+                float worst = c == K ? rd[K - 1] : INFINITY;
+                for (int64_t j0 = 0; j0 < mpad; j0 += 16) {
+                    int any = 0;
+                    for (int jj = 0; jj < 16; ++jj) any |= d2[j0 + jj] < worst;
+                    if (!any) continue;
+                    for (int64_t j = j0; j < j0 + 16; ++j) {
+                        if (!(d2[j] < worst)) continue;   /* ties keep the smaller id (earlier edge) */
+                        int t = c < K ? c : K - 1;
+                        while (t > 0 && rd[t - 1] > d2[j]) { rd[t] = rd[t - 1]; ri[t] = ri[t - 1]; --t; }
+                        rd[t] = d2[j]; ri[t] = (int32_t)(e0 + j);
+                        if (c < K) ++c;
+                        worst = c == K ? rd[K - 1] : INFINITY;
+                    }
+                }
+                cnt[r] = c;
+            }
+        }
+        free(mid); free(d2);
+    }
+    /* merge: per query the K smallest (d2, id) over the threads' lists */
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < S; ++r) {
+        int head[1024];
+        int *hp = nthreads <= 1024 ? head : (int *)malloc(sizeof(int) * (size_t)nthreads);
+        for (int t = 0; t < nthreads; ++t) hp[t] = 0;
+        for (int c = 0; c < K; ++c) {
+            int best = -1;
+            for (int t = 0; t < nthreads; ++t) {
+                if (hp[t] >= cnt_all[(size_t)t * S + r]) continue;
+                if (best < 0) { best = t; continue; }
+                const float dv = bd_all[((size_t)t * S + r) * K + hp[t]], db = bd_all[((size_t)best * S + r) * K + hp[best]];
+                const int32_t iv = bi_all[((size_t)t * S + r) * K + hp[t]], ib = bi_all[((size_t)best * S + r) * K + hp[best]];
+                if (dv < db || (dv == db && iv < ib)) best = t;
+            }
+            const int32_t id = bi_all[((size_t)best * S + r) * K + hp[best]];
+            hp[best]++;
+            if (c >= 1) knn_out[(size_t)r * k + (c - 1)] = id;   /* column 0 dropped (pt.py:421) */
+        }
+        if (hp != head) free(hp);
+    }
+    free(q); free(bd_all); free(bi_all); free(cnt_all);
+    return GO_OK;
+}
+
 int go_step_omp(float *pos, int64_t n, int D, const int32_t *edges, int64_t E, const int64_t *rowptr,
                 const int32_t *adj, const int8_t *sign, const int32_t *sampled, int64_t S, int k, float L_min,
                 float k_attr, float k_inter) {
@@ -453,7 +551,7 @@ int go_step_omp(float *pos, int64_t n, int D, const int32_t *edges, int64_t E, c
     int32_t *knn = (int32_t *)malloc(sizeof(int32_t) * (size_t)(S * k > 0 ? S * k : 1));
     if (!Fs || !Fi || !knn) { free(Fs); free(Fi); free(knn); return GO_ERR_NOMEM; }
     go_spring_forces_pull(pos, n, D, rowptr, adj, sign, L_min, k_attr, Fs);
-    int err = go_knn_midpoints(pos, D, edges, E, sampled, S, k, knn, NULL);
+    int err = go_knn_midpoints_tiled(pos, D, edges, E, sampled, S, k, knn);
     if (err == GO_OK) {
         go_intersection_forces(pos, n, D, edges, sampled, S, knn, k, k_inter, Fi, NULL);   /* O(S k): serial */
         double *sum = (double *)calloc((size_t)D, sizeof(double)), *sq = (double *)calloc((size_t)D, sizeof(double));

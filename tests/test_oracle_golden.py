@@ -129,6 +129,8 @@ def test_bench_baselines_equal_the_oracle(golden):
         assert np.array_equal(st.spring_forces(pos, Lm, ka), g[f"F_spring_{t}"])
         out = st.step(pos, sampled, k, Lm, ka, ki)
         assert np.abs(out - g[f"pos_next_{t}"]).max() <= 2e-6
+        assert np.array_equal(oracle.knn_midpoints(pos, edges, sampled, k, tiled=True),
+                              oracle.knn_midpoints(pos, edges, sampled, k))
         tp = torch_cpu.step(torch.from_numpy(np.ascontiguousarray(pos)), te, torch.from_numpy(sampled.astype(np.int64)),
                             k, Lm, ka, ki).numpy()
         assert np.abs(tp - g[f"pos_next_{t}"]).max() <= 2e-6
@@ -136,3 +138,20 @@ def test_bench_baselines_equal_the_oracle(golden):
                                       torch.from_numpy(np.ascontiguousarray(pos))[te[:, 1]]) / 2.0,
                                      torch.from_numpy(sampled.astype(np.int64)), k).numpy()
         assert np.array_equal(tk, g[f"knn_{t}"])
+
+
+def test_tiled_knn_of_the_baseline_equals_the_plain_search_with_ties():
+    """The blocked search bench.py's all-cores baseline runs (go_knn_midpoints_tiled) returns the rows of the per-query
+    search, including on a lattice where most distances tie (ties by smaller id across blocks and threads)."""
+    rng = np.random.default_rng(5)
+    n = 3000
+    pos = rng.integers(0, 3, size=(n, 2)).astype(np.float32)     # midpoints on a 5 x 5 lattice: ties everywhere
+    edges = rng.integers(0, n, size=(9000, 2)).astype(np.int32)
+    edges = edges[edges[:, 0] != edges[:, 1]]
+    sampled = rng.choice(len(edges), 200, replace=False).astype(np.int32)
+    for k in (1, 7, 40):
+        assert np.array_equal(oracle.knn_midpoints(pos, edges, sampled, k, tiled=True),
+                              oracle.knn_midpoints(pos, edges, sampled, k))
+    pos = rng.standard_normal((n, 5)).astype(np.float32)
+    assert np.array_equal(oracle.knn_midpoints(pos, edges, sampled, 15, tiled=True),
+                          oracle.knn_midpoints(pos, edges, sampled, 15))
