@@ -20,6 +20,7 @@
  * Layout: positions (n, D) row-major f32; edges (E, 2) row-major int32 with
  * u < v in CSR row order (pt.py:220-245); sampled (S,) int32; knn (S, k) int32.
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -480,43 +481,51 @@ int go_knn_midpoints_tiled(const float *pos, int D, const int32_t *edges, int64_
         int32_t *bi = bi_all + (size_t)tid * S * K;
         int *cnt = cnt_all + (size_t)tid * S;
         float *mid = (float *)malloc(sizeof(float) * (size_t)GO_KNN_BLOCK * D);
-        float *d2 = (float *)malloc(sizeof(float) * GO_KNN_BLOCK);
+        float d2[16];
 #pragma omp for schedule(static)   /* contiguous, ascending block ranges per thread */
         for (int64_t b = 0; b < nblocks; ++b) {
             const int64_t e0 = b * GO_KNN_BLOCK, m = (E - e0 < GO_KNN_BLOCK) ? E - e0 : GO_KNN_BLOCK, mpad = (m + 15) & ~(int64_t)15;
             for (int64_t j = 0; j < m; ++j)   /* coordinate-major inside the block: the distance loop below is unit-stride */
                 for (int d = 0; d < D; ++d)
                     mid[(size_t)d * GO_KNN_BLOCK + j] = (pos[(size_t)edges[2 * (e0 + j)] * D + d] + pos[(size_t)edges[2 * (e0 + j) + 1] * D + d]) / 2.0f;
-            for (int64_t j = m; j < mpad; ++j) d2[j] = INFINITY;
+            for (int64_t j = m; j < mpad; ++j)   /* padding lanes: far away in coordinate 0, never selected (d2 = inf) */
+                for (int d = 0; d < D; ++d) mid[(size_t)d * GO_KNN_BLOCK + j] = d == 0 ? INFINITY : 0.0f;
             for (int64_t r = 0; r < S; ++r) {
                 const float *qq = q + (size_t)r * D;
-                for (int64_t j = 0; j < m; ++j) d2[j] = 0.0f;
-                for (int d = 0; d < D; ++d) {   /* go_d2's fma chain per j, coordinates in order */
-                    const float qd = qq[d];
-                    const float *md = mid + (size_t)d * GO_KNN_BLOCK;
-                    for (int64_t j = 0; j < m; ++j) { const float t = qd - md[j]; d2[j] = fmaf(t, t, d2[j]); }
-                }
                 float *rd = bd + (size_t)r * K;
                 int32_t *ri = bi + (size_t)r * K;
                 int c = cnt[r];
                 float worst = c == K ? rd[K - 1] : INFINITY;
+                __m256 vworst = _mm256_set1_ps(worst);
                 for (int64_t j0 = 0; j0 < mpad; j0 += 16) {
-                    int any = 0;
-                    for (int jj = 0; jj < 16; ++jj) any |= d2[j0 + jj] < worst;
-                    if (!any) continue;
-                    for (int64_t j = j0; j < j0 + 16; ++j) {
-                        if (!(d2[j] < worst)) continue;   /* ties keep the smaller id (earlier edge) */
+                    /* go_d2's chain per lane: t = q_d - m_d (rounded), acc = fma(t, t, acc), coordinates in order */
+                    __m256 a0 = _mm256_setzero_ps(), a1 = _mm256_setzero_ps();
+                    for (int d = 0; d < D; ++d) {
+                        const __m256 qd = _mm256_broadcast_ss(qq + d);
+                        const float *md = mid + (size_t)d * GO_KNN_BLOCK + j0;
+                        const __m256 t0 = _mm256_sub_ps(qd, _mm256_loadu_ps(md)), t1 = _mm256_sub_ps(qd, _mm256_loadu_ps(md + 8));
+                        a0 = _mm256_fmadd_ps(t0, t0, a0);
+                        a1 = _mm256_fmadd_ps(t1, t1, a1);
+                    }
+                    const int hit = _mm256_movemask_ps(_mm256_or_ps(_mm256_cmp_ps(a0, vworst, _CMP_LT_OQ), _mm256_cmp_ps(a1, vworst, _CMP_LT_OQ)));
+                    if (!hit) continue;
+                    _mm256_storeu_ps(d2, a0);
+                    _mm256_storeu_ps(d2 + 8, a1);
+                    for (int jj = 0; jj < 16; ++jj) {
+                        const float v = d2[jj];
+                        if (!(v < worst)) continue;   /* ties keep the smaller id (earlier edge) */
                         int t = c < K ? c : K - 1;
-                        while (t > 0 && rd[t - 1] > d2[j]) { rd[t] = rd[t - 1]; ri[t] = ri[t - 1]; --t; }
-                        rd[t] = d2[j]; ri[t] = (int32_t)(e0 + j);
+                        while (t > 0 && rd[t - 1] > v) { rd[t] = rd[t - 1]; ri[t] = ri[t - 1]; --t; }
+                        rd[t] = v; ri[t] = (int32_t)(e0 + j0 + jj);
                         if (c < K) ++c;
                         worst = c == K ? rd[K - 1] : INFINITY;
                     }
+                    vworst = _mm256_set1_ps(worst);
                 }
                 cnt[r] = c;
             }
         }
-        free(mid); free(d2);
+        free(mid);
     }
     /* merge: per query the K smallest (d2, id) over the threads' lists */
 #pragma omp parallel for schedule(static)
