@@ -182,7 +182,10 @@ def main():
     ap.add_argument("--sampler", default="device", choices=["device", "host"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sample-size", type=int, default=None, help="override the workload's number of sampled midpoints")
-    ap.add_argument("--knn", default="auto", choices=["auto", "scan", "grid"], help="KNN search (gh_params.knn_method)")
+    ap.add_argument("--knn", default="auto", choices=["auto", "scan", "grid", "ivf"],
+                    help="KNN search (gh_params.knn_method); ivf is approximate (recall: tools/ivf_probe.py)")
+    ap.add_argument("--ivf-lists", type=int, default=0)
+    ap.add_argument("--ivf-probes", type=int, default=0)
     ap.add_argument("--knn-distance", default="exact", choices=["exact", "cdist"],
                     help="exact = speed mode; cdist = the reference's cdist + topk rows (parity mode, gh_params.knn_distance)")
     ap.add_argument("--dim", type=int, default=None, help="override the workload's number of components (experiments)")
@@ -234,7 +237,7 @@ def main():
         eng = lay.engine.eng
     else:
         eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, device_id=local_rank, knn_method=args.knn,
-                             knn_distance=args.knn_distance)
+                             knn_distance=args.knn_distance, ivf_lists=args.ivf_lists, ivf_probes=args.ivf_probes)
         eng.set_positions(pos)
         stream = None
         if args.sampler == "host":  # ids drawn on the host before the timed region (parity-style stream)

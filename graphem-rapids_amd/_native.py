@@ -27,18 +27,19 @@ SYMBOLS = [
     "gh_comm_init_loopback", "gh_comm_destroy", "gh_run_partitioned", "gh_comm_last_error", "gh_debug_stamps",
     "gh_knn_cdist_stats", "gh_rank_layout", "gh_step_finish_own", "gh_comm_available", "gh_selftest_arith",
     "gh_create_f64", "gh_set_positions_f64", "gh_get_positions_f64", "gh_positions_device_f64", "gh_spring_forces_f64",
-    "gh_intersection_forces_f64", "gh_trlan_sweep",
+    "gh_intersection_forces_f64", "gh_trlan_sweep", "gh_knn_ivf_config", "gh_knn_ivf_list_sizes",
 ]
 
 
 class GhParams(ctypes.Structure):
     _fields_ = [("L_min", ctypes.c_float), ("k_attr", ctypes.c_float), ("k_inter", ctypes.c_float),
                 ("n_neighbors", ctypes.c_int32), ("sample_size", ctypes.c_int32), ("seed", ctypes.c_uint64),
-                ("reorder", ctypes.c_int32), ("knn_method", ctypes.c_int32), ("knn_distance", ctypes.c_int32)]
+                ("reorder", ctypes.c_int32), ("knn_method", ctypes.c_int32), ("knn_distance", ctypes.c_int32),
+                ("ivf_lists", ctypes.c_int32), ("ivf_probes", ctypes.c_int32)]
 
 
 REORDER = {"auto": 0, "off": 1, "bfs": 2}  # gh_params.reorder (include/graphem_hip.h GH_REORDER_*)
-KNN_METHOD = {"auto": 0, "scan": 1, "grid": 2}  # gh_params.knn_method (GH_KNN_*)
+KNN_METHOD = {"auto": 0, "scan": 1, "grid": 2, "ivf": 3}  # gh_params.knn_method (GH_KNN_*)
 KNN_DISTANCE = {"exact": 0, "cdist": 1}  # gh_params.knn_distance (GH_DIST_*)
 
 
@@ -153,6 +154,10 @@ def load():
     L.gh_knn_last_counts.restype = ctypes.c_int
     L.gh_knn_cdist_stats.argtypes = [vp, vp, vp]
     L.gh_knn_cdist_stats.restype = ctypes.c_int
+    L.gh_knn_ivf_config.argtypes = [vp, vp, vp]
+    L.gh_knn_ivf_config.restype = ctypes.c_int
+    L.gh_knn_ivf_list_sizes.argtypes = [vp, vp, ctypes.c_int32]
+    L.gh_knn_ivf_list_sizes.restype = ctypes.c_int
     L.gh_comm_unique_id.argtypes = [vp]
     L.gh_comm_unique_id.restype = ctypes.c_int
     L.gh_comm_init_rccl.argtypes = [vp, i32, i32, vp]
@@ -200,7 +205,8 @@ class Engine:
     """Thin RAII wrapper over a gh_handle."""
 
     def __init__(self, n, D, edges, L_min, k_attr, k_inter, n_neighbors, sample_size, seed=0, device_id=0,
-                 partition=None, reorder="auto", knn_method="auto", knn_distance="exact", dtype="float32"):
+                 partition=None, reorder="auto", knn_method="auto", knn_distance="exact", dtype="float32", ivf_lists=0,
+                 ivf_probes=0):
         """dtype='float64': the engine of csrc/f64.hip -- every phase in double; positions, spring and intersection forces
         cross the boundary as float64 arrays (whole graph only; reorder / knn_method / knn_distance do not apply)."""
         self.lib = load()
@@ -215,7 +221,8 @@ class Engine:
         edges = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
         self.E = edges.shape[0]
         prm = GhParams(float(L_min), float(k_attr), float(k_inter), int(n_neighbors), int(sample_size),
-                       int(seed) & 0xFFFFFFFFFFFFFFFF, REORDER[reorder], KNN_METHOD[knn_method], KNN_DISTANCE[knn_distance])
+                       int(seed) & 0xFFFFFFFFFFFFFFFF, REORDER[reorder], KNN_METHOD[knn_method], KNN_DISTANCE[knn_distance],
+                       int(ivf_lists), int(ivf_probes))
         part = None
         if partition is not None:
             vals = [int(x) for x in partition]  # (row_lo, row_hi, edge_lo, edge_hi[, edge_rule])
@@ -408,6 +415,18 @@ class Engine:
         a, b = ctypes.c_int32(0), ctypes.c_int32(0)
         self._chk(self.lib.gh_knn_cdist_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def knn_ivf_config(self):
+        """(lists, probes per query) of a knn_method='ivf' engine; (0, 0) otherwise."""
+        a, b = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._chk(self.lib.gh_knn_ivf_config(self.handle, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def knn_ivf_list_sizes(self):
+        """(lists,) int32 members of every inverted list after the last search."""
+        out = np.zeros(self.knn_ivf_config()[0], dtype=np.int32)
+        self._chk(self.lib.gh_knn_ivf_list_sizes(self.handle, ptr(out), len(out)))
+        return out
 
     # instrumentation
     def timing_enable(self, on=True):

@@ -83,6 +83,7 @@ static gh_status reject_f64(gh_engine *h, const char *what) {
 
 static void free_all(gh_engine *h) {
     gh_f64_free(h);
+    gh_ivf_free(h);
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
                     h->d_ovf, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rare, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
@@ -123,13 +124,14 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     h->prm = *params;
     h->k = params->n_neighbors; h->K = h->k + 1;
     h->S = std::min<int64_t>(params->sample_size, E);
-    if (h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID)   // AUTO (and anything unknown)
+    if (h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID && h->prm.knn_method != GH_KNN_IVF)   // AUTO (and anything unknown)
         h->prm.knn_method = (D <= 3 && h->S >= 12288) ? GH_KNN_GRID : GH_KNN_SCAN;
-    if (const char *e = getenv("GRAPHEM_HIP_KNN")) h->prm.knn_method = atoi(e) == GH_KNN_GRID ? GH_KNN_GRID : GH_KNN_SCAN;  // A/B runs
+    if (const char *e = getenv("GRAPHEM_HIP_KNN")) h->prm.knn_method = atoi(e) == GH_KNN_GRID ? GH_KNN_GRID : atoi(e) == GH_KNN_IVF ? GH_KNN_IVF : GH_KNN_SCAN;  // A/B runs
     if (params->knn_distance != GH_DIST_EXACT && params->knn_distance != GH_DIST_CDIST) { delete h; return fail(GH_ERR_INVALID, "unknown knn_distance"); }
     h->cdist = params->knn_distance == GH_DIST_CDIST;
     if (h->cdist && part) { delete h; return fail(GH_ERR_INVALID, "knn_distance = GH_DIST_CDIST needs the whole graph on one engine (no gh_partition)"); }
     if (h->cdist) h->prm.knn_method = GH_KNN_SCAN;   // the grid search knows exact distances only
+    if (h->prm.knn_method == GH_KNN_IVF && part) { delete h; return fail(GH_ERR_INVALID, "knn_method = GH_KNN_IVF needs the whole graph on one engine (no gh_partition)"); }
     h->Ksel = h->K + (h->cdist ? 1 : 0);
     if (part) h->part = *part;
     else h->part = gh_partition{0, n, 0, E, GH_EDGES_RANGE};
@@ -441,6 +443,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         return bail(GH_ERR_HIP);
     }
     if ((st = gh_grid_alloc(h)) != GH_OK) return bail(st);
+    if ((st = gh_ivf_alloc(h)) != GH_OK) return bail(st);
     if ((st = gh_cdist_alloc(h)) != GH_OK) return bail(st);
     GH_A2(d_tau_flag, 1);
     GH_A2(d_iter, 1);
@@ -620,6 +623,12 @@ static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
         GH_TRY(gh_grid_search(h));
         return gh_knn_finish(h, true, fuse_intersect);
     }
+    if (gh_ivf_path(h)) {   // inverted-file search (approximate: probed lists only; ivf.hip)
+        GH_TRY(gh_knn_prepare(h));          // query records only
+        GH_TRY(gh_launch_spring_mid(h));
+        GH_TRY(gh_ivf_search(h));
+        return gh_knn_finish(h, true, fuse_intersect);
+    }
     if (h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused) {
         GH_TRY(gh_knn_prepare(h));
         if (!h->tau_embedded) GH_TRY(gh_knn_thresholds(h));   // else: the first workgroups of the fused launch (tau_core.h)
@@ -642,7 +651,7 @@ static gh_status step_merge(gh_engine *h, const uint64_t *gathered, int world) {
 // gh_knn_prepare falls back to its own kernel when the next step turns out different.
 static gh_status step_finish(gh_engine *h, int next_mode = -1, int32_t *next_ids = nullptr) {
     const bool presetup = next_mode >= 0 && h->rows == h->n && !h->d_gbuf && gh_knn_scan_path(h) &&
-                          ((h->fused_scan && !h->force_unfused) || gh_grid_path(h)) && h->S > 0 && h->k > 0 &&
+                          ((h->fused_scan && !h->force_unfused) || gh_grid_path(h) || gh_ivf_path(h)) && h->S > 0 && h->k > 0 &&
                           !getenv("GRAPHEM_HIP_NO_PRESETUP");
     GH_TRY(gh_launch_normalise(h, true, presetup, next_mode, next_ids));  // also zeroes what the intersection phase touched
     h->iter += 1;
@@ -698,7 +707,7 @@ static gh_status run_one_device_sampled(gh_engine *h) {
 // carry over to kernels with 200-byte argument blocks), so the enqueued loop stays the default.
 static bool graph_replay_applies(gh_engine *h) {
     return whole_graph(h) && !h->d_gbuf && !h->g_world && !h->cdist && !h->timing && !h->d_stamps && h->fused_scan && !h->force_unfused &&
-           gh_knn_scan_path(h) && !gh_grid_path(h) && h->S > 0 && h->k > 0 && h->K <= 128 && h->LD <= 16 &&
+           gh_knn_scan_path(h) && !gh_grid_path(h) && !gh_ivf_path(h) && h->S > 0 && h->k > 0 && h->K <= 128 && h->LD <= 16 &&
            getenv("GRAPHEM_HIP_GRAPH") && atoi(getenv("GRAPHEM_HIP_GRAPH")) != 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
 }
 static int graph_iters() {   // iterations per captured graph (a graph launch has a cost of its own: one iteration per graph

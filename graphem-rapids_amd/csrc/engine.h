@@ -30,6 +30,7 @@ struct gh_timer_slot {
 
 struct gh_comm;   // comm.hip: collective backend of the native partitioned loop
 struct gh_f64;    // f64.hip: state of a float64 engine (gh_create_f64)
+struct gh_ivf;    // ivf.hip: buffers of the inverted-file search (GH_KNN_IVF)
 
 struct gh_engine {
     int device = 0;
@@ -148,6 +149,8 @@ struct gh_engine {
     void *d_grid_smid = nullptr;      // (own_count) float4 midpoints in cell order
     void *d_grid_temp = nullptr;      // radix sort scratch
 
+    gh_ivf *ivf = nullptr;            // GH_KNN_IVF (ivf.hip)
+
     // normalisation
     double *d_blockstats = nullptr; // (nblocks, 2, LD)
     int nblocks_update = 0;
@@ -200,7 +203,7 @@ gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint6
 unsigned gh_setup_blocks(const gh_setup_args &a);
 int64_t gh_gmin_floats(const gh_engine *h);   // size of d_gmin
 gh_status gh_knn_prepare(gh_engine *h);
-gh_status gh_knn_thresholds(gh_engine *h);
+gh_status gh_knn_thresholds(gh_engine *h, int64_t groups = 0);   // groups > 0: d_gmin holds (S, groups) minima written by the caller (ivf.hip)
 struct gh_tau_args;
 gh_tau_args gh_make_tau_args(gh_engine *h);  // tau_core.h
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
@@ -213,6 +216,11 @@ gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows);   // candidate lists
 bool gh_grid_path(const gh_engine *h);
 gh_status gh_grid_alloc(gh_engine *h);
 gh_status gh_grid_search(gh_engine *h);            // d_mid + tau -> candidate lists
+// ivf.hip
+bool gh_ivf_path(const gh_engine *h);
+gh_status gh_ivf_alloc(gh_engine *h);
+void gh_ivf_free(gh_engine *h);
+gh_status gh_ivf_search(gh_engine *h);             // d_mid + query records -> tau and candidate lists (probed lists only)
 // fused.hip
 gh_status gh_radial_topk_device(gh_engine *h, int K, uint64_t *d_part, int nparts, int32_t *d_ids);
 int gh_fused_mfma_kb(const gh_engine *h);          // operand rows the thresholds must write: 0 = split-f16 MFMA form (D <= 3), -1 = none

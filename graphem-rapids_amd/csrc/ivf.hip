@@ -1,0 +1,631 @@
+// GH_KNN_IVF: an inverted-file (IVF-Flat) search of the sampled midpoints, rebuilt every iteration like the reference's
+// cuVS backend rebuilds its index (embedder_cuvs.py:255-313 builds IVF-Flat / IVF-PQ over the midpoints of the iteration,
+// :384-430 searches it).  APPROXIMATE by construction -- a query sees only the members of the `probes` lists whose
+// centroids are nearest to it -- but exact inside those lists: distances are the exact-difference fma chain every other
+// method ranks on, and the k + 1 returned ids are the k + 1 smallest (distance, id) keys among the probed members.
+//
+// What makes it an MI355X design rather than a port of a query-major IVF search:
+//  * the coarse quantiser is a flat argmin over C centroids on the MATRIX pipe: one v_mfma_f32_32x32x16_f16 gives
+//    |c|^2 - 2 c.m for 32 centroids x 32 midpoints with single-piece f16 operands (the assignment only has to be A
+//    partition, not the nearest centroid to the last bit), the winning row rides in the four low mantissa bits of the score;
+//  * the search is LIST-major: (query, probed list) pairs are bucketed by list, and a workgroup takes one 512-member tile
+//    of one list and runs that list's queries over it with the packed-VALU filtered scan of scan_core.h -- a list is read
+//    once per iteration (E * LD * 4 bytes in all), not once per probing query;
+//  * thresholds come from the query's nearest list(s): 256 group minima per query, the K-th smallest of them (the
+//    existing threshold kernel, tau_core.h) bounds the K-th smallest distance INSIDE the probed lists from above, so the
+//    filtered scan finds at least K candidates and usually few more.
+// Everything after the candidate lists (selection, intersection phase) is the code of the exact methods.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "engine.h"
+#include "scan_core.h"
+
+#define GH_IVF_TILE 512          /* members per scan workgroup (R = 2 references per thread) */
+#define GH_IVF_MAX_LISTS 2048
+#define GH_IVF_GROUPS 256        /* group minima per query the threshold is taken from */
+#define GH_IVF_MB 4              /* member blocks of 32 a wave of the assignment holds */
+// Counters that many waves bump with returning atomics: one per 128-byte line (adjacent counters serialise on their L2
+// line, ~11 ns per returning atomic: 32 lists of 2000 members per line cost the assignment 0.7 ms), and GH_IVF_NSUB
+// counters per list taken in turn by the waves, so that a list ten times the mean (16 dimensions: lists near the centre
+// of the cloud) is not one address either.
+#define GH_IVF_CSTRIDE 32
+#define GH_IVF_NSUB 8
+
+struct gh_ivf {
+    int C = 0, P = 0;             // lists, probes per query
+    int64_t M = 0;                // own midpoints
+    int64_t cap_rows = 0;         // rows of the list-ordered copy: M + C * GH_IVF_TILE (every list padded to whole tiles)
+    int64_t max_tiles = 0;
+    unsigned char *blob = nullptr;
+    float *cent = nullptr;        // (C, LD) centroids, fp32
+    uint4 *A = nullptr;           // (C, 2) f16 operand rows: -2 c, 8 halfs per lane half
+    float *cnorm = nullptr;       // (C) |c|^2
+    uint32_t *assign = nullptr;   // (M) list of every own midpoint
+    uint32_t *rank = nullptr;     // (M) its position inside the list
+    int32_t *subcount = nullptr;  // (C * NSUB * CSTRIDE) members counted per (list, sub-counter), one counter per line
+    int32_t *substart = nullptr;  // (C * NSUB) first row of every (list, sub-counter)
+    int32_t *lcount = nullptr;    // (C) members
+    int32_t *lstart = nullptr;    // (C + 1) first row of every list in the padded order
+    int32_t *tile_list = nullptr; // (max_tiles) list of every tile
+    int32_t *meta = nullptr;      // [0] tiles in use
+    float *lmid = nullptr;        // (cap_rows, LD) midpoints in list order
+    uint32_t *lids = nullptr;     // (cap_rows) their edge ids; 0xFFFFFFFF = padding
+    int32_t *lqcount = nullptr;   // (C * CSTRIDE) probing queries per list, one counter per line
+    int32_t *qstart = nullptr;    // (C + 1)
+    uint32_t *pair_l = nullptr;   // (S, P) probed list of pair (query, r)
+    uint32_t *pair_slot = nullptr;// (S, P) position of the query among the list's queries
+    int32_t *pair_q = nullptr;    // (S * P) queries bucketed by list
+};
+
+namespace {
+
+typedef _Float16 ivf_h8 __attribute__((ext_vector_type(8)));
+typedef float ivf_f16x __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ _Float16 ivf_half(float x) { return (_Float16)fminf(fmaxf(x, -30000.0f), 30000.0f); }
+
+// Centroids = this iteration's midpoints of C evenly spaced own edges (a sample of the data's own density, as k-means++
+// seeding without the refinement passes: lists come out at roughly equal mass), their operand rows and norms; counters
+// of the iteration zeroed.
+template <int LD>
+__global__ __launch_bounds__(256) void ivf_centroid_kernel(const float *__restrict__ mid, int64_t M, int C, float *__restrict__ cent,
+                                                           uint4 *__restrict__ A, float *__restrict__ cnorm) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t j = (int64_t)c * M / C + (M / C) / 2;
+    float v[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) v[d] = 0.0f;
+    gh_load_row<LD>(mid, j, v);
+    gh_store_row<LD>(cent, c, v);
+    float nn = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) nn = fmaf(v[d], v[d], nn);
+    cnorm[c] = nn;
+    ivf_h8 lo, hi;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { lo[d] = ivf_half(-2.0f * v[d]); hi[d] = ivf_half(-2.0f * v[8 + d]); }
+    A[2 * c] = __builtin_bit_cast(uint4, lo);
+    A[2 * c + 1] = __builtin_bit_cast(uint4, hi);
+}
+
+// Nearest centroid of every own midpoint.  A wave holds GH_IVF_MB blocks of 32 midpoints as B operands (lane = column,
+// lane half = which 8 of the 16 coordinates) and walks the centroids 32 at a time: accumulator initialised with |c|^2,
+// one MFMA per member block, row index packed into the low 4 mantissa bits, minimum over the lane's 16 rows, running
+// best per column.  The two lane halves of a column hold different rows: combined at the end.
+template <int LD>
+__global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict__ mid, int64_t M, int C, const uint4 *__restrict__ A,
+                                                         const float *__restrict__ cnorm, uint32_t *__restrict__ assign,
+                                                         uint32_t *__restrict__ rank, int32_t *__restrict__ subcount) {
+    extern __shared__ __align__(16) unsigned char ivf_smem[];
+    uint4 *Ash = reinterpret_cast<uint4 *>(ivf_smem);              // (C, 2)
+    float *nsh = reinterpret_cast<float *>(Ash + 2 * (size_t)C);     // (C)
+    for (int i = threadIdx.x; i < 2 * C; i += 256) Ash[i] = A[i];
+    for (int i = threadIdx.x; i < C; i += 256) nsh[i] = cnorm[i];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, hsel = lane >> 5;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + w;
+    const int64_t base = wave * (32 * GH_IVF_MB);
+    const int sc = (int)(wave & (GH_IVF_NSUB - 1));   // = ivf_sub_of(j) for this wave's members
+    ivf_h8 B[GH_IVF_MB];
+#pragma unroll
+    for (int mb = 0; mb < GH_IVF_MB; ++mb) {
+        const int64_t j = base + mb * 32 + col;
+        float v[8];   // this lane half's 8 coordinates (coordinates past LD are 0)
+#pragma unroll
+        for (int d = 0; d < 8; ++d) v[d] = 0.0f;
+        if (j < M && hsel * 8 < LD) {
+            constexpr int NQ = LD >= 8 ? 2 : 1;
+            const float4 *src = reinterpret_cast<const float4 *>(mid + j * LD + hsel * 8);
+#pragma unroll
+            for (int p = 0; p < NQ; ++p) {
+                const float4 x = src[p];
+                v[4 * p] = x.x; v[4 * p + 1] = x.y; v[4 * p + 2] = x.z; v[4 * p + 3] = x.w;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) B[mb][d] = ivf_half(v[d]);
+    }
+    float best[GH_IVF_MB];
+    int bestcb[GH_IVF_MB];
+#pragma unroll
+    for (int mb = 0; mb < GH_IVF_MB; ++mb) { best[mb] = INFINITY; bestcb[mb] = 0; }
+    __syncthreads();
+    const int ncb = C / 32;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const ivf_h8 a = __builtin_bit_cast(ivf_h8, Ash[(cb * 32 + col) * 2 + hsel]);
+        ivf_f16x cinit;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 n4 = *reinterpret_cast<const float4 *>(nsh + cb * 32 + 8 * g + 4 * hsel);
+            cinit[4 * g] = n4.x; cinit[4 * g + 1] = n4.y; cinit[4 * g + 2] = n4.z; cinit[4 * g + 3] = n4.w;
+        }
+        ivf_f16x f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[0], cinit, 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < GH_IVF_MB; ++mb) {
+            ivf_f16x fn = cinit;
+            if (mb + 1 < GH_IVF_MB) fn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[mb + 1], cinit, 0, 0, 0);   // in the matrix pipe while block mb is reduced
+            float mn = INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mn = fminf(mn, __uint_as_float((__float_as_uint(f[i]) & ~15u) | (uint32_t)i));
+            asm volatile("" : "+v"(mn));
+            const bool better = mn < best[mb];
+            best[mb] = better ? mn : best[mb];
+            bestcb[mb] = better ? cb : bestcb[mb];
+            f = fn;
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < GH_IVF_MB; ++mb) {
+        const float ob = __shfl_xor(best[mb], 32, 64);
+        const int ocb = __shfl_xor(bestcb[mb], 32, 64);
+        const int64_t j = base + mb * 32 + col;
+        if (hsel == 0 && j < M) {
+            const bool mine = best[mb] <= ob;
+            const float bv = mine ? best[mb] : ob;
+            const int cb = mine ? bestcb[mb] : ocb;
+            const int i = (int)(__float_as_uint(bv) & 15u);
+            const int l = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (mine ? 0 : 1);
+            assign[j] = (uint32_t)l;
+            rank[j] = (uint32_t)atomicAdd(&subcount[(l * GH_IVF_NSUB + sc) * GH_IVF_CSTRIDE], 1);
+        }
+    }
+}
+
+__device__ __forceinline__ int ivf_sub_of(int64_t j) { return (int)((j / (32 * GH_IVF_MB)) & (GH_IVF_NSUB - 1)); }
+
+// Exclusive prefix over 1024 per-thread sums (one workgroup); returns what precedes this thread, *total = the sum.
+__device__ __forceinline__ int ivf_block_prefix(int sum, int *part, int *total) {
+    const int t = threadIdx.x;
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    *total = part[1023];
+    return part[t] - sum;
+}
+
+// One workgroup: members per list from the sub-counters, every list padded to whole tiles -> lstart (C + 1), the first
+// row of every (list, sub-counter), the list of every tile, the tiles in use.
+__global__ __launch_bounds__(1024) void ivf_list_layout_kernel(const int32_t *__restrict__ subcount, int C, int32_t *__restrict__ lcount,
+                                                               int32_t *__restrict__ lstart, int32_t *__restrict__ substart,
+                                                               int32_t *__restrict__ tile_list, int32_t *__restrict__ meta) {
+    __shared__ int part[1024];
+    constexpr int PER = GH_IVF_MAX_LISTS / 1024;
+    const int t = threadIdx.x;
+    int tot[PER], sub[PER][GH_IVF_NSUB], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = t * PER + i;
+        tot[i] = 0;
+#pragma unroll
+        for (int u = 0; u < GH_IVF_NSUB; ++u) {
+            sub[i][u] = c < C ? subcount[(c * GH_IVF_NSUB + u) * GH_IVF_CSTRIDE] : 0;
+            tot[i] += sub[i][u];
+        }
+        sum += (tot[i] + GH_IVF_TILE - 1) / GH_IVF_TILE * GH_IVF_TILE;
+    }
+    int total;
+    int at = ivf_block_prefix(sum, part, &total);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = t * PER + i;
+        if (c >= C) break;
+        lstart[c] = at;
+        lcount[c] = tot[i];
+        int r = at;
+#pragma unroll
+        for (int u = 0; u < GH_IVF_NSUB; ++u) { substart[c * GH_IVF_NSUB + u] = r; r += sub[i][u]; }
+        const int nt = (tot[i] + GH_IVF_TILE - 1) / GH_IVF_TILE;
+        for (int k = 0; k < nt; ++k) tile_list[at / GH_IVF_TILE + k] = c;
+        at += nt * GH_IVF_TILE;
+    }
+    if (t == 0) { lstart[C] = total; meta[0] = total / GH_IVF_TILE; }
+}
+
+// One workgroup: probing queries per list -> qstart (C + 1).
+__global__ __launch_bounds__(1024) void ivf_query_layout_kernel(const int32_t *__restrict__ lqcount, int C, int32_t *__restrict__ qstart) {
+    __shared__ int part[1024];
+    constexpr int PER = GH_IVF_MAX_LISTS / 1024;
+    const int t = threadIdx.x;
+    int cnt[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = t * PER + i;
+        cnt[i] = c < C ? lqcount[c * GH_IVF_CSTRIDE] : 0;
+        sum += cnt[i];
+    }
+    int total;
+    int at = ivf_block_prefix(sum, part, &total);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = t * PER + i;
+        if (c >= C) break;
+        qstart[c] = at;
+        at += cnt[i];
+    }
+    if (t == 0) qstart[C] = total;
+}
+
+// Midpoints and edge ids into list order.
+template <int LD>
+__global__ __launch_bounds__(256) void ivf_scatter_kernel(const float *__restrict__ mid, int64_t M, const uint32_t *__restrict__ assign,
+                                                          const uint32_t *__restrict__ rank, const int32_t *__restrict__ substart,
+                                                          int64_t e_lo, const int32_t *__restrict__ eids, float *__restrict__ lmid,
+                                                          uint32_t *__restrict__ lids) {
+    constexpr int Q = LD / 4;   // 16-byte pieces per row: consecutive threads move consecutive pieces
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = i / Q;
+    const int p = (int)(i % Q);
+    if (j >= M) return;
+    const int64_t dst = (int64_t)substart[assign[j] * GH_IVF_NSUB + ivf_sub_of(j)] + rank[j];
+    reinterpret_cast<float4 *>(lmid)[dst * Q + p] = reinterpret_cast<const float4 *>(mid)[j * Q + p];
+    if (p == 0) lids[dst] = eids ? (uint32_t)eids[j] : (uint32_t)(e_lo + j);
+}
+
+__device__ __forceinline__ uint64_t ivf_wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint64_t o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// One wave per query, 16 queries per workgroup: distances to the C centroids (NV per lane) from the f16 operand table
+// staged in LDS -- |c|^2 - 2 c.q + |q|^2 with c to 11 bits: the ORDER of the lists is all that is needed --, the P
+// nearest lists -> pairs, and the group minima (exact distances) of the nearest list(s) the threshold is taken from.
+template <int LD, int NV>
+__global__ __launch_bounds__(1024) void ivf_probe_kernel(const float *__restrict__ qt, int QS, int S, int D, const uint4 *__restrict__ A,
+                                                         const float *__restrict__ cnorm, int C, int P, const int32_t *__restrict__ lstart,
+                                                         const int32_t *__restrict__ lcount, const float *__restrict__ lmid, int tau_members,
+                                                         uint32_t *__restrict__ pair_l, uint32_t *__restrict__ pair_slot,
+                                                         int32_t *__restrict__ lqcount, uint32_t *__restrict__ gmin) {
+    extern __shared__ __align__(16) unsigned char ivf_smem[];
+    uint4 *Ash = reinterpret_cast<uint4 *>(ivf_smem);              // (C, 2)
+    float *nsh = reinterpret_cast<float *>(Ash + 2 * (size_t)C);     // (C)
+    for (int i = threadIdx.x; i < 2 * C; i += 1024) Ash[i] = A[i];
+    for (int i = threadIdx.x; i < C; i += 1024) nsh[i] = cnorm[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (qi >= S) return;
+    float q[LD];
+#pragma unroll
+    for (int d = 0; d < LD; ++d) q[d] = d < D ? qt[(int64_t)qi * QS + d] : 0.0f;
+    float qn = 0.0f;
+#pragma unroll
+    for (int d = 0; d < LD; ++d) qn = fmaf(q[d], q[d], qn);
+    uint32_t v[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = j * 64 + lane;
+        v[j] = 0x7F800000u;
+        if (c < C) {
+            float acc = nsh[c] + qn;
+            const ivf_h8 lo = __builtin_bit_cast(ivf_h8, Ash[2 * c]);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) if (d < LD) acc = fmaf((float)lo[d], q[d], acc);
+            if constexpr (LD > 8) {
+                const ivf_h8 hi = __builtin_bit_cast(ivf_h8, Ash[2 * c + 1]);
+#pragma unroll
+                for (int d = 0; d < 8; ++d) acc = fmaf((float)hi[d], q[8 + d], acc);
+            }
+            v[j] = __float_as_uint(fmaxf(acc, 0.0f));
+        }
+    }
+    // the P-th smallest centroid distance, bit by bit from the top (as gh_tau_kth).  All 31 bits: in 16 dimensions the
+    // centroid distances of a query crowd together, and a band of 2^-8 around the P-th held a dozen lists more than P,
+    // of which the first P in LIST order were taken -- not the nearest
+    uint32_t prefix = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+        const uint32_t t = prefix | (1u << bit);
+        int below = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) below += __popcll(__ballot(v[j] < t));
+        if (below < P) prefix = t;
+    }
+    const uint32_t thr = prefix;
+    int base = 0;
+    uint32_t took = 0;   // bit j: this lane's list j * 64 + lane is probed (the band around the P-th value can hold more than P)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const bool in = v[j] <= thr && j * 64 + lane < C;
+        const unsigned long long b = __ballot(in);
+        const int r = base + __popcll(b & ((1ull << lane) - 1ull));
+        if (in && r < P) {
+            took |= 1u << j;
+            const int l = j * 64 + lane;
+            pair_l[(int64_t)qi * P + r] = (uint32_t)l;
+            pair_slot[(int64_t)qi * P + r] = (uint32_t)atomicAdd(&lqcount[l * GH_IVF_CSTRIDE], 1);
+        }
+        base += __popcll(b);
+    }
+    for (int r = base + lane; r < P; r += 64) pair_l[(int64_t)qi * P + r] = 0xFFFFFFFFu;   // fewer than P lists in all
+    // group minima over the nearest lists, nearest first, until tau_members members have been seen
+    constexpr int NG = GH_IVF_GROUPS / 64;
+    float gm[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) gm[g] = INFINITY;
+    int seen = 0;
+    for (int round = 0; round < P && seen < tau_members; ++round) {
+        uint64_t mine = ~0ull;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const uint64_t key = ((took >> j) & 1u) ? ((uint64_t)v[j] << 32) | (uint32_t)(j * 64 + lane) : ~0ull;
+            mine = key < mine ? key : mine;
+        }
+        const uint64_t win = ivf_wave_min_u64(mine);
+        if (win == ~0ull) break;   // only lists this query probes
+        const int l = (int)(uint32_t)win;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) took &= (j * 64 + lane == l) ? ~(1u << j) : ~0u;
+        const int64_t r0 = lstart[l];
+        const int n = min(lcount[l], tau_members - seen);   // any subset of the probed members bounds their K-th distance from above
+        for (int i0 = 0; i0 < n; i0 += 64 * NG) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int i = i0 + g * 64 + lane;
+                if (i < n) {
+                    float m[LD];
+                    gh_load_row<LD>(lmid, r0 + i, m);
+                    float d2 = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < LD; ++d) { const float t = q[d] - m[d]; d2 = fmaf(t, t, d2); }
+                    gm[g] = fminf(gm[g], d2);
+                }
+            }
+        }
+        seen += n;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) gmin[(int64_t)qi * GH_IVF_GROUPS + g * 64 + lane] = __float_as_uint(gm[g]);
+}
+
+__global__ __launch_bounds__(256) void ivf_pair_scatter_kernel(const uint32_t *__restrict__ pair_l, const uint32_t *__restrict__ pair_slot,
+                                                               int64_t npairs, int P, const int32_t *__restrict__ qstart,
+                                                               int32_t *__restrict__ pair_q) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const uint32_t l = pair_l[i];
+    if (l != 0xFFFFFFFFu) pair_q[qstart[l] + pair_slot[i]] = (int32_t)(i / P);
+}
+
+// One tile of one list against the queries that probe the list: the filtered scan of scan_core.h (pre-filter in
+// norm-expansion form on packed fp32, exact fma chain on what passes, hits parked in LDS).
+template <int D>
+__global__ __launch_bounds__(256) void ivf_scan_kernel(const float *__restrict__ lmid, const uint32_t *__restrict__ lids,
+                                                       const int32_t *__restrict__ tile_list, const int32_t *__restrict__ meta,
+                                                       const int32_t *__restrict__ qstart, const int32_t *__restrict__ pair_q,
+                                                       const float *__restrict__ qt, const float *__restrict__ qscan,
+                                                       uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
+    constexpr int R = GH_IVF_TILE / 256;
+    constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
+    constexpr int QS = D <= 3 ? 4 : LD + 4;
+    constexpr int QT = D <= 3 ? 3 : LD;
+    __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)];
+    __shared__ float taush[GH_SCAN_QGROUP];
+    __shared__ int qmap[GH_SCAN_QGROUP];
+    __shared__ uint64_t hkey[1024];
+    __shared__ int hq[1024];
+    __shared__ int hcount;
+    const int tile = blockIdx.x;
+    if (tile >= meta[0]) return;
+    const int l = tile_list[tile];
+    const int q0 = qstart[l], q1 = qstart[l + 1];
+    if (q0 == q1) return;
+    gh_f2 m[R / 2][D], c0[R / 2];
+    uint32_t id[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t j = (int64_t)tile * GH_IVF_TILE + r * 256 + threadIdx.x;
+        id[r] = lids[j];
+        const bool valid = id[r] != 0xFFFFFFFFu;
+        float mv[LD];
+#pragma unroll
+        for (int d = 0; d < LD; ++d) mv[d] = 0.0f;
+        if (valid) gh_load_row<LD>(lmid, j, mv);
+        const float c = gh_ref_c0<D>(mv, valid);
+        if (r & 1) c0[r / 2].y = c; else c0[r / 2].x = c;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (r & 1) m[r / 2][d].y = mv[d];
+            else m[r / 2][d].x = mv[d];
+        }
+    }
+    for (int qb = q0; qb < q1; qb += GH_SCAN_QGROUP) {
+        const int nq = min(q1 - qb, GH_SCAN_QGROUP);
+        __syncthreads();
+        if (threadIdx.x == 0) hcount = 0;
+        for (int i = threadIdx.x; i < (nq + 1) * (QS / 4); i += 256) {
+            const int s = i / (QS / 4), p = i % (QS / 4);
+            qsh[i] = s < nq ? reinterpret_cast<const float4 *>(qscan)[(int64_t)pair_q[qb + s] * (QS / 4) + p] : make_float4(0.f, 0.f, 0.f, -1.f);
+        }
+        for (int i = threadIdx.x; i < nq; i += 256) {
+            const int s = pair_q[qb + i];
+            qmap[i] = s;
+            taush[i] = qt[(int64_t)s * QS + QT];
+        }
+        __syncthreads();
+        gh_scan_queries<D, R, 1024>(m, c0, id, qsh, nq, 0, taush, hkey, hq, &hcount, cand, cnt, qmap);
+        __syncthreads();
+        gh_flush_hits<1024>(hkey, hq, &hcount, cand, cnt);
+    }
+}
+
+size_t ivf_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+bool gh_ivf_path(const gh_engine *h) {
+    return h->prm.knn_method == GH_KNN_IVF && !h->cdist && h->D >= 2 && h->LD <= 16 && gh_knn_scan_path(h) &&
+           h->own_count >= 64 * 64 && h->own_count < ((int64_t)1 << 31) - (int64_t)GH_IVF_MAX_LISTS * GH_IVF_TILE;
+}
+
+void gh_ivf_free(gh_engine *h) {
+    if (!h->ivf) return;
+    if (h->ivf->blob) (void)hipFree(h->ivf->blob);
+    delete h->ivf;
+    h->ivf = nullptr;
+}
+
+gh_status gh_ivf_alloc(gh_engine *h) {
+    if (!gh_ivf_path(h)) return GH_OK;
+    gh_ivf *v = new gh_ivf();
+    h->ivf = v;
+    const int64_t M = h->own_count;
+    v->M = M;
+    // lists: about sqrt(M) / 2, a multiple of 64, at least 64 members on average (the assignment costs M * C score
+    // evaluations: 4 M midpoints, 1984 lists 520 us, 1024 lists 270 us, and the same recall for the same scan work);
+    // probes: a sixteenth of them unless told otherwise (4 M midpoints: recall 0.992 in 16 dimensions, > 0.999 in 6)
+    int64_t C = h->prm.ivf_lists > 0 ? h->prm.ivf_lists : (int64_t)std::llround(std::sqrt((double)M) / 2.0);
+    C = std::min<int64_t>(C, M / 64);
+    C = std::max<int64_t>(64, std::min<int64_t>(GH_IVF_MAX_LISTS, (C + 32) / 64 * 64));
+    int64_t P = h->prm.ivf_probes > 0 ? h->prm.ivf_probes : C / 16;
+    P = std::max<int64_t>(1, std::min<int64_t>(P, C));
+    v->C = (int)C;
+    v->P = (int)P;
+    v->cap_rows = M + C * GH_IVF_TILE;
+    v->max_tiles = v->cap_rows / GH_IVF_TILE + 1;
+    const size_t S = (size_t)h->S, LD = (size_t)h->LD;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += ivf_align(bytes); return o; };
+    const size_t o_cent = take(4 * C * LD), o_A = take(32 * C), o_cn = take(4 * C), o_as = take(4 * M), o_rk = take(4 * M),
+                 o_sc = take(4 * C * GH_IVF_NSUB * GH_IVF_CSTRIDE), o_ss = take(4 * C * GH_IVF_NSUB), o_lc = take(4 * C), o_ls = take(4 * (C + 1)), o_tl = take(4 * v->max_tiles), o_me = take(16),
+                 o_lm = take(4 * v->cap_rows * LD), o_li = take(4 * v->cap_rows), o_lq = take(4 * C * GH_IVF_CSTRIDE), o_qs = take(4 * (C + 1)),
+                 o_pl = take(4 * S * P), o_ps = take(4 * S * P), o_pq = take(4 * S * P);
+    if (hipMalloc(reinterpret_cast<void **>(&v->blob), off) != hipSuccess) {
+        h->err = "hipMalloc of the IVF buffers failed";
+        return GH_ERR_NOMEM;
+    }
+    if (hipMemset(v->blob, 0, off) != hipSuccess) { h->err = "hipMemset of the IVF buffers failed"; return GH_ERR_HIP; }
+    unsigned char *b = v->blob;
+    v->cent = reinterpret_cast<float *>(b + o_cent);
+    v->A = reinterpret_cast<uint4 *>(b + o_A);
+    v->cnorm = reinterpret_cast<float *>(b + o_cn);
+    v->assign = reinterpret_cast<uint32_t *>(b + o_as);
+    v->rank = reinterpret_cast<uint32_t *>(b + o_rk);
+    v->subcount = reinterpret_cast<int32_t *>(b + o_sc);
+    v->substart = reinterpret_cast<int32_t *>(b + o_ss);
+    v->lcount = reinterpret_cast<int32_t *>(b + o_lc);
+    v->lstart = reinterpret_cast<int32_t *>(b + o_ls);
+    v->tile_list = reinterpret_cast<int32_t *>(b + o_tl);
+    v->meta = reinterpret_cast<int32_t *>(b + o_me);
+    v->lmid = reinterpret_cast<float *>(b + o_lm);
+    v->lids = reinterpret_cast<uint32_t *>(b + o_li);
+    v->lqcount = reinterpret_cast<int32_t *>(b + o_lq);
+    v->qstart = reinterpret_cast<int32_t *>(b + o_qs);
+    v->pair_l = reinterpret_cast<uint32_t *>(b + o_pl);
+    v->pair_slot = reinterpret_cast<uint32_t *>(b + o_ps);
+    v->pair_q = reinterpret_cast<int32_t *>(b + o_pq);
+    return GH_OK;
+}
+
+extern "C" gh_status gh_knn_ivf_list_sizes(gh_handle h, int32_t *sizes, int32_t count) {
+    if (!h) return GH_ERR_INVALID;
+    if (!h->ivf || !sizes || count != h->ivf->C) { h->err = "gh_knn_ivf_list_sizes: not a GH_KNN_IVF engine, or count != lists"; return GH_ERR_INVALID; }
+    GH_HIP(hipStreamSynchronize(h->stream));
+    GH_HIP(hipMemcpy(sizes, h->ivf->lcount, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost));
+    return GH_OK;
+}
+
+extern "C" gh_status gh_knn_ivf_config(gh_handle h, int32_t *lists, int32_t *probes) {
+    if (!h) return GH_ERR_INVALID;
+    if (lists) *lists = h->ivf ? h->ivf->C : 0;
+    if (probes) *probes = h->ivf ? h->ivf->P : 0;
+    return GH_OK;
+}
+
+// d_mid (this iteration's own midpoints) + the query records -> tau of every query and its candidate list.
+gh_status gh_ivf_search(gh_engine *h) {
+    gh_ivf *v = h->ivf;
+    const int64_t M = v->M;
+    const int C = v->C, P = v->P, QS = gh_qs(h->D, h->LD), S = (int)h->S;
+    // members the threshold is taken from: the K-th smallest of an m-sample of the N probed members sits near rank K * N / m
+    // of them, which is what the filtered scan then lets through per query: m = N / 16 (N / 64 left the queries next to
+    // the crowded lists of a 16-dimensional cloud with more than the 16384 keys a candidate list holds), 1024 ... 8192
+    const int64_t probed = (int64_t)P * (M / C);
+    const int tau_members = (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / 16));
+#define GH_IVF_LD(X)                          \
+    switch (h->LD) {                          \
+        case 4: { X(4) } break;               \
+        case 8: { X(8) } break;               \
+        default: { X(16) } break;             \
+    }
+    {
+        gh_scope t(h, "ivf_build");
+        GH_HIP(hipMemsetAsync(v->lids, 0xFF, sizeof(uint32_t) * (size_t)v->cap_rows, h->stream));
+        GH_HIP(hipMemsetAsync(v->subcount, 0, sizeof(int32_t) * (size_t)C * GH_IVF_NSUB * GH_IVF_CSTRIDE, h->stream));
+        GH_HIP(hipMemsetAsync(v->lqcount, 0, sizeof(int32_t) * (size_t)C * GH_IVF_CSTRIDE, h->stream));
+#define GH_X(L) ivf_centroid_kernel<L><<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, M, C, v->cent, v->A, v->cnorm);
+        GH_IVF_LD(GH_X)
+#undef GH_X
+        GH_LAUNCH_CHECK();
+    }
+    {
+        gh_scope t(h, "ivf_assign");
+        const unsigned ablocks = (unsigned)((M + 4 * 32 * GH_IVF_MB - 1) / (4 * 32 * GH_IVF_MB));
+        const size_t lds = (size_t)C * 36;
+#define GH_X(L)                                                                                                                                  \
+    if (lds > 48 * 1024) GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_assign_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    ivf_assign_kernel<L><<<dim3(ablocks), dim3(256), lds, h->stream>>>(h->d_mid, M, C, v->A, v->cnorm, v->assign, v->rank, v->subcount);
+        GH_IVF_LD(GH_X)
+#undef GH_X
+        GH_LAUNCH_CHECK();
+    }
+    {
+        gh_scope t(h, "ivf_layout");
+        ivf_list_layout_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(v->subcount, C, v->lcount, v->lstart, v->substart, v->tile_list, v->meta);
+        const int Q = h->LD / 4;
+#define GH_X(L) ivf_scatter_kernel<L><<<dim3((unsigned)((M * Q + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, M, v->assign, v->rank, v->substart, h->part.edge_lo, h->d_own_eids, v->lmid, v->lids);
+        GH_IVF_LD(GH_X)
+#undef GH_X
+        GH_LAUNCH_CHECK();
+    }
+    {
+        gh_scope t(h, "ivf_probe");
+        const unsigned pb = (unsigned)((S + 15) / 16);
+        const int nv = (C + 63) / 64;
+        const size_t lds = (size_t)C * 36;
+#define GH_PROBE(L, NVv)                                                                                                                              \
+    {                                                                                                                                                 \
+        if (lds > 48 * 1024) GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_probe_kernel<L, NVv>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        ivf_probe_kernel<L, NVv><<<dim3(pb), dim3(1024), lds, h->stream>>>(h->d_q, QS, S, h->D, v->A, v->cnorm, C, P, v->lstart, v->lcount, v->lmid, tau_members, \
+                                                                          v->pair_l, v->pair_slot, v->lqcount, reinterpret_cast<uint32_t *>(h->d_gmin)); \
+    }
+#define GH_X(L)                               \
+    if (nv <= 8) GH_PROBE(L, 8)               \
+    else if (nv <= 16) GH_PROBE(L, 16)        \
+    else GH_PROBE(L, 32)
+        GH_IVF_LD(GH_X)
+#undef GH_X
+#undef GH_PROBE
+        ivf_query_layout_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(v->lqcount, C, v->qstart);
+        const int64_t npairs = (int64_t)S * P;
+        ivf_pair_scatter_kernel<<<dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, h->stream>>>(v->pair_l, v->pair_slot, npairs, P, v->qstart, v->pair_q);
+        GH_LAUNCH_CHECK();
+    }
+    GH_TRY_ST(gh_knn_thresholds(h, GH_IVF_GROUPS));
+    {
+        gh_scope t(h, "ivf_scan");
+        const dim3 grid((unsigned)v->max_tiles);
+#define GH_X(DD) ivf_scan_kernel<DD><<<grid, dim3(256), 0, h->stream>>>(v->lmid, v->lids, v->tile_list, v->meta, v->qstart, v->pair_q, h->d_q, h->d_qscan, h->d_cand, h->d_cnt)
+        switch (h->D) {
+            case 2: GH_X(2); break;
+            case 3: GH_X(3); break;
+            case 4: GH_X(4); break;
+            default:
+                if (h->LD == 8) GH_X(8);
+                else GH_X(16);
+        }
+#undef GH_X
+        GH_LAUNCH_CHECK();
+    }
+#undef GH_IVF_LD
+    return GH_OK;
+}

@@ -685,7 +685,7 @@ bool gh_knn_scan_path(const gh_engine *h) {
 gh_setup_args gh_make_setup_args(gh_engine *h, int mode, int32_t *sampled, uint64_t iter) {
     if (h->thr_stride == 0) {  // fixed at the first use: d_gmin is sized from it
         const int64_t Mtot = own_edges(h);
-        const bool scan = gh_knn_scan_path(h) && !gh_grid_path(h);   // the grid search takes its thresholds from the grid
+        const bool scan = gh_knn_scan_path(h) && !gh_grid_path(h) && !gh_ivf_path(h);   // the grid / IVF searches take their thresholds from their own structures
         h->thr_stride = scan ? subset_stride(Mtot, h->Ksel, h->S, gh_fused_tile(h), gh_fused_uses_mfma(h)) : 1;
         h->thr_M1 = scan ? (Mtot + h->thr_stride - 1) / h->thr_stride : 0;
     }
@@ -704,6 +704,7 @@ unsigned gh_setup_blocks(const gh_setup_args &a) {
 }
 int64_t gh_gmin_floats(const gh_engine *h) {
     const gh_setup_args a = gh_make_setup_args(const_cast<gh_engine *>(h), 0, nullptr, 0);
+    if (gh_ivf_path(h)) return h->S * 256 + 4;   // GH_IVF_GROUPS minima per query, written by ivf_probe_kernel
     if (a.tiles == 0) return 4;
     return h->S * a.Gpad + 4;
 }
@@ -745,9 +746,10 @@ gh_tau_args gh_make_tau_args(gh_engine *h) {
 }
 
 // tau of every query from the group minima the set-up left in d_gmin.  Needs gh_knn_scan_path(h).
-gh_status gh_knn_thresholds(gh_engine *h) {
+gh_status gh_knn_thresholds(gh_engine *h, int64_t groups) {
     gh_scope t(h, "knn_tau");
-    const gh_tau_args a = gh_make_tau_args(h);
+    gh_tau_args a = gh_make_tau_args(h);
+    if (groups > 0) a.Gpad = groups;
     const int nv = gh_tau_nv_host(a.Gpad);
 #define GH_TAU_FORM(NVv)                                                                            \
     if (a.qA_kb == 0) knn_tau_kernel<NVv, 0><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(a);  \

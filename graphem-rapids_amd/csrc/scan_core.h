@@ -89,7 +89,7 @@ __device__ __forceinline__ void gh_scan_queries(const gh_f2 (&m)[R / 2][D], cons
                                                 const uint32_t (&id)[R], const float4 *qsh, int nq, int s_lo,
                                                 const float *taush, uint64_t *hkey, int *hq,
                                                 int *hcount, uint64_t *__restrict__ cand,
-                                                int32_t *__restrict__ cnt) {
+                                                int32_t *__restrict__ cnt, const int *qmap = nullptr /* LDS: query of slot s (ivf.hip) */) {
     constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     constexpr int QT = D <= 3 ? 3 : LD;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void gh_scan_queries(const gh_f2 (&m)[R / 2][D], cons
 #pragma unroll
         for (int r = 1; r < R / 2; ++r) amin = fminf(amin, fminf(a[r].x, a[r].y));
         if (amin <= t) {  // rare: some reference of this thread may be a candidate
-            const int sg = s_lo + s;
+            const int sg = qmap ? qmap[s] : s_lo + s;
             float q[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) q[d] = -0.5f * qv[d];  // the record holds -2q: exact both ways

@@ -56,6 +56,8 @@ class GraphEmbedderHIP:
         init="auto",
         knn_method="auto",
         knn_distance="auto",
+        ivf_lists=0,
+        ivf_probes=0,
     ):
         """Arguments as pt.py:51-104.  Extra keyword-only arguments:
 
@@ -67,7 +69,11 @@ class GraphEmbedderHIP:
             exact search through a grid over the midpoints rebuilt every iteration -- sub-quadratic, pays from
             several thousand sampled midpoints on; the counterpart of the reference's cuVS indexes,
             embedder_cuvs.py:255-313; with more components the scan is taken), or 'auto' = 'grid' when
-            n_components <= 3 and sample_size >= 12288.
+            n_components <= 3 and sample_size >= 12288.  'ivf': an inverted-file search rebuilt every iteration, any
+            n_components <= 16 -- APPROXIMATE like the reference's cuVS IVF-Flat index (embedder_cuvs.py:255-313): a
+            query sees the `ivf_probes` of `ivf_lists` lists nearest to it (0 = engine defaults: about sqrt(E) lists, an
+            eighth of them probed) and gets the exact k + 1 nearest among their members; pays from a few thousand
+            sampled midpoints on.  Not available with knn_distance='cdist' (the parity mode is exact).
         knn_distance : 'cdist' ranks the neighbours on the value torch.cdist gives (ATen's matmul form, fp32) and orders
             equal values as torch.topk does, i.e. the neighbour ids of the reference's PyTorch-CPU backend row for row
             (pt.py:580-583); 'exact' ranks on the exact-difference squared distance, ties on the smaller id (what the
@@ -140,8 +146,10 @@ class GraphEmbedderHIP:
         self.sampler = sampler
         if knn_distance not in ("auto", "exact", "cdist"):
             raise ValueError(f"Invalid knn_distance: {knn_distance}")
+        if knn_method == "ivf" and knn_distance == "cdist":
+            raise ValueError("knn_method='ivf' is approximate; knn_distance='cdist' (the parity mode) needs an exact search")
         if knn_distance == "auto":
-            knn_distance = "cdist" if sampler == "torch" else "exact"
+            knn_distance = "cdist" if sampler == "torch" and knn_method != "ivf" else "exact"
         self.knn_distance = knn_distance
 
         # the device sampler's key: an unseeded embedder draws it from torch's global generator, so unseeded
@@ -157,7 +165,7 @@ class GraphEmbedderHIP:
         self._engine = _native.Engine(
             self.n, n_components, self._edges_np, L_min, k_attr, k_inter, n_neighbors, self.sample_size,
             seed=self._engine_seed, device_id=self.device.index, knn_method=knn_method,
-            knn_distance="exact" if dtype == torch.float64 else knn_distance,
+            knn_distance="exact" if dtype == torch.float64 else knn_distance, ivf_lists=ivf_lists, ivf_probes=ivf_probes,
             dtype="float64" if dtype == torch.float64 else "float32")
         if self.verbose:
             self.logger.info("Initialized GraphEmbedderHIP on %s", self.device)

@@ -81,7 +81,7 @@ def test_grid_path_is_taken_and_runs_a_layout():
     out = emb.run_layout(3)
     assert out.shape == (n, 3) and np.isfinite(out).all()
     with pytest.raises(ValueError):
-        gra.create_graphem(gra.edges_to_adjacency(n, edges), n_components=3, backend="hip", verbose=False, knn_method="ivf")
+        gra.create_graphem(gra.edges_to_adjacency(n, edges), n_components=3, backend="hip", verbose=False, knn_method="kdtree")
 
 
 def test_grid_knn_at_16_components_on_the_snap_shape(monkeypatch):
