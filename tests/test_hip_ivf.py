@@ -1,0 +1,160 @@
+"""knn_method='ivf' (second half: the counterpart of the cuVS backend's IVF-Flat index,
+embedder_cuvs.py:255-313, 384-430), csrc/ivf.hip.  The search is approximate by construction -- a query sees the members
+of the lists it probes -- and exact inside them, which gives two kinds of test:
+
+  * probing EVERY list must reproduce the exact search id for id (partition complete, list order, per-list query buckets,
+    thresholds from the nearest lists, filtered scan, selection: any member lost anywhere shows up here), for 2 to 16
+    components, with outliers beyond the f16 range of the assignment's operands, with k + 1 up to 33;
+  * with the engine's defaults the RECALL against the exact kernel and the effect on a step are measured and asserted with
+    the stated bounds (200 K vertices / 800 K edges: >= 0.995 of the neighbour ids in 6 components and >= 0.97 in 16 with the
+    defaults, >= 0.99 in 16 with a seventh of the lists probed), every returned id a
+    member of a probed list at its exact distance, k-th distance within a few percent of the exact one.
+Needs a real MI355X."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(n, deg, seed):
+    import graphem_rapids_amd as gra
+    return np.ascontiguousarray(gra.random_regular_edges(n, deg, seed=seed), dtype=np.int32)
+
+
+def _layout(n, D, edges, k, S, iters=8, scale=0.1, seed=5):
+    """A layout a few exact iterations in (what the index meets in a run), from the reference's kind of random start."""
+    from graphem_rapids_amd import _native
+    pos = (np.random.default_rng(seed).standard_normal((n, D)) * scale).astype(np.float32)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=1, knn_method="scan")
+    eng.set_positions(pos)
+    eng.run(iters)
+    out = eng.get_positions()
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("n,D,k,S,state", [
+    (30000, 2, 10, 512, "layout"), (30000, 3, 10, 1024, "layout"), (30000, 4, 10, 512, "layout"),
+    (30000, 6, 15, 1024, "layout"), (30000, 8, 10, 512, "start"), (30000, 12, 10, 512, "layout"),
+    (30000, 16, 32, 1024, "layout"), (30000, 16, 10, 300, "outliers"), (30000, 3, 10, 777, "outliers"),
+])
+def test_probing_every_list_gives_the_exact_rows(n, D, k, S, state):
+    from graphem_rapids_amd import _native
+    edges = _graph(n, 6, seed=3)
+    rng = np.random.default_rng(9)
+    if state == "layout":
+        pos = _layout(n, D, edges, k, S)
+    else:
+        pos = rng.standard_normal((n, D)).astype(np.float32) * np.float32(0.1 if state == "start" else 1.0)
+    if state == "outliers":   # beyond the +-30000 the assignment clamps its f16 operands to, and beyond the scan's f16 range
+        far = rng.permutation(n)[:50]
+        pos[far] *= np.float32(1e5)
+    sampled = rng.permutation(len(edges))[:S].astype(np.int32)
+    ref = oracle.knn_midpoints(pos, edges, sampled, k)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_method="ivf", ivf_lists=128, ivf_probes=128)
+    assert eng.knn_ivf_config() == (128, 128)
+    eng.set_positions(pos)
+    rows = eng.knn_midpoints(sampled)
+    sizes = eng.knn_ivf_list_sizes()
+    assert sizes.sum() == len(edges) and sizes.min() >= 0          # a partition of the edges
+    assert np.array_equal(rows, ref)
+    assert "ivf_scan" in _timed_step(eng, sampled)
+    # a whole step through it: the exact step
+    eng.set_positions(pos)
+    eng.step(sampled)
+    assert np.abs(eng.get_positions() - oracle.step(pos, edges, sampled, k)).max() <= 1e-4
+    eng.close()
+
+
+def _timed_step(eng, sampled):
+    eng.timing_enable(True)
+    eng.step(sampled)
+    eng.sync()
+    names = set(eng.timings())
+    eng.timing_enable(False)
+    return names
+
+
+@pytest.mark.parametrize("D,probes,min_recall", [(6, 0, 0.995), (16, 0, 0.97), (16, 64, 0.99)])
+def test_recall_of_the_index(D, probes, min_recall):
+    """200 K vertices / 800 K edges, engine defaults (448 lists, 28 probed) and, for the 16-component cloud, a seventh of the
+    lists: recall of the neighbour ids against the exact kernel (measured 0.9999 / 0.979 / see the printed line), and what a
+    returned row is -- ids of probed members at their exact distances, ascending, no duplicates."""
+    from graphem_rapids_amd import _native
+    n, k, S = 200000, 10, 2048
+    edges = _graph(n, 8, seed=4)
+    pos = _layout(n, D, edges, k, S)
+    rng = np.random.default_rng(2)
+    sampled = rng.permutation(len(edges))[:S].astype(np.int32)
+    exact = oracle.knn_midpoints(pos, edges, sampled, k, tiled=True)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_method="ivf", ivf_probes=probes)
+    lists, probes = eng.knn_ivf_config()
+    assert lists == 448 and probes in (28, 64)
+    eng.set_positions(pos)
+    rows = eng.knn_midpoints(sampled)
+    again = eng.knn_midpoints(sampled)
+    assert np.array_equal(rows, again)     # list order depends on atomics, the rows do not
+    hits = sum(len(np.intersect1d(rows[i], exact[i])) for i in range(S))
+    recall = hits / (S * k)
+    mid = (pos[edges[:, 0]] + pos[edges[:, 1]]) / np.float32(2.0)
+    q = mid[sampled][:, None, :].astype(np.float64)
+    d_ivf = np.sqrt(((q - mid[rows]) ** 2).sum(-1))
+    d_ex = np.sqrt(((q - mid[exact]) ** 2).sum(-1))
+    print(f"\nivf D={D}: lists={lists} probes={probes} recall={recall:.4f} rows complete={np.mean((rows == exact).all(1)):.3f} "
+          f"k-th distance ratio mean={np.mean(d_ivf[:, -1] / d_ex[:, -1]):.4f} max={np.max(d_ivf[:, -1] / d_ex[:, -1]):.3f}")
+    assert recall >= min_recall
+    assert (np.diff(d_ivf, axis=1) >= -1e-6).all()                          # ascending
+    assert all(len(set(r)) == k for r in rows)                              # no duplicates
+    assert (d_ivf[:, -1] >= d_ex[:, -1] * (1 - 1e-6)).all()                 # never better than exact
+    assert np.mean(d_ivf[:, -1] / d_ex[:, -1]) <= 1.01 and np.max(d_ivf[:, -1] / d_ex[:, -1]) <= 1.5
+    _, _, fallback = eng.knn_last_counts()
+    assert fallback.sum() <= S // 100
+    eng.close()
+
+
+def test_ivf_layout_run_and_public_class():
+    """A device-sampled run through the index stays finite and close to the exact run over a short horizon; the public
+    class takes knn_method='ivf' (and refuses it together with the parity distance)."""
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    n, D, k, S = 60000, 6, 10, 1024
+    edges = _graph(n, 8, seed=6)
+    pos0 = (np.random.default_rng(0).standard_normal((n, D)) * 0.1).astype(np.float32)
+    sampled = np.random.default_rng(3).permutation(len(edges))[:S].astype(np.int32)
+    out, rows = {}, {}
+    for method in ("scan", "ivf"):
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=7, knn_method=method)
+        eng.set_positions(pos0)
+        rows[method] = eng.knn_midpoints(sampled)
+        eng.step(sampled)                       # one step from the same state with the same sample
+        out[method + "_1"] = eng.get_positions()
+        eng.run(5)                              # then the device-sampled loop (set-up inside the normalise launch)
+        out[method] = eng.get_positions()
+        eng.close()
+    assert np.isfinite(out["ivf"]).all() and np.abs(out["ivf"].std(axis=0, ddof=1) - 1.0).max() < 1e-3
+    # a missed neighbour changes the forces on the four endpoints of one pair of edges; everything else moves only through
+    # the column statistics
+    missed = int((rows["ivf"] != rows["scan"]).any(axis=1).sum()) * k
+    moved = int((np.abs(out["ivf_1"] - out["scan_1"]).max(axis=1) > 1e-3).sum())
+    print(f"\nivf step: rows that differ {missed // k} of {S}, vertices moved by more than 1e-3: {moved}")
+    assert moved <= 4 * missed
+    # the device-sampled loop with every list probed is the exact loop (same seed, same samples)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=7, knn_method="ivf", ivf_lists=64, ivf_probes=64)
+    eng.set_positions(pos0)
+    eng.step(sampled)
+    eng.run(5)
+    full = eng.get_positions()
+    eng.close()
+    assert np.abs(full - out["scan"]).max() <= 1e-4
+    adj = gra.edges_to_adjacency(n, edges)
+    emb = gra.create_graphem(adj, n_components=D, backend="hip", verbose=False, seed=0, init="random", sample_size=S,
+                             knn_method="ivf", ivf_probes=16)
+    assert emb.knn_distance == "exact"
+    res = emb.run_layout(3)
+    assert res.shape == (n, D) and np.isfinite(res).all()
+    with pytest.raises(ValueError):
+        gra.create_graphem(adj, n_components=D, backend="hip", verbose=False, knn_method="ivf", knn_distance="cdist")
+    with pytest.raises(ValueError):     # whole-graph engines only
+        _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_method="ivf", partition=(0, n // 2, 0, len(edges) // 2))
