@@ -482,11 +482,13 @@ gh_status gh_ivf_alloc(gh_engine *h) {
     v->M = M;
     // lists: about sqrt(M) / 2, a multiple of 64, at least 64 members on average (the assignment costs M * C score
     // evaluations: 4 M midpoints, 1984 lists 520 us, 1024 lists 270 us, and the same recall for the same scan work);
-    // probes: a sixteenth of them unless told otherwise (4 M midpoints: recall 0.992 in 16 dimensions, > 0.999 in 6)
+    // probes unless told otherwise: a sixteenth of the lists for more than 8 components (4 M midpoints, 1024 lists: recall
+    // 0.989 - 0.992 in 16 dimensions), a thirty-second for 5 - 8 and a sixty-fourth below (6 components: 8 of 1024 lists 0.995,
+    // 16 of 1984 0.999, 32 of 1984 1.0000; 4 components: 8 of 1984 0.997)
     int64_t C = h->prm.ivf_lists > 0 ? h->prm.ivf_lists : (int64_t)std::llround(std::sqrt((double)M) / 2.0);
     C = std::min<int64_t>(C, M / 64);
     C = std::max<int64_t>(64, std::min<int64_t>(GH_IVF_MAX_LISTS, (C + 32) / 64 * 64));
-    int64_t P = h->prm.ivf_probes > 0 ? h->prm.ivf_probes : C / 16;
+    int64_t P = h->prm.ivf_probes > 0 ? h->prm.ivf_probes : C / (h->D > 8 ? 16 : h->D > 4 ? 32 : 64);
     P = std::max<int64_t>(1, std::min<int64_t>(P, C));
     v->C = (int)C;
     v->P = (int)P;

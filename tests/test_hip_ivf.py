@@ -6,7 +6,7 @@ of the lists it probes -- and exact inside them, which gives two kinds of test:
     thresholds from the nearest lists, filtered scan, selection: any member lost anywhere shows up here), for 2 to 16
     components, with outliers beyond the f16 range of the assignment's operands, with k + 1 up to 33;
   * with the engine's defaults the RECALL against the exact kernel and the effect on a step are measured and asserted with
-    the stated bounds (200 K vertices / 800 K edges: >= 0.995 of the neighbour ids in 6 components and >= 0.97 in 16 with the
+    the stated bounds (200 K vertices / 800 K edges: >= 0.99 of the neighbour ids in 6 components and >= 0.97 in 16 with the
     defaults, >= 0.99 in 16 with a seventh of the lists probed), every returned id a
     member of a probed list at its exact distance, k-th distance within a few percent of the exact one.
 Needs a real MI355X."""
@@ -77,10 +77,10 @@ def _timed_step(eng, sampled):
     return names
 
 
-@pytest.mark.parametrize("D,probes,min_recall", [(6, 0, 0.995), (16, 0, 0.97), (16, 64, 0.99)])
+@pytest.mark.parametrize("D,probes,min_recall", [(6, 0, 0.99), (16, 0, 0.97), (16, 64, 0.99)])
 def test_recall_of_the_index(D, probes, min_recall):
-    """200 K vertices / 800 K edges, engine defaults (448 lists, 28 probed) and, for the 16-component cloud, a seventh of the
-    lists: recall of the neighbour ids against the exact kernel (measured 0.9999 / 0.979 / see the printed line), and what a
+    """200 K vertices / 800 K edges, engine defaults (448 lists; 14 probed in 6 components, 28 in 16) and, for the 16-component cloud,
+    a seventh of the lists: recall of the neighbour ids against the exact kernel (see the printed lines), and what a
     returned row is -- ids of probed members at their exact distances, ascending, no duplicates."""
     from graphem_rapids_amd import _native
     n, k, S = 200000, 10, 2048
@@ -90,8 +90,9 @@ def test_recall_of_the_index(D, probes, min_recall):
     sampled = rng.permutation(len(edges))[:S].astype(np.int32)
     exact = oracle.knn_midpoints(pos, edges, sampled, k, tiled=True)
     eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_method="ivf", ivf_probes=probes)
+    want = probes or (14 if D == 6 else 28)     # lists / 32 for 5 - 8 components, / 16 above
     lists, probes = eng.knn_ivf_config()
-    assert lists == 448 and probes in (28, 64)
+    assert (lists, probes) == (448, want)
     eng.set_positions(pos)
     rows = eng.knn_midpoints(sampled)
     again = eng.knn_midpoints(sampled)
