@@ -458,6 +458,184 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const float *__restrict__
     }
 }
 
+// The same tile-of-a-list x queries-of-the-list search with the pre-filter on the MATRIX pipe, 4 <= D <= 16: the wide form of
+// scan_core.h (F = C0 - 2 q.m - T <= 0 from single-piece f16 coordinates and three-piece constants, conservative; the
+// decision is taken on the exact fma chain), organised as phase B of the fused spring+scan kernel (fused.hip): each wave
+// owns 4 column blocks of 32 members whose operands stay in registers, the list's queries stream past as A operands from
+// LDS, pairs that pass are listed and decided by all threads after the group's last matrix instruction.  The fp32 tile
+// and query records stay in LDS for those exact checks.  (Packed fp32 VALU: D / 2 instructions per pair and lane.)
+template <int D, int LD>
+__global__ __launch_bounds__(256) void ivf_scan_mfma_kernel(const float *__restrict__ lmid, const uint32_t *__restrict__ lids,
+                                                            const int32_t *__restrict__ tile_list, const int32_t *__restrict__ meta,
+                                                            const int32_t *__restrict__ qstart, const int32_t *__restrict__ pair_q,
+                                                            const float *__restrict__ qt, const float *__restrict__ qscan,
+                                                            uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
+    constexpr int NT = 256, R = GH_IVF_TILE / NT, TILE = GH_IVF_TILE, NB = 2 * R;
+    constexpr int HITBUF = LD == 16 ? 256 : 512;
+    constexpr int KB = D <= 10 ? 1 : 2;
+    constexpr int QS = LD + 4, QT = LD;
+    constexpr int PENDCAP = 512;
+    __shared__ float4 tile[TILE * LD / 4];
+    __shared__ gh_h8 qa[GH_SCAN_QGROUP * KB * 2];
+    __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)];
+    __shared__ float taush[GH_SCAN_QGROUP];
+    __shared__ int qmap[GH_SCAN_QGROUP];
+    __shared__ uint64_t hkey[HITBUF];
+    __shared__ int hq[HITBUF];
+    __shared__ uint16_t badlist[TILE];
+    __shared__ uint32_t ids[TILE];
+    __shared__ uint16_t exq[GH_SCAN_QGROUP];
+    __shared__ uint32_t pend[PENDCAP];
+    __shared__ int hcount, nbad, nexq, npend;
+    const int t_idx = blockIdx.x;
+    if (t_idx >= meta[0]) return;
+    const int l = tile_list[t_idx];
+    const int q0 = qstart[l], q1 = qstart[l + 1];
+    if (q0 == q1) return;
+    float *mids = reinterpret_cast<float *>(tile);
+    if (threadIdx.x == 0) { hcount = 0; nbad = 0; nexq = 0; npend = 0; }
+    for (int j = threadIdx.x; j < TILE; j += NT) ids[j] = lids[(int64_t)t_idx * TILE + j];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(lmid) + (int64_t)t_idx * TILE * (LD / 4);
+        for (int i = threadIdx.x; i < TILE * LD / 4; i += NT) tile[i] = src[i];   // (padding rows are never read as members)
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = lane & 31, hsel = lane >> 5;
+    gh_h8 B[NB][KB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = w * (64 * R) + b * 32 + col;
+        const bool valid = ids[j] != 0xFFFFFFFFu;
+        float mv[LD];
+        gh_load_row<LD>(mids, valid ? j : 0, mv);
+        if (!gh_mfw_ref_col<D, KB>(mv, valid, hsel, B[b]) && hsel == 0) badlist[atomicAdd(&nbad, 1)] = (uint16_t)j;
+    }
+    auto park = [&](int s, int j) {  // exact decision on pair (query s of the group, member j of the tile)
+        const float *qv = reinterpret_cast<const float *>(qsh) + s * QS;   // (-2q_0 .. -2q_{D-1}, .., t)
+        float mv[LD];
+        gh_load_row<LD>(mids, j, mv);
+        float d2 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float df = -0.5f * qv[d] - mv[d];   // the record holds -2q: exact both ways
+            d2 = fmaf(df, df, d2);
+        }
+        if (d2 <= taush[s]) {
+            const uint32_t id = ids[j];
+            const int p = atomicAdd(&hcount, 1);
+            if (p < HITBUF) { hkey[p] = gh_key(d2, id); hq[p] = qmap[s]; }
+            else gh_append_candidate(cand, cnt, qmap[s], gh_key(d2, id));
+        }
+    };
+    const gh_f16x zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int qb0 = q0; qb0 < q1; qb0 += GH_SCAN_QGROUP) {
+        const int nq = min(q1 - qb0, GH_SCAN_QGROUP);
+        __syncthreads();  // the previous group's rows and lists are still being read (first group: the operands above)
+        if (qb0 > q0) {
+            const bool flush = hcount >= HITBUF / 4;
+            if (flush) gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+            __syncthreads();
+            if (threadIdx.x == 0) { nexq = 0; npend = 0; if (flush) hcount = 0; }
+            __syncthreads();
+        }
+        for (int i = threadIdx.x; i < (nq + 1) * (QS / 4); i += NT) {
+            const int s = i / (QS / 4), p = i % (QS / 4);
+            qsh[i] = s < nq ? reinterpret_cast<const float4 *>(qscan)[(int64_t)pair_q[qb0 + s] * (QS / 4) + p] : make_float4(0.f, 0.f, 0.f, -1.f);
+        }
+        {
+            const int q = threadIdx.x;   // one query per thread: its A row from the query record and the threshold
+            _Float16 row[16 * KB];
+            if (q < nq) {
+                const int sq = pair_q[qb0 + q];
+                const float4 *src = reinterpret_cast<const float4 *>(qscan) + (int64_t)sq * (QS / 4);
+                float qv[16];
+#pragma unroll
+                for (int d = 0; d < 16; ++d) qv[d] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < LD / 4; ++i) {
+                    const float4 v = src[i];
+                    qv[4 * i] = -0.5f * v.x; qv[4 * i + 1] = -0.5f * v.y; qv[4 * i + 2] = -0.5f * v.z; qv[4 * i + 3] = -0.5f * v.w;
+                }
+                const float tau = qt[(int64_t)sq * QS + QT];
+                qmap[q] = sq;
+                taush[q] = tau;
+                if (!gh_mfw_query_row<KB>(qv, tau, row)) exq[atomicAdd(&nexq, 1)] = (uint16_t)q;
+            } else {  // padding row: never passes
+#pragma unroll
+                for (int k = 0; k < 16 * KB; ++k) row[k] = (_Float16)0.0f;
+                row[gh_mfw<KB>::base + 3] = (_Float16)GH_MF_NEVER;
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * KB; ++i) {
+                gh_h8 hv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hv[e] = row[i * 8 + e];
+                qa[q * (2 * KB) + i] = hv;
+            }
+        }
+        __syncthreads();
+        const int nqb = (nq + 31) / 32;
+        for (int qb = 0; qb < nqb; ++qb) {
+            gh_h8 a[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) a[kb] = qa[((qb * 32 + col) * KB + kb) * 2 + hsel];
+            auto tile_of = [&](int b) {
+                gh_f16x f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], B[b][0], zero, 0, 0, 0);
+                if constexpr (KB == 2) f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], B[b][1], f, 0, 0, 0);
+                return f;
+            };
+            gh_f16x f = tile_of(0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                gh_f16x fn = zero;
+                if (b + 1 < NB) fn = tile_of(b + 1);   // in the matrix pipe while block b is tested
+                int mn = min(__float_as_int(f[0]), __float_as_int(f[1]));
+#pragma unroll
+                for (int i = 2; i < 16; ++i) mn = min(mn, __float_as_int(f[i]));
+                asm volatile("" : "+v"(mn));
+                if (mn <= 0) {  // rare: result row (i&3) + 8(i>>2) + 4*half, column = this lane's member
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m = __builtin_amdgcn_alignbit(m, __float_as_uint(f[i]), 31);
+                    const int j = w * (64 * R) + b * 32 + col;
+                    while (m) {
+                        const int bit = 31 - __builtin_clz(m);
+                        m &= ~(1u << bit);
+                        const int i = 15 - bit;
+                        const int s = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
+                        if (s < nq) {
+                            const int p = atomicAdd(&npend, 1);
+                            if (p < PENDCAP) pend[p] = ((uint32_t)s << 16) | (uint32_t)j;
+                            else park(s, j);   // list full: decided on the spot
+                        }
+                    }
+                }
+                f = fn;
+            }
+        }
+        __syncthreads();
+        for (int p = threadIdx.x, np = min(npend, PENDCAP); p < np; p += NT) park((int)(pend[p] >> 16), (int)(pend[p] & 0xFFFFu));
+        // outside the f16 range: exact scan of this group's listed queries over the whole tile ...
+        const int nex = nexq;
+        for (int x = 0; x < nex; ++x) {
+            const int s = exq[x];
+            for (int j = threadIdx.x; j < TILE; j += NT)
+                if (ids[j] != 0xFFFFFFFFu) park(s, j);
+        }
+        // ... and of the tile's out-of-range members against every other query of the group
+        const int nb_ = nbad;
+        for (int p = threadIdx.x; p < nb_ * nq; p += NT) {
+            const int s = p % nq;
+            const gh_h8 tv = qa[(s * KB + (gh_mfw<KB>::base + 3) / 16) * 2 + ((gh_mfw<KB>::base + 3) % 16) / 8];
+            if ((float)tv[(gh_mfw<KB>::base + 3) % 8] == GH_MF_NEVER) continue;  // a listed query: the loop above has done this pair
+            park(s, badlist[p / nq]);
+        }
+    }
+    __syncthreads();
+    gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
+}
+
 size_t ivf_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -617,14 +795,35 @@ gh_status gh_ivf_search(gh_engine *h) {
         gh_scope t(h, "ivf_scan");
         const dim3 grid((unsigned)v->max_tiles);
 #define GH_X(DD) ivf_scan_kernel<DD><<<grid, dim3(256), 0, h->stream>>>(v->lmid, v->lids, v->tile_list, v->meta, v->qstart, v->pair_q, h->d_q, h->d_qscan, h->d_cand, h->d_cnt)
-        switch (h->D) {
-            case 2: GH_X(2); break;
-            case 3: GH_X(3); break;
-            case 4: GH_X(4); break;
-            default:
-                if (h->LD == 8) GH_X(8);
-                else GH_X(16);
+#define GH_XM(DD, LL) ivf_scan_mfma_kernel<DD, LL><<<grid, dim3(256), 0, h->stream>>>(v->lmid, v->lids, v->tile_list, v->meta, v->qstart, v->pair_q, h->d_q, h->d_qscan, h->d_cand, h->d_cnt)
+        static const bool valu = getenv("GRAPHEM_HIP_IVF_VALU") != nullptr;   // A/B: the packed-fp32 filter for every dimension
+        if (h->D >= 4 && !valu) {
+            switch (h->D) {
+                case 4: GH_XM(4, 4); break;
+                case 5: GH_XM(5, 8); break;
+                case 6: GH_XM(6, 8); break;
+                case 7: GH_XM(7, 8); break;
+                case 8: GH_XM(8, 8); break;
+                case 9: GH_XM(9, 16); break;
+                case 10: GH_XM(10, 16); break;
+                case 11: GH_XM(11, 16); break;
+                case 12: GH_XM(12, 16); break;
+                case 13: GH_XM(13, 16); break;
+                case 14: GH_XM(14, 16); break;
+                case 15: GH_XM(15, 16); break;
+                default: GH_XM(16, 16); break;
+            }
+        } else {
+            switch (h->D) {
+                case 2: GH_X(2); break;
+                case 3: GH_X(3); break;
+                case 4: GH_X(4); break;
+                default:
+                    if (h->LD == 8) GH_X(8);
+                    else GH_X(16);
+            }
         }
+#undef GH_XM
 #undef GH_X
         GH_LAUNCH_CHECK();
     }
