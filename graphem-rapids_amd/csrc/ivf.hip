@@ -727,10 +727,12 @@ gh_status gh_ivf_search(gh_engine *h) {
     const int64_t M = v->M;
     const int C = v->C, P = v->P, QS = gh_qs(h->D, h->LD), S = (int)h->S;
     // members the threshold is taken from: the K-th smallest of an m-sample of the N probed members sits near rank K * N / m
-    // of them, which is what the filtered scan then lets through per query: m = N / 16 (N / 64 left the queries next to
-    // the crowded lists of a 16-dimensional cloud with more than the 16384 keys a candidate list holds), 1024 ... 8192
+    // of them, which is what the filtered scan then lets through per query: m = N / 16 above 8 components (N / 64 left the
+    // queries next to the crowded lists of a 16-dimensional cloud with more than the 16384 keys a candidate list holds), N / 64
+    // below (there the nearest lists hold the nearest members, and at 16 K queries the sample was the probe kernel's 0.55 ms);
+    // 1024 ... 8192
     const int64_t probed = (int64_t)P * (M / C);
-    const int tau_members = (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / 16));
+    const int tau_members = (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / (h->D > 8 ? 16 : 64)));
 #define GH_IVF_LD(X)                          \
     switch (h->LD) {                          \
         case 4: { X(4) } break;               \
