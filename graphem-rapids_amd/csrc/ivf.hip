@@ -34,7 +34,9 @@
 #define GH_IVF_NSUB 8
 
 struct gh_ivf {
-    int C = 0, P = 0;             // lists, probes per query
+    int C = 0, P = 0;             // lists, probes per query (exact mode: the most a query may probe before it falls back)
+    bool exact = false;           // ivf_probes < 0: every list that can hold one of the k + 1 nearest is probed (exact search)
+    uint32_t *r2 = nullptr;       // (C * NSUB * CSTRIDE) exact mode: upper bound of the squared radius of every (list, sub-counter), float bits
     int64_t M = 0;                // own midpoints
     int64_t cap_rows = 0;         // rows of the list-ordered copy: M + C * GH_IVF_TILE (every list padded to whole tiles)
     int64_t max_tiles = 0;
@@ -98,7 +100,8 @@ __global__ __launch_bounds__(256) void ivf_centroid_kernel(const float *__restri
 template <int LD>
 __global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict__ mid, int64_t M, int C, const uint4 *__restrict__ A,
                                                          const float *__restrict__ cnorm, uint32_t *__restrict__ assign,
-                                                         uint32_t *__restrict__ rank, int32_t *__restrict__ subcount) {
+                                                         uint32_t *__restrict__ rank, int32_t *__restrict__ subcount,
+                                                         uint32_t *__restrict__ r2 /* exact mode, else null */) {
     extern __shared__ __align__(16) unsigned char ivf_smem[];
     uint4 *Ash = reinterpret_cast<uint4 *>(ivf_smem);              // (C, 2)
     float *nsh = reinterpret_cast<float *>(Ash + 2 * (size_t)C);     // (C)
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict
     const int64_t base = wave * (32 * GH_IVF_MB);
     const int sc = (int)(wave & (GH_IVF_NSUB - 1));   // = ivf_sub_of(j) for this wave's members
     ivf_h8 B[GH_IVF_MB];
+    float mnorm[GH_IVF_MB];   // this lane half's share of |m|^2; +inf when a coordinate is beyond what the f16 operand can carry
 #pragma unroll
     for (int mb = 0; mb < GH_IVF_MB; ++mb) {
         const int64_t j = base + mb * 32 + col;
@@ -124,8 +128,12 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict
                 v[4 * p] = x.x; v[4 * p + 1] = x.y; v[4 * p + 2] = x.z; v[4 * p + 3] = x.w;
             }
         }
+        mnorm[mb] = 0.0f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) B[mb][d] = ivf_half(v[d]);
+        for (int d = 0; d < 8; ++d) {
+            B[mb][d] = ivf_half(v[d]);
+            mnorm[mb] = fabsf(v[d]) <= 30000.0f ? fmaf(v[d], v[d], mnorm[mb]) : INFINITY;
+        }
     }
     float best[GH_IVF_MB];
     int bestcb[GH_IVF_MB];
@@ -160,6 +168,7 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict
     for (int mb = 0; mb < GH_IVF_MB; ++mb) {
         const float ob = __shfl_xor(best[mb], 32, 64);
         const int ocb = __shfl_xor(bestcb[mb], 32, 64);
+        const float mn2 = mnorm[mb] + __shfl_xor(mnorm[mb], 32, 64);
         const int64_t j = base + mb * 32 + col;
         if (hsel == 0 && j < M) {
             const bool mine = best[mb] <= ob;
@@ -169,6 +178,20 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict
             const int l = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (mine ? 0 : 1);
             assign[j] = (uint32_t)l;
             rank[j] = (uint32_t)atomicAdd(&subcount[(l * GH_IVF_NSUB + sc) * GH_IVF_CSTRIDE], 1);
+            if (r2) {
+                // |m - c|^2 <= score + |m|^2 + what the f16 operands dropped: <= 2^-10 (|c|^2 + |m|^2) over the products, the
+                // accumulation and the four index bits far below; doubled.  A centroid or member beyond the f16 operands' clamp
+                // makes the bound infinite (the list is then probed by every query).
+                const float cn = nsh[l];
+                // (f16 subnormals: absolute 2^-25 per operand, <= 1e-6 sqrt(|c|^2 + |m|^2) over the 16 products)
+                const float up = fmaxf(bv + mn2, 0.0f) + (1.953125e-3f * (cn + mn2) + 1e-6f * sqrtf(cn + mn2)) + 1e-30f;
+                const bool fin = mn2 < INFINITY && cn <= 15000.0f * 15000.0f;   // no coordinate of -2c reached the clamp
+                // (a plain look first: the maximum only grows, a stale smaller value costs one atomic more, and after the first
+                // few thousand members almost nobody raises it -- unconditional atomics cost the kernel 150 us)
+                uint32_t *slot = &r2[(l * GH_IVF_NSUB + sc) * GH_IVF_CSTRIDE];
+                const uint32_t ub = fin ? __float_as_uint(up) : 0x7F800000u;
+                if (ub > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, ub);
+            }
         }
     }
 }
@@ -278,19 +301,35 @@ __device__ __forceinline__ uint64_t ivf_wave_min_u64(uint64_t v) {
 }
 
 // One wave per query, 16 queries per workgroup: distances to the C centroids (NV per lane) from the f16 operand table
-// staged in LDS -- |c|^2 - 2 c.q + |q|^2 with c to 11 bits: the ORDER of the lists is all that is needed --, the P
-// nearest lists -> pairs, and the group minima (exact distances) of the nearest list(s) the threshold is taken from.
-template <int LD, int NV>
+// staged in LDS -- |c|^2 - 2 c.q + |q|^2 with c to 11 bits --, the lists to probe -> pairs, and the group minima (exact
+// distances) of a sample of the nearest lists' members, from which the threshold is taken.
+//   EXACT = false: the P lists with the smallest centroid distance (the ORDER of the lists is all that is needed).
+//   EXACT = true:  every list that can hold one of the K nearest: with tau >= the K-th smallest distance (the same
+//                  K-th smallest of the group minima the threshold kernel extracts), a member x with |q - x|^2 <= tau of a
+//                  list with centroid c and radius R >= |x - c| has |q - c| <= sqrt(tau) + R; the centroid distance enters
+//                  with its f16 error subtracted.  A query that would probe more than P lists is handed to the exhaustive
+//                  search of the selection kernel (its candidate counter is pushed past the capacity).
+template <int LD, int NV, bool EXACT>
 __global__ __launch_bounds__(1024) void ivf_probe_kernel(const float *__restrict__ qt, int QS, int S, int D, const uint4 *__restrict__ A,
-                                                         const float *__restrict__ cnorm, int C, int P, const int32_t *__restrict__ lstart,
+                                                         const float *__restrict__ cnorm, int C, int P, int K, const int32_t *__restrict__ lstart,
                                                          const int32_t *__restrict__ lcount, const float *__restrict__ lmid, int tau_members,
-                                                         uint32_t *__restrict__ pair_l, uint32_t *__restrict__ pair_slot,
-                                                         int32_t *__restrict__ lqcount, uint32_t *__restrict__ gmin) {
+                                                         const uint32_t *__restrict__ r2, uint32_t *__restrict__ pair_l,
+                                                         uint32_t *__restrict__ pair_slot, int32_t *__restrict__ lqcount,
+                                                         uint32_t *__restrict__ gmin, int32_t *__restrict__ cnt) {
     extern __shared__ __align__(16) unsigned char ivf_smem[];
     uint4 *Ash = reinterpret_cast<uint4 *>(ivf_smem);              // (C, 2)
     float *nsh = reinterpret_cast<float *>(Ash + 2 * (size_t)C);     // (C)
+    float *rsh = nsh + C;                                            // (C) list radii (EXACT)
     for (int i = threadIdx.x; i < 2 * C; i += 1024) Ash[i] = A[i];
-    for (int i = threadIdx.x; i < C; i += 1024) nsh[i] = cnorm[i];
+    for (int i = threadIdx.x; i < C; i += 1024) {
+        nsh[i] = cnorm[i];
+        if constexpr (EXACT) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int u = 0; u < GH_IVF_NSUB; ++u) m = max(m, r2[(i * GH_IVF_NSUB + u) * GH_IVF_CSTRIDE]);
+            rsh[i] = sqrtf(__uint_as_float(m)) * 1.00001f;
+        }
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int qi = blockIdx.x * 16 + (threadIdx.x >> 6);
@@ -319,41 +358,46 @@ __global__ __launch_bounds__(1024) void ivf_probe_kernel(const float *__restrict
             v[j] = __float_as_uint(fmaxf(acc, 0.0f));
         }
     }
-    // the P-th smallest centroid distance, bit by bit from the top (as gh_tau_kth).  All 31 bits: in 16 dimensions the
-    // centroid distances of a query crowd together, and a band of 2^-8 around the P-th held a dozen lists more than P,
-    // of which the first P in LIST order were taken -- not the nearest
-    uint32_t prefix = 0;
-    for (int bit = 30; bit >= 0; --bit) {
-        const uint32_t t = prefix | (1u << bit);
-        int below = 0;
+    uint32_t took = 0;   // bit j: this lane's list j * 64 + lane is one the threshold sample may come from
+    if constexpr (!EXACT) {
+        // the P-th smallest centroid distance, bit by bit from the top (as gh_tau_kth).  All 31 bits: in 16 dimensions the
+        // centroid distances of a query crowd together, and a band of 2^-8 around the P-th held a dozen lists more than P,
+        // of which the first P in LIST order were taken -- not the nearest
+        uint32_t prefix = 0;
+        for (int bit = 30; bit >= 0; --bit) {
+            const uint32_t t = prefix | (1u << bit);
+            int below = 0;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) below += __popcll(__ballot(v[j] < t));
-        if (below < P) prefix = t;
-    }
-    const uint32_t thr = prefix;
-    int base = 0;
-    uint32_t took = 0;   // bit j: this lane's list j * 64 + lane is probed (the band around the P-th value can hold more than P)
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const bool in = v[j] <= thr && j * 64 + lane < C;
-        const unsigned long long b = __ballot(in);
-        const int r = base + __popcll(b & ((1ull << lane) - 1ull));
-        if (in && r < P) {
-            took |= 1u << j;
-            const int l = j * 64 + lane;
-            pair_l[(int64_t)qi * P + r] = (uint32_t)l;
-            pair_slot[(int64_t)qi * P + r] = (uint32_t)atomicAdd(&lqcount[l * GH_IVF_CSTRIDE], 1);
+            for (int j = 0; j < NV; ++j) below += __popcll(__ballot(v[j] < t));
+            if (below < P) prefix = t;
         }
-        base += __popcll(b);
+        const uint32_t thr = prefix;
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool in = v[j] <= thr && j * 64 + lane < C;
+            const unsigned long long b = __ballot(in);
+            const int r = base + __popcll(b & ((1ull << lane) - 1ull));
+            if (in && r < P) {
+                took |= 1u << j;
+                const int l = j * 64 + lane;
+                pair_l[(int64_t)qi * P + r] = (uint32_t)l;
+                pair_slot[(int64_t)qi * P + r] = (uint32_t)atomicAdd(&lqcount[l * GH_IVF_CSTRIDE], 1);
+            }
+            base += __popcll(b);
+        }
+        for (int r = base + lane; r < P; r += 64) pair_l[(int64_t)qi * P + r] = 0xFFFFFFFFu;   // fewer than P lists in all
+    } else {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) took |= (j * 64 + lane < C) ? 1u << j : 0u;
     }
-    for (int r = base + lane; r < P; r += 64) pair_l[(int64_t)qi * P + r] = 0xFFFFFFFFu;   // fewer than P lists in all
-    // group minima over the nearest lists, nearest first, until tau_members members have been seen
+    // group minima over the nearest of those lists, nearest first, until tau_members members have been seen
     constexpr int NG = GH_IVF_GROUPS / 64;
     float gm[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) gm[g] = INFINITY;
     int seen = 0;
-    for (int round = 0; round < P && seen < tau_members; ++round) {
+    for (int round = 0; round < C && seen < tau_members; ++round) {
         uint64_t mine = ~0ull;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -361,7 +405,7 @@ __global__ __launch_bounds__(1024) void ivf_probe_kernel(const float *__restrict
             mine = key < mine ? key : mine;
         }
         const uint64_t win = ivf_wave_min_u64(mine);
-        if (win == ~0ull) break;   // only lists this query probes
+        if (win == ~0ull) break;   // no list left
         const int l = (int)(uint32_t)win;
 #pragma unroll
         for (int j = 0; j < NV; ++j) took &= (j * 64 + lane == l) ? ~(1u << j) : ~0u;
@@ -385,6 +429,78 @@ __global__ __launch_bounds__(1024) void ivf_probe_kernel(const float *__restrict
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) gmin[(int64_t)qi * GH_IVF_GROUPS + g * 64 + lane] = __float_as_uint(gm[g]);
+    if constexpr (EXACT) {
+        // tau = the K-th smallest of the group minima as a multiset: what knn_tau_kernel will extract from gmin
+        uint32_t prefix = 0;
+        for (int bit = 30; bit >= 0; --bit) {
+            const uint32_t t = prefix | (1u << bit);
+            int below = 0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) below += __popcll(__ballot(__float_as_uint(gm[g]) < t));
+            if (below < K) prefix = t;
+        }
+        const float st = sqrtf(__uint_as_float(prefix)) * 1.00001f;   // inf when the sample held fewer than K members
+        // Second bound, from the assignment itself: a member x is filed under the centroid with the smallest (f16) score, so
+        // |x - c_l|^2 <= |x - c*|^2 + e for ANY other centroid c* -- take the one nearest to q, at distance <= dstar -- and with
+        // |q - x| <= r:  |q - c_l| <= r + |x - c_l| <= r + sqrt((r + dstar)^2 + e_l).  It does not know the list's radius, which
+        // one far-out member of a list at the rim of the cloud makes several times the list's typical size.
+        // e_l: what two f16 scores can differ from the truth, <= 2^-10 (|c|^2 + |m|^2) each, with |m| <= |q| + r; doubled.
+        uint64_t nearest = ~0ull;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = j * 64 + lane;
+            const bool ok = c < C && nsh[c < C ? c : 0] <= 15000.0f * 15000.0f;   // its operand row is the centroid, not a clamp
+            const uint64_t key = ok ? ((uint64_t)v[j] << 32) | (uint32_t)c : ~0ull;
+            nearest = key < nearest ? key : nearest;
+        }
+        nearest = ivf_wave_min_u64(nearest);
+        float dstar = INFINITY, cstar = 0.0f;
+        if (nearest != ~0ull) {
+            cstar = nsh[(uint32_t)nearest];
+            const float a2 = __uint_as_float((uint32_t)(nearest >> 32));
+            dstar = sqrtf(a2 + (9.765625e-4f * (cstar + qn) + 1e-6f * sqrtf(cstar + qn))) * 1.00001f;
+        }
+        const float mmax = sqrtf(qn) + st;   // |m| of a member within r of q
+        uint32_t in_mask = 0;
+        int total = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = j * 64 + lane;
+            bool in = false;
+            if (c < C) {
+                const float cn = nsh[c];
+                // what the f16 centroid dropped from the distance above: <= 2^-11 * 2 |c| |q| (+ subnormal and accumulation terms)
+                const float e = 9.765625e-4f * (cn + qn) + 1e-6f * sqrtf(cn + qn);
+                const float lb2 = fmaxf(__uint_as_float(v[j]) - e, 0.0f);
+                const float el = 3.90625e-3f * (cn + cstar + 2.0f * mmax * mmax) + 4e-6f * sqrtf(cn + cstar + 2.0f * mmax * mmax);
+                const float R = rsh[c];
+                const float reach = fminf(R, sqrtf((st + dstar) * (st + dstar) + el) * 1.00001f);
+                const float rhs = st + reach;
+                in = !(lb2 > rhs * rhs * 1.00001f) || !(R < INFINITY);   // (no finite radius: a clamped member or centroid -- no bound at all)
+            }
+            in_mask |= in ? 1u << j : 0u;
+            total += __popcll(__ballot(in));
+        }
+        if (total > P) {   // too many: the exhaustive search takes the query
+            if (lane == 0) atomicAdd(&cnt[(int64_t)qi * GH_CNT_STRIDE], GH_CAND_CAP + 1);
+            total = 0;
+            in_mask = 0;
+        }
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const bool in = (in_mask >> j) & 1u;
+            const unsigned long long b = __ballot(in);
+            const int r = base + __popcll(b & ((1ull << lane) - 1ull));
+            if (in) {
+                const int l = j * 64 + lane;
+                pair_l[(int64_t)qi * P + r] = (uint32_t)l;
+                pair_slot[(int64_t)qi * P + r] = (uint32_t)atomicAdd(&lqcount[l * GH_IVF_CSTRIDE], 1);
+            }
+            base += __popcll(b);
+        }
+        for (int r = base + lane; r < P; r += 64) pair_l[(int64_t)qi * P + r] = 0xFFFFFFFFu;
+    }
 }
 
 __global__ __launch_bounds__(256) void ivf_pair_scatter_kernel(const uint32_t *__restrict__ pair_l, const uint32_t *__restrict__ pair_slot,
@@ -668,6 +784,8 @@ gh_status gh_ivf_alloc(gh_engine *h) {
     C = std::max<int64_t>(64, std::min<int64_t>(GH_IVF_MAX_LISTS, (C + 32) / 64 * 64));
     int64_t P = h->prm.ivf_probes > 0 ? h->prm.ivf_probes : C / (h->D > 8 ? 16 : h->D > 4 ? 32 : 64);
     P = std::max<int64_t>(1, std::min<int64_t>(P, C));
+    v->exact = h->prm.ivf_probes < 0;
+    if (v->exact) P = std::min<int64_t>(C, std::max<int64_t>(64, C / 4));   // a query that needs more goes to the exhaustive search
     v->C = (int)C;
     v->P = (int)P;
     v->cap_rows = M + C * GH_IVF_TILE;
@@ -676,7 +794,7 @@ gh_status gh_ivf_alloc(gh_engine *h) {
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += ivf_align(bytes); return o; };
     const size_t o_cent = take(4 * C * LD), o_A = take(32 * C), o_cn = take(4 * C), o_as = take(4 * M), o_rk = take(4 * M),
-                 o_sc = take(4 * C * GH_IVF_NSUB * GH_IVF_CSTRIDE), o_ss = take(4 * C * GH_IVF_NSUB), o_lc = take(4 * C), o_ls = take(4 * (C + 1)), o_tl = take(4 * v->max_tiles), o_me = take(16),
+                 o_sc = take(4 * C * GH_IVF_NSUB * GH_IVF_CSTRIDE), o_r2 = take(v->exact ? 4 * C * GH_IVF_NSUB * GH_IVF_CSTRIDE : 16), o_ss = take(4 * C * GH_IVF_NSUB), o_lc = take(4 * C), o_ls = take(4 * (C + 1)), o_tl = take(4 * v->max_tiles), o_me = take(16),
                  o_lm = take(4 * v->cap_rows * LD), o_li = take(4 * v->cap_rows), o_lq = take(4 * C * GH_IVF_CSTRIDE), o_qs = take(4 * (C + 1)),
                  o_pl = take(4 * S * P), o_ps = take(4 * S * P), o_pq = take(4 * S * P);
     if (hipMalloc(reinterpret_cast<void **>(&v->blob), off) != hipSuccess) {
@@ -691,6 +809,7 @@ gh_status gh_ivf_alloc(gh_engine *h) {
     v->assign = reinterpret_cast<uint32_t *>(b + o_as);
     v->rank = reinterpret_cast<uint32_t *>(b + o_rk);
     v->subcount = reinterpret_cast<int32_t *>(b + o_sc);
+    v->r2 = v->exact ? reinterpret_cast<uint32_t *>(b + o_r2) : nullptr;
     v->substart = reinterpret_cast<int32_t *>(b + o_ss);
     v->lcount = reinterpret_cast<int32_t *>(b + o_lc);
     v->lstart = reinterpret_cast<int32_t *>(b + o_ls);
@@ -732,7 +851,7 @@ gh_status gh_ivf_search(gh_engine *h) {
     // below (there the nearest lists hold the nearest members, and at 16 K queries the sample was the probe kernel's 0.55 ms);
     // 1024 ... 8192
     const int64_t probed = (int64_t)P * (M / C);
-    const int tau_members = (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / (h->D > 8 ? 16 : 64)));
+    const int tau_members = v->exact ? std::max(4096, 16 * h->Ksel) /* a tight threshold keeps the ball small */ : (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / (h->D > 8 ? 16 : 64)));
 #define GH_IVF_LD(X)                          \
     switch (h->LD) {                          \
         case 4: { X(4) } break;               \
@@ -744,6 +863,7 @@ gh_status gh_ivf_search(gh_engine *h) {
         GH_HIP(hipMemsetAsync(v->lids, 0xFF, sizeof(uint32_t) * (size_t)v->cap_rows, h->stream));
         GH_HIP(hipMemsetAsync(v->subcount, 0, sizeof(int32_t) * (size_t)C * GH_IVF_NSUB * GH_IVF_CSTRIDE, h->stream));
         GH_HIP(hipMemsetAsync(v->lqcount, 0, sizeof(int32_t) * (size_t)C * GH_IVF_CSTRIDE, h->stream));
+        if (v->exact) GH_HIP(hipMemsetAsync(v->r2, 0, sizeof(uint32_t) * (size_t)C * GH_IVF_NSUB * GH_IVF_CSTRIDE, h->stream));
 #define GH_X(L) ivf_centroid_kernel<L><<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, M, C, v->cent, v->A, v->cnorm);
         GH_IVF_LD(GH_X)
 #undef GH_X
@@ -755,7 +875,7 @@ gh_status gh_ivf_search(gh_engine *h) {
         const size_t lds = (size_t)C * 36;
 #define GH_X(L)                                                                                                                                  \
     if (lds > 48 * 1024) GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_assign_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    ivf_assign_kernel<L><<<dim3(ablocks), dim3(256), lds, h->stream>>>(h->d_mid, M, C, v->A, v->cnorm, v->assign, v->rank, v->subcount);
+    ivf_assign_kernel<L><<<dim3(ablocks), dim3(256), lds, h->stream>>>(h->d_mid, M, C, v->A, v->cnorm, v->assign, v->rank, v->subcount, v->r2);
         GH_IVF_LD(GH_X)
 #undef GH_X
         GH_LAUNCH_CHECK();
@@ -773,19 +893,24 @@ gh_status gh_ivf_search(gh_engine *h) {
         gh_scope t(h, "ivf_probe");
         const unsigned pb = (unsigned)((S + 15) / 16);
         const int nv = (C + 63) / 64;
-        const size_t lds = (size_t)C * 36;
-#define GH_PROBE(L, NVv)                                                                                                                              \
+        const size_t lds = (size_t)C * 40;
+#define GH_PROBE2(L, NVv, EX)                                                                                                                         \
     {                                                                                                                                                 \
-        if (lds > 48 * 1024) GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_probe_kernel<L, NVv>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        ivf_probe_kernel<L, NVv><<<dim3(pb), dim3(1024), lds, h->stream>>>(h->d_q, QS, S, h->D, v->A, v->cnorm, C, P, v->lstart, v->lcount, v->lmid, tau_members, \
-                                                                          v->pair_l, v->pair_slot, v->lqcount, reinterpret_cast<uint32_t *>(h->d_gmin)); \
+        if (lds > 48 * 1024) GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_probe_kernel<L, NVv, EX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        ivf_probe_kernel<L, NVv, EX><<<dim3(pb), dim3(1024), lds, h->stream>>>(h->d_q, QS, S, h->D, v->A, v->cnorm, C, P, h->Ksel, v->lstart, v->lcount, v->lmid, \
+                                                                              tau_members, v->r2, v->pair_l, v->pair_slot, v->lqcount,                \
+                                                                              reinterpret_cast<uint32_t *>(h->d_gmin), h->d_cnt);                    \
     }
+#define GH_PROBE(L, NVv)                      \
+    if (v->exact) GH_PROBE2(L, NVv, true)     \
+    else GH_PROBE2(L, NVv, false)
 #define GH_X(L)                               \
-    if (nv <= 8) GH_PROBE(L, 8)               \
-    else if (nv <= 16) GH_PROBE(L, 16)        \
-    else GH_PROBE(L, 32)
+    if (nv <= 8) { GH_PROBE(L, 8) }           \
+    else if (nv <= 16) { GH_PROBE(L, 16) }    \
+    else { GH_PROBE(L, 32) }
         GH_IVF_LD(GH_X)
 #undef GH_X
+#undef GH_PROBE2
 #undef GH_PROBE
         ivf_query_layout_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(v->lqcount, C, v->qstart);
         const int64_t npairs = (int64_t)S * P;

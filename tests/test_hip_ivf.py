@@ -68,6 +68,41 @@ def test_probing_every_list_gives_the_exact_rows(n, D, k, S, state):
     eng.close()
 
 
+@pytest.mark.parametrize("n,D,k,S,state", [
+    (60000, 2, 10, 1024, "layout"), (60000, 3, 10, 2048, "layout"), (60000, 4, 15, 1024, "layout"),
+    (60000, 6, 10, 1024, "layout"), (60000, 8, 32, 512, "layout"), (60000, 3, 10, 512, "start"),
+    (60000, 6, 10, 300, "outliers"), (40000, 16, 10, 256, "layout"),
+])
+def test_exact_mode_returns_the_exact_rows(n, D, k, S, state):
+    """ivf_probes < 0: a query probes every list that can hold one of its k + 1 nearest (centroid distance <= sqrt(tau) +
+    list radius, f16 errors on the safe side), so the rows are the exact rows -- whatever the lists look like; queries that
+    would probe more than a quarter of the lists (16 components: nearly all of them) go to the exhaustive search."""
+    from graphem_rapids_amd import _native
+    edges = _graph(n, 8, seed=8)
+    rng = np.random.default_rng(12)
+    if state == "layout":
+        pos = _layout(n, D, edges, k, S)
+    else:
+        pos = rng.standard_normal((n, D)).astype(np.float32) * np.float32(0.1 if state == "start" else 1.0)
+    if state == "outliers":
+        far = rng.permutation(n)[:50]
+        pos[far] *= np.float32(1e5)
+    sampled = rng.permutation(len(edges))[:S].astype(np.int32)
+    ref = oracle.knn_midpoints(pos, edges, sampled, k, tiled=True)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_method="ivf", ivf_probes=-1)
+    eng.set_positions(pos)
+    rows = eng.knn_midpoints(sampled)
+    _, final, fallback = eng.knn_last_counts()
+    print(f"\nexact ivf D={D} {state}: lists, cap = {eng.knn_ivf_config()}, queries sent to the exhaustive search {int(fallback.sum())} of {S}")
+    assert np.array_equal(rows, ref)
+    if D <= 4 and state == "layout":   # (6 components, 256 lists: a fifth of the queries reach more than 64 lists)
+        assert fallback.sum() <= S // 20
+    eng.set_positions(pos)
+    eng.step(sampled)
+    assert np.abs(eng.get_positions() - oracle.step(pos, edges, sampled, k)).max() <= 1e-4
+    eng.close()
+
+
 def _timed_step(eng, sampled):
     eng.timing_enable(True)
     eng.step(sampled)

@@ -1,4 +1,4 @@
-"""knn_method='ivf' against the exact scan on a bench workload: recall of the neighbour rows, distance ratio, time per
+"""knn_method='ivf' (--probes -1: its exact mode) against the exact scan on a bench workload: recall of the neighbour rows, distance ratio, time per
 iteration (whole steps, host-timed over `iters` iterations of a device-sampled run) and the per-kernel table.
 
     python tools/ivf_probe.py rr1m --dim 16 --S 4096 --probes 0,32,64,128 [--lists 0] [--iters 20] [--warm 10]
