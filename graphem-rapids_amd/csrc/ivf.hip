@@ -785,7 +785,9 @@ gh_status gh_ivf_alloc(gh_engine *h) {
     int64_t P = h->prm.ivf_probes > 0 ? h->prm.ivf_probes : C / (h->D > 8 ? 16 : h->D > 4 ? 32 : 64);
     P = std::max<int64_t>(1, std::min<int64_t>(P, C));
     v->exact = h->prm.ivf_probes < 0;
-    if (v->exact) P = std::min<int64_t>(C, std::max<int64_t>(64, C / 4));   // a query that needs more goes to the exhaustive search
+    // exact mode: room for every list (a query far out, or many components: the ball reaches most of them -- it then costs
+    // what a brute-force scan costs, not the single-workgroup exhaustive search), within 1 GiB per pair array
+    if (v->exact) P = std::min<int64_t>(C, std::max<int64_t>(64, ((int64_t)1 << 28) / std::max<int64_t>(1, h->S)));
     v->C = (int)C;
     v->P = (int)P;
     v->cap_rows = M + C * GH_IVF_TILE;

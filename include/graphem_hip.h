@@ -50,7 +50,8 @@ typedef struct {
     int32_t knn_method;   /* GH_KNN_AUTO / _SCAN / _GRID / _IVF: how the KNN of the sampled midpoints is searched */
     int32_t knn_distance; /* GH_DIST_EXACT / GH_DIST_CDIST: which distance ranks the neighbours (below) */
     int32_t ivf_lists;    /* GH_KNN_IVF: inverted lists (0: about sqrt(own edges) / 2; always a multiple of 64 in 64 ... 2048) */
-    int32_t ivf_probes;   /* GH_KNN_IVF: lists a query searches (0: lists / 16 for more than 8 components, / 32 for 5 - 8, / 64 below) */
+    int32_t ivf_probes;   /* GH_KNN_IVF: lists a query searches (0: lists / 16 for more than 8 components, / 32 for 5 - 8, / 64 below;
+                             < 0: exact mode, every list that can hold a neighbour) */
 } gh_params;
 
 /* Distance the KNN ranks on (pt.py:543-593).
@@ -84,7 +85,15 @@ typedef struct {
  *                under an unprobed list is missed.  Measured on a million vertices / 4 M edges, 4096 queries, defaults
  *                (1024 lists, 64 probes): recall 0.992 in 16 dimensions (2.0 ms per iteration against 2.9 for SCAN), > 0.999
  *                in 6 (0.9 against 1.7); pays from a few thousand queries on, never chosen by AUTO.
- *   GH_KNN_AUTO  SCAN, or GRID when n_components <= 3 and sample_size >= 12288 (exact methods only). */
+ *                ivf_probes < 0 selects its EXACT mode: a query probes every list that can hold one of its k+1 nearest -- with
+ *                tau >= the (k+1)-th smallest distance, the lists whose centroid lies within sqrt(tau) + min(list radius,
+ *                sqrt(tau) + distance to the query's nearest centroid) -- and the rows are those of SCAN, id for id.  A few
+ *                lists per query up to 4 components, a few dozen at 6, most of them beyond 8 (then it costs a scan plus the
+ *                index).  rr1m, SCAN / exact IVF us per iteration: D = 3 S = 4096 1190 / 750, 16384 4182 / 1320 (GRID 2220);
+ *                D = 4 S = 16384 4682 / 1201; D = 6 S = 4096 1681 / 998, 16384 5630 / 1853.
+ *   GH_KNN_AUTO  exact methods only: whole-graph engines with 2-6 components, GH_DIST_EXACT and thousands of queries (<= 4
+ *                components: sample_size >= 4096 and E >= 262144; 5-6: >= 8192 and E >= 1000000) take IVF in its exact mode;
+ *                else GRID when n_components <= 3 and sample_size >= 12288; else SCAN. */
 #define GH_KNN_AUTO 0
 #define GH_KNN_SCAN 1
 #define GH_KNN_GRID 2

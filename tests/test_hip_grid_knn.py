@@ -107,8 +107,9 @@ def test_grid_knn_at_16_components_on_the_snap_shape(monkeypatch):
 
 def test_grid_knn_on_row_partitions_and_auto_choice():
     """The grid indexes the OWN edges of a rank, like the scan: three row-partitioned engines in the native loop
-    (loopback collectives, one thread each) with knn_method='grid' must reproduce the single engine; and AUTO picks the
-    grid from 12288 sampled midpoints on."""
+    (loopback collectives, one thread each) with knn_method='grid' must reproduce the single engine; and AUTO picks an
+    exact sub-quadratic search from thousands of sampled midpoints on (whole graph: the inverted file in its exact mode;
+    a partitioned engine: the grid)."""
     import threading
     from graphem_rapids_amd import _native
     from graphem_rapids_amd.distributed import partition_rows
@@ -162,8 +163,16 @@ def test_grid_knn_on_row_partitions_and_auto_choice():
     big.timing_enable(True)
     big.run(1)
     big.sync()
-    assert "grid_build" in big.timings()
+    assert "ivf_scan" in big.timings() and big.knn_ivf_config() == (320, 320)     # exact mode: room for every list
     big.close()
+    chunk, lo, hi = partition_rows(n, 2, 0)
+    part = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, 16384, seed=1, partition=(lo, hi, 0, 0, _native.EDGES_HASHED))
+    part.set_positions(pos)
+    part.timing_enable(True)
+    part.step_begin(rng.permutation(len(edges))[:16384].astype(np.int32))
+    part.sync()
+    assert "grid_build" in part.timings()
+    part.close()
     small = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, 256, seed=1)
     small.set_positions(pos)
     small.timing_enable(True)
