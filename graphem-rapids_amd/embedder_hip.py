@@ -66,14 +66,14 @@ class GraphEmbedderHIP:
             'device' uses the engine's on-GPU sampler (no host work in the loop);
             'auto' = 'torch' up to 2**20 edges, 'device' above.
         knn_method : 'scan' (exact filtered brute-force scan fused with the spring phase), 'grid' (n_components <= 3:
-            exact search through a grid over the midpoints rebuilt every iteration -- sub-quadratic, pays from
-            several thousand sampled midpoints on; the counterpart of the reference's cuVS indexes,
-            embedder_cuvs.py:255-313; with more components the scan is taken), or 'auto' = 'grid' when
-            n_components <= 3 and sample_size >= 12288.  'ivf': an inverted-file search rebuilt every iteration, any
-            n_components <= 16 -- APPROXIMATE like the reference's cuVS IVF-Flat index (embedder_cuvs.py:255-313): a
-            query sees the `ivf_probes` of `ivf_lists` lists nearest to it (0 = engine defaults: about sqrt(E) lists, an
-            eighth of them probed) and gets the exact k + 1 nearest among their members; pays from a few thousand
-            sampled midpoints on.  Not available with knn_distance='cdist' (the parity mode is exact).
+            exact search through a grid over the midpoints rebuilt every iteration), 'ivf' (n_components <= 16: an
+            inverted-file index rebuilt every iteration, the counterpart of the reference's cuVS IVF-Flat,
+            embedder_cuvs.py:255-313 -- `ivf_lists` centroids, every midpoint filed under the nearest; with
+            `ivf_probes` > 0 (or 0 = engine default) a query sees that many lists and gets the exact k + 1 nearest among
+            their members: APPROXIMATE; with `ivf_probes` < 0 it sees every list that can hold a neighbour: EXACT, the
+            rows of 'scan'), or 'auto' = exact methods only: the exact inverted file for 2-8 components, >= 262144 edges
+            and thousands of sampled midpoints (sample_size >= 4096 up to 4 components, >= 8192 for 5-8), else 'grid' when n_components <= 3 and sample_size >= 12288, else 'scan'.  The sub-quadratic searches pay
+            from a few thousand sampled midpoints on.  'ivf' is not available with knn_distance='cdist'.
         knn_distance : 'cdist' ranks the neighbours on the value torch.cdist gives (ATen's matmul form, fp32) and orders
             equal values as torch.topk does, i.e. the neighbour ids of the reference's PyTorch-CPU backend row for row
             (pt.py:580-583); 'exact' ranks on the exact-difference squared distance, ties on the smaller id (what the

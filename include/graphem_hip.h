@@ -89,11 +89,11 @@ typedef struct {
  *                tau >= the (k+1)-th smallest distance, the lists whose centroid lies within sqrt(tau) + min(list radius,
  *                sqrt(tau) + distance to the query's nearest centroid) -- and the rows are those of SCAN, id for id.  A few
  *                lists per query up to 4 components, a few dozen at 6, most of them beyond 8 (then it costs a scan plus the
- *                index).  rr1m, SCAN / exact IVF us per iteration: D = 3 S = 4096 1190 / 750, 16384 4182 / 1320 (GRID 2220);
- *                D = 4 S = 16384 4682 / 1201; D = 6 S = 4096 1681 / 998, 16384 5630 / 1853.
- *   GH_KNN_AUTO  exact methods only: whole-graph engines with 2-6 components, GH_DIST_EXACT and thousands of queries (<= 4
- *                components: sample_size >= 4096 and E >= 262144; 5-6: >= 8192 and E >= 1000000) take IVF in its exact mode;
- *                else GRID when n_components <= 3 and sample_size >= 12288; else SCAN. */
+ *                index).  rr1m, SCAN / exact IVF us per iteration: D = 3 S = 4096 1088 / 766, 16384 3834 / 1203 (GRID 2260);
+ *                D = 6 S = 4096 1566 / 1001, 16384 5307 / 1731; D = 8 S = 16384 5395 / 2411; D = 16 S = 16384 9088 / 6965.
+ *   GH_KNN_AUTO  exact methods only: whole-graph engines with 2-8 components, GH_DIST_EXACT, E >= 262144 and thousands of
+ *                queries (sample_size >= 4096 up to 4 components, >= 8192 for 5-8) take IVF in its exact mode; else GRID when
+ *                n_components <= 3 and sample_size >= 12288; else SCAN. */
 #define GH_KNN_AUTO 0
 #define GH_KNN_SCAN 1
 #define GH_KNN_GRID 2
