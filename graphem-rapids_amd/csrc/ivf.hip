@@ -26,17 +26,20 @@
 #define GH_IVF_MAX_LISTS 2048
 #define GH_IVF_GROUPS 256        /* group minima per query the threshold is taken from */
 #define GH_IVF_MB 4              /* member blocks of 32 a wave of the assignment holds */
-// Counters that many waves bump with returning atomics: one per 128-byte line (adjacent counters serialise on their L2
-// line, ~11 ns per returning atomic: 32 lists of 2000 members per line cost the assignment 0.7 ms), and GH_IVF_NSUB
-// counters per list taken in turn by the waves, so that a list ten times the mean (16 dimensions: lists near the centre
-// of the cloud) is not one address either.
+// Counters that many workgroups bump with returning atomics sit one per 128-byte line (adjacent counters serialise on
+// their L2 line, ~11 ns per returning atomic).  The members of a list are counted in two levels: a workgroup of the
+// assignment files its share (thousands of midpoints) under LDS counters -- the position inside the workgroup's share --
+// and reserves one range per list with ONE global atomic; 4 M device-scope returning atomics were a floor of 0.2 ms
+// under the kernel whatever the number of lists (and 0.7 ms while 32 counters shared a line).
 #define GH_IVF_CSTRIDE 32
-#define GH_IVF_NSUB 8
+#define GH_IVF_ASSIGN_WGS 3072   /* at most this many workgroups (each walks its share in steps of 512 midpoints) */
 
 struct gh_ivf {
     int C = 0, P = 0;             // lists, probes per query (exact mode: the most a query may probe before it falls back)
     bool exact = false;           // ivf_probes < 0: every list that can hold one of the k + 1 nearest is probed (exact search)
-    uint32_t *r2 = nullptr;       // (C * NSUB * CSTRIDE) exact mode: upper bound of the squared radius of every (list, sub-counter), float bits
+    uint32_t *r2 = nullptr;       // (C * CSTRIDE) exact mode: upper bound of the squared radius of every list, float bits
+    int64_t share = 0;            // midpoints per workgroup of the assignment (a multiple of 512)
+    int awgs = 0;                 // workgroups of the assignment
     int64_t M = 0;                // own midpoints
     int64_t cap_rows = 0;         // rows of the list-ordered copy: M + C * GH_IVF_TILE (every list padded to whole tiles)
     int64_t max_tiles = 0;
@@ -46,8 +49,8 @@ struct gh_ivf {
     float *cnorm = nullptr;       // (C) |c|^2
     uint32_t *assign = nullptr;   // (M) list of every own midpoint
     uint32_t *rank = nullptr;     // (M) its position inside the list
-    int32_t *subcount = nullptr;  // (C * NSUB * CSTRIDE) members counted per (list, sub-counter), one counter per line
-    int32_t *substart = nullptr;  // (C * NSUB) first row of every (list, sub-counter)
+    int32_t *count = nullptr;     // (C * CSTRIDE) members per list, one counter per line
+    int32_t *wgbase = nullptr;    // (awgs, C) first position inside the list of what workgroup w filed under it
     int32_t *lcount = nullptr;    // (C) members
     int32_t *lstart = nullptr;    // (C + 1) first row of every list in the padded order
     int32_t *tile_list = nullptr; // (max_tiles) list of every tile
@@ -96,107 +99,113 @@ __global__ __launch_bounds__(256) void ivf_centroid_kernel(const float *__restri
 // Nearest centroid of every own midpoint.  A wave holds GH_IVF_MB blocks of 32 midpoints as B operands (lane = column,
 // lane half = which 8 of the 16 coordinates) and walks the centroids 32 at a time: accumulator initialised with |c|^2,
 // one MFMA per member block, row index packed into the low 4 mantissa bits, minimum over the lane's 16 rows, running
-// best per column.  The two lane halves of a column hold different rows: combined at the end.
+// best per column.  The two lane halves of a column hold different rows: combined at the end.  A workgroup walks its
+// share of the midpoints in steps of 512 with the centroid table staged once; positions inside the lists: see
+// GH_IVF_CSTRIDE above.
 template <int LD>
-__global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict__ mid, int64_t M, int C, const uint4 *__restrict__ A,
-                                                         const float *__restrict__ cnorm, uint32_t *__restrict__ assign,
-                                                         uint32_t *__restrict__ rank, int32_t *__restrict__ subcount,
+__global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict__ mid, int64_t M, int64_t share, int C,
+                                                         const uint4 *__restrict__ A, const float *__restrict__ cnorm,
+                                                         uint32_t *__restrict__ assign, uint32_t *__restrict__ rank,
+                                                         int32_t *__restrict__ count, int32_t *__restrict__ wgbase,
                                                          uint32_t *__restrict__ r2 /* exact mode, else null */) {
     extern __shared__ __align__(16) unsigned char ivf_smem[];
     uint4 *Ash = reinterpret_cast<uint4 *>(ivf_smem);              // (C, 2)
     float *nsh = reinterpret_cast<float *>(Ash + 2 * (size_t)C);     // (C)
+    int *hist = reinterpret_cast<int *>(nsh + C);                    // (C) members this workgroup filed under the list
+    uint32_t *rmax = reinterpret_cast<uint32_t *>(hist + C);         // (C) exact mode: their radius bound
     for (int i = threadIdx.x; i < 2 * C; i += 256) Ash[i] = A[i];
-    for (int i = threadIdx.x; i < C; i += 256) nsh[i] = cnorm[i];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, hsel = lane >> 5;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + w;
-    const int64_t base = wave * (32 * GH_IVF_MB);
-    const int sc = (int)(wave & (GH_IVF_NSUB - 1));   // = ivf_sub_of(j) for this wave's members
-    ivf_h8 B[GH_IVF_MB];
-    float mnorm[GH_IVF_MB];   // this lane half's share of |m|^2; +inf when a coordinate is beyond what the f16 operand can carry
-#pragma unroll
-    for (int mb = 0; mb < GH_IVF_MB; ++mb) {
-        const int64_t j = base + mb * 32 + col;
-        float v[8];   // this lane half's 8 coordinates (coordinates past LD are 0)
-#pragma unroll
-        for (int d = 0; d < 8; ++d) v[d] = 0.0f;
-        if (j < M && hsel * 8 < LD) {
-            constexpr int NQ = LD >= 8 ? 2 : 1;
-            const float4 *src = reinterpret_cast<const float4 *>(mid + j * LD + hsel * 8);
-#pragma unroll
-            for (int p = 0; p < NQ; ++p) {
-                const float4 x = src[p];
-                v[4 * p] = x.x; v[4 * p + 1] = x.y; v[4 * p + 2] = x.z; v[4 * p + 3] = x.w;
-            }
-        }
-        mnorm[mb] = 0.0f;
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            B[mb][d] = ivf_half(v[d]);
-            mnorm[mb] = fabsf(v[d]) <= 30000.0f ? fmaf(v[d], v[d], mnorm[mb]) : INFINITY;
-        }
-    }
-    float best[GH_IVF_MB];
-    int bestcb[GH_IVF_MB];
-#pragma unroll
-    for (int mb = 0; mb < GH_IVF_MB; ++mb) { best[mb] = INFINITY; bestcb[mb] = 0; }
+    for (int i = threadIdx.x; i < C; i += 256) { nsh[i] = cnorm[i]; hist[i] = 0; rmax[i] = 0; }
     __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = lane & 31, hsel = lane >> 5;
+    const int64_t lo = (int64_t)blockIdx.x * share, hi = min(M, lo + share);
     const int ncb = C / 32;
-    for (int cb = 0; cb < ncb; ++cb) {
-        const ivf_h8 a = __builtin_bit_cast(ivf_h8, Ash[(cb * 32 + col) * 2 + hsel]);
-        ivf_f16x cinit;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 n4 = *reinterpret_cast<const float4 *>(nsh + cb * 32 + 8 * g + 4 * hsel);
-            cinit[4 * g] = n4.x; cinit[4 * g + 1] = n4.y; cinit[4 * g + 2] = n4.z; cinit[4 * g + 3] = n4.w;
-        }
-        ivf_f16x f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[0], cinit, 0, 0, 0);
+    for (int64_t step = lo; step < hi; step += 4 * 32 * GH_IVF_MB) {
+        const int64_t base = step + w * (32 * GH_IVF_MB);
+        ivf_h8 B[GH_IVF_MB];
+        float mnorm[GH_IVF_MB];   // this lane half's share of |m|^2; +inf when a coordinate is beyond what the f16 operand can carry
 #pragma unroll
         for (int mb = 0; mb < GH_IVF_MB; ++mb) {
-            ivf_f16x fn = cinit;
-            if (mb + 1 < GH_IVF_MB) fn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[mb + 1], cinit, 0, 0, 0);   // in the matrix pipe while block mb is reduced
-            float mn = INFINITY;
+            const int64_t j = base + mb * 32 + col;
+            float v[8];   // this lane half's 8 coordinates (coordinates past LD are 0)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) mn = fminf(mn, __uint_as_float((__float_as_uint(f[i]) & ~15u) | (uint32_t)i));
-            asm volatile("" : "+v"(mn));
-            const bool better = mn < best[mb];
-            best[mb] = better ? mn : best[mb];
-            bestcb[mb] = better ? cb : bestcb[mb];
-            f = fn;
+            for (int d = 0; d < 8; ++d) v[d] = 0.0f;
+            if (j < hi && hsel * 8 < LD) {
+                constexpr int NQ = LD >= 8 ? 2 : 1;
+                const float4 *src = reinterpret_cast<const float4 *>(mid + j * LD + hsel * 8);
+#pragma unroll
+                for (int p = 0; p < NQ; ++p) {
+                    const float4 x = src[p];
+                    v[4 * p] = x.x; v[4 * p + 1] = x.y; v[4 * p + 2] = x.z; v[4 * p + 3] = x.w;
+                }
+            }
+            mnorm[mb] = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                B[mb][d] = ivf_half(v[d]);
+                mnorm[mb] = fabsf(v[d]) <= 30000.0f ? fmaf(v[d], v[d], mnorm[mb]) : INFINITY;
+            }
         }
-    }
+        float best[GH_IVF_MB];
+        int bestcb[GH_IVF_MB];
 #pragma unroll
-    for (int mb = 0; mb < GH_IVF_MB; ++mb) {
-        const float ob = __shfl_xor(best[mb], 32, 64);
-        const int ocb = __shfl_xor(bestcb[mb], 32, 64);
-        const float mn2 = mnorm[mb] + __shfl_xor(mnorm[mb], 32, 64);
-        const int64_t j = base + mb * 32 + col;
-        if (hsel == 0 && j < M) {
-            const bool mine = best[mb] <= ob;
-            const float bv = mine ? best[mb] : ob;
-            const int cb = mine ? bestcb[mb] : ocb;
-            const int i = (int)(__float_as_uint(bv) & 15u);
-            const int l = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (mine ? 0 : 1);
-            assign[j] = (uint32_t)l;
-            rank[j] = (uint32_t)atomicAdd(&subcount[(l * GH_IVF_NSUB + sc) * GH_IVF_CSTRIDE], 1);
-            if (r2) {
-                // |m - c|^2 <= score + |m|^2 + what the f16 operands dropped: <= 2^-10 (|c|^2 + |m|^2) over the products, the
-                // accumulation and the four index bits far below; doubled.  A centroid or member beyond the f16 operands' clamp
-                // makes the bound infinite (the list is then probed by every query).
-                const float cn = nsh[l];
-                // (f16 subnormals: absolute 2^-25 per operand, <= 1e-6 sqrt(|c|^2 + |m|^2) over the 16 products)
-                const float up = fmaxf(bv + mn2, 0.0f) + (1.953125e-3f * (cn + mn2) + 1e-6f * sqrtf(cn + mn2)) + 1e-30f;
-                const bool fin = mn2 < INFINITY && cn <= 15000.0f * 15000.0f;   // no coordinate of -2c reached the clamp
-                // (a plain look first: the maximum only grows, a stale smaller value costs one atomic more, and after the first
-                // few thousand members almost nobody raises it -- unconditional atomics cost the kernel 150 us)
-                uint32_t *slot = &r2[(l * GH_IVF_NSUB + sc) * GH_IVF_CSTRIDE];
-                const uint32_t ub = fin ? __float_as_uint(up) : 0x7F800000u;
-                if (ub > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, ub);
+        for (int mb = 0; mb < GH_IVF_MB; ++mb) { best[mb] = INFINITY; bestcb[mb] = 0; }
+        for (int cb = 0; cb < ncb; ++cb) {
+            const ivf_h8 a = __builtin_bit_cast(ivf_h8, Ash[(cb * 32 + col) * 2 + hsel]);
+            ivf_f16x cinit;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 n4 = *reinterpret_cast<const float4 *>(nsh + cb * 32 + 8 * g + 4 * hsel);
+                cinit[4 * g] = n4.x; cinit[4 * g + 1] = n4.y; cinit[4 * g + 2] = n4.z; cinit[4 * g + 3] = n4.w;
+            }
+            ivf_f16x f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[0], cinit, 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < GH_IVF_MB; ++mb) {
+                ivf_f16x fn = cinit;
+                if (mb + 1 < GH_IVF_MB) fn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[mb + 1], cinit, 0, 0, 0);   // in the matrix pipe while block mb is reduced
+                float mn = INFINITY;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mn = fminf(mn, __uint_as_float((__float_as_uint(f[i]) & ~15u) | (uint32_t)i));
+                asm volatile("" : "+v"(mn));
+                const bool better = mn < best[mb];
+                best[mb] = better ? mn : best[mb];
+                bestcb[mb] = better ? cb : bestcb[mb];
+                f = fn;
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < GH_IVF_MB; ++mb) {
+            const float ob = __shfl_xor(best[mb], 32, 64);
+            const int ocb = __shfl_xor(bestcb[mb], 32, 64);
+            const float mn2 = mnorm[mb] + __shfl_xor(mnorm[mb], 32, 64);
+            const int64_t j = base + mb * 32 + col;
+            if (hsel == 0 && j < hi) {
+                const bool mine = best[mb] <= ob;
+                const float bv = mine ? best[mb] : ob;
+                const int cb = mine ? bestcb[mb] : ocb;
+                const int i = (int)(__float_as_uint(bv) & 15u);
+                const int l = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (mine ? 0 : 1);
+                assign[j] = (uint32_t)l;
+                rank[j] = (uint32_t)atomicAdd(&hist[l], 1);   // LDS: position inside this workgroup's share of the list
+                if (r2) {
+                    // |m - c|^2 <= score + |m|^2 + what the f16 operands dropped: <= 2^-10 (|c|^2 + |m|^2) over the products, the
+                    // accumulation and the four index bits far below; doubled.  A centroid or member beyond the f16 operands' clamp
+                    // makes the bound infinite (the list is then probed by every query).
+                    // (f16 subnormals: absolute 2^-25 per operand, <= 1e-6 sqrt(|c|^2 + |m|^2) over the 16 products)
+                    const float cn = nsh[l];
+                    const float up = fmaxf(bv + mn2, 0.0f) + (1.953125e-3f * (cn + mn2) + 1e-6f * sqrtf(cn + mn2)) + 1e-30f;
+                    const bool fin = mn2 < INFINITY && cn <= 15000.0f * 15000.0f;   // no coordinate of -2c reached the clamp
+                    atomicMax(&rmax[l], fin ? __float_as_uint(up) : 0x7F800000u);
+                }
             }
         }
     }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int n = hist[c];
+        if (n > 0) wgbase[(int64_t)blockIdx.x * C + c] = atomicAdd(&count[c * GH_IVF_CSTRIDE], n);
+        if (r2 && rmax[c] > 0) atomicMax(&r2[c * GH_IVF_CSTRIDE], rmax[c]);
+    }
 }
-
-__device__ __forceinline__ int ivf_sub_of(int64_t j) { return (int)((j / (32 * GH_IVF_MB)) & (GH_IVF_NSUB - 1)); }
 
 // Exclusive prefix over 1024 per-thread sums (one workgroup); returns what precedes this thread, *total = the sum.
 __device__ __forceinline__ int ivf_block_prefix(int sum, int *part, int *total) {
@@ -213,24 +222,18 @@ __device__ __forceinline__ int ivf_block_prefix(int sum, int *part, int *total) 
     return part[t] - sum;
 }
 
-// One workgroup: members per list from the sub-counters, every list padded to whole tiles -> lstart (C + 1), the first
-// row of every (list, sub-counter), the list of every tile, the tiles in use.
-__global__ __launch_bounds__(1024) void ivf_list_layout_kernel(const int32_t *__restrict__ subcount, int C, int32_t *__restrict__ lcount,
-                                                               int32_t *__restrict__ lstart, int32_t *__restrict__ substart,
-                                                               int32_t *__restrict__ tile_list, int32_t *__restrict__ meta) {
+// One workgroup: every list padded to whole tiles -> lstart (C + 1), lcount, the list of every tile, the tiles in use.
+__global__ __launch_bounds__(1024) void ivf_list_layout_kernel(const int32_t *__restrict__ count, int C, int32_t *__restrict__ lcount,
+                                                               int32_t *__restrict__ lstart, int32_t *__restrict__ tile_list,
+                                                               int32_t *__restrict__ meta) {
     __shared__ int part[1024];
     constexpr int PER = GH_IVF_MAX_LISTS / 1024;
     const int t = threadIdx.x;
-    int tot[PER], sub[PER][GH_IVF_NSUB], sum = 0;
+    int tot[PER], sum = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
         const int c = t * PER + i;
-        tot[i] = 0;
-#pragma unroll
-        for (int u = 0; u < GH_IVF_NSUB; ++u) {
-            sub[i][u] = c < C ? subcount[(c * GH_IVF_NSUB + u) * GH_IVF_CSTRIDE] : 0;
-            tot[i] += sub[i][u];
-        }
+        tot[i] = c < C ? count[c * GH_IVF_CSTRIDE] : 0;
         sum += (tot[i] + GH_IVF_TILE - 1) / GH_IVF_TILE * GH_IVF_TILE;
     }
     int total;
@@ -241,9 +244,6 @@ __global__ __launch_bounds__(1024) void ivf_list_layout_kernel(const int32_t *__
         if (c >= C) break;
         lstart[c] = at;
         lcount[c] = tot[i];
-        int r = at;
-#pragma unroll
-        for (int u = 0; u < GH_IVF_NSUB; ++u) { substart[c * GH_IVF_NSUB + u] = r; r += sub[i][u]; }
         const int nt = (tot[i] + GH_IVF_TILE - 1) / GH_IVF_TILE;
         for (int k = 0; k < nt; ++k) tile_list[at / GH_IVF_TILE + k] = c;
         at += nt * GH_IVF_TILE;
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(1024) void ivf_query_layout_kernel(const int32_t *_
 // Midpoints and edge ids into list order.
 template <int LD>
 __global__ __launch_bounds__(256) void ivf_scatter_kernel(const float *__restrict__ mid, int64_t M, const uint32_t *__restrict__ assign,
-                                                          const uint32_t *__restrict__ rank, const int32_t *__restrict__ substart,
+                                                          const uint32_t *__restrict__ rank, const int32_t *__restrict__ lstart,
+                                                          const int32_t *__restrict__ wgbase, int64_t share, int C,
                                                           int64_t e_lo, const int32_t *__restrict__ eids, float *__restrict__ lmid,
                                                           uint32_t *__restrict__ lids) {
     constexpr int Q = LD / 4;   // 16-byte pieces per row: consecutive threads move consecutive pieces
@@ -286,7 +287,8 @@ __global__ __launch_bounds__(256) void ivf_scatter_kernel(const float *__restric
     const int64_t j = i / Q;
     const int p = (int)(i % Q);
     if (j >= M) return;
-    const int64_t dst = (int64_t)substart[assign[j] * GH_IVF_NSUB + ivf_sub_of(j)] + rank[j];
+    const uint32_t l = assign[j];
+    const int64_t dst = (int64_t)lstart[l] + wgbase[(j / share) * C + l] + rank[j];
     reinterpret_cast<float4 *>(lmid)[dst * Q + p] = reinterpret_cast<const float4 *>(mid)[j * Q + p];
     if (p == 0) lids[dst] = eids ? (uint32_t)eids[j] : (uint32_t)(e_lo + j);
 }
@@ -324,10 +326,7 @@ __global__ __launch_bounds__(1024) void ivf_probe_kernel(const float *__restrict
     for (int i = threadIdx.x; i < C; i += 1024) {
         nsh[i] = cnorm[i];
         if constexpr (EXACT) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int u = 0; u < GH_IVF_NSUB; ++u) m = max(m, r2[(i * GH_IVF_NSUB + u) * GH_IVF_CSTRIDE]);
-            rsh[i] = sqrtf(__uint_as_float(m)) * 1.00001f;
+            rsh[i] = sqrtf(__uint_as_float(r2[i * GH_IVF_CSTRIDE])) * 1.00001f;
         }
     }
     __syncthreads();
@@ -779,7 +778,10 @@ gh_status gh_ivf_alloc(gh_engine *h) {
     // probes unless told otherwise: a sixteenth of the lists for more than 8 components (4 M midpoints, 1024 lists: recall
     // 0.989 - 0.992 in 16 dimensions), a thirty-second for 5 - 8 and a sixty-fourth below (6 components: 8 of 1024 lists 0.995,
     // 16 of 1984 0.999, 32 of 1984 1.0000; 4 components: 8 of 1984 0.997)
-    int64_t C = h->prm.ivf_lists > 0 ? h->prm.ivf_lists : (int64_t)std::llround(std::sqrt((double)M) / 2.0);
+    // default: at most 512 lists up to 4 components, 1024 above (the scan's share shrinks like S / C while the assignment grows
+    // like C: 16 M midpoints, 3 components, 16 K queries: 1984 lists 4.1 ms per iteration, 1024 2.95, 512 2.76)
+    int64_t C = h->prm.ivf_lists > 0 ? h->prm.ivf_lists
+                                     : std::min<int64_t>(h->D <= 4 ? 512 : 1024, (int64_t)std::llround(std::sqrt((double)M) / 2.0));
     C = std::min<int64_t>(C, M / 64);
     C = std::max<int64_t>(64, std::min<int64_t>(GH_IVF_MAX_LISTS, (C + 32) / 64 * 64));
     int64_t P = h->prm.ivf_probes > 0 ? h->prm.ivf_probes : C / (h->D > 8 ? 16 : h->D > 4 ? 32 : 64);
@@ -791,12 +793,14 @@ gh_status gh_ivf_alloc(gh_engine *h) {
     v->C = (int)C;
     v->P = (int)P;
     v->cap_rows = M + C * GH_IVF_TILE;
+    v->share = ((M + GH_IVF_ASSIGN_WGS - 1) / GH_IVF_ASSIGN_WGS + 511) / 512 * 512;
+    v->awgs = (int)((M + v->share - 1) / v->share);
     v->max_tiles = v->cap_rows / GH_IVF_TILE + 1;
     const size_t S = (size_t)h->S, LD = (size_t)h->LD;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += ivf_align(bytes); return o; };
     const size_t o_cent = take(4 * C * LD), o_A = take(32 * C), o_cn = take(4 * C), o_as = take(4 * M), o_rk = take(4 * M),
-                 o_sc = take(4 * C * GH_IVF_NSUB * GH_IVF_CSTRIDE), o_r2 = take(v->exact ? 4 * C * GH_IVF_NSUB * GH_IVF_CSTRIDE : 16), o_ss = take(4 * C * GH_IVF_NSUB), o_lc = take(4 * C), o_ls = take(4 * (C + 1)), o_tl = take(4 * v->max_tiles), o_me = take(16),
+                 o_sc = take(4 * C * GH_IVF_CSTRIDE), o_r2 = take(v->exact ? 4 * C * GH_IVF_CSTRIDE : 16), o_ss = take(4 * (size_t)v->awgs * C), o_lc = take(4 * C), o_ls = take(4 * (C + 1)), o_tl = take(4 * v->max_tiles), o_me = take(16),
                  o_lm = take(4 * v->cap_rows * LD), o_li = take(4 * v->cap_rows), o_lq = take(4 * C * GH_IVF_CSTRIDE), o_qs = take(4 * (C + 1)),
                  o_pl = take(4 * S * P), o_ps = take(4 * S * P), o_pq = take(4 * S * P);
     if (hipMalloc(reinterpret_cast<void **>(&v->blob), off) != hipSuccess) {
@@ -810,9 +814,9 @@ gh_status gh_ivf_alloc(gh_engine *h) {
     v->cnorm = reinterpret_cast<float *>(b + o_cn);
     v->assign = reinterpret_cast<uint32_t *>(b + o_as);
     v->rank = reinterpret_cast<uint32_t *>(b + o_rk);
-    v->subcount = reinterpret_cast<int32_t *>(b + o_sc);
+    v->count = reinterpret_cast<int32_t *>(b + o_sc);
     v->r2 = v->exact ? reinterpret_cast<uint32_t *>(b + o_r2) : nullptr;
-    v->substart = reinterpret_cast<int32_t *>(b + o_ss);
+    v->wgbase = reinterpret_cast<int32_t *>(b + o_ss);
     v->lcount = reinterpret_cast<int32_t *>(b + o_lc);
     v->lstart = reinterpret_cast<int32_t *>(b + o_ls);
     v->tile_list = reinterpret_cast<int32_t *>(b + o_tl);
@@ -863,9 +867,9 @@ gh_status gh_ivf_search(gh_engine *h) {
     {
         gh_scope t(h, "ivf_build");
         GH_HIP(hipMemsetAsync(v->lids, 0xFF, sizeof(uint32_t) * (size_t)v->cap_rows, h->stream));
-        GH_HIP(hipMemsetAsync(v->subcount, 0, sizeof(int32_t) * (size_t)C * GH_IVF_NSUB * GH_IVF_CSTRIDE, h->stream));
+        GH_HIP(hipMemsetAsync(v->count, 0, sizeof(int32_t) * (size_t)C * GH_IVF_CSTRIDE, h->stream));
         GH_HIP(hipMemsetAsync(v->lqcount, 0, sizeof(int32_t) * (size_t)C * GH_IVF_CSTRIDE, h->stream));
-        if (v->exact) GH_HIP(hipMemsetAsync(v->r2, 0, sizeof(uint32_t) * (size_t)C * GH_IVF_NSUB * GH_IVF_CSTRIDE, h->stream));
+        if (v->exact) GH_HIP(hipMemsetAsync(v->r2, 0, sizeof(uint32_t) * (size_t)C * GH_IVF_CSTRIDE, h->stream));
 #define GH_X(L) ivf_centroid_kernel<L><<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, M, C, v->cent, v->A, v->cnorm);
         GH_IVF_LD(GH_X)
 #undef GH_X
@@ -873,20 +877,19 @@ gh_status gh_ivf_search(gh_engine *h) {
     }
     {
         gh_scope t(h, "ivf_assign");
-        const unsigned ablocks = (unsigned)((M + 4 * 32 * GH_IVF_MB - 1) / (4 * 32 * GH_IVF_MB));
-        const size_t lds = (size_t)C * 36;
+        const size_t lds = (size_t)C * 44;
 #define GH_X(L)                                                                                                                                  \
     if (lds > 48 * 1024) GH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ivf_assign_kernel<L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    ivf_assign_kernel<L><<<dim3(ablocks), dim3(256), lds, h->stream>>>(h->d_mid, M, C, v->A, v->cnorm, v->assign, v->rank, v->subcount, v->r2);
+    ivf_assign_kernel<L><<<dim3((unsigned)v->awgs), dim3(256), lds, h->stream>>>(h->d_mid, M, v->share, C, v->A, v->cnorm, v->assign, v->rank, v->count, v->wgbase, v->r2);
         GH_IVF_LD(GH_X)
 #undef GH_X
         GH_LAUNCH_CHECK();
     }
     {
         gh_scope t(h, "ivf_layout");
-        ivf_list_layout_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(v->subcount, C, v->lcount, v->lstart, v->substart, v->tile_list, v->meta);
+        ivf_list_layout_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(v->count, C, v->lcount, v->lstart, v->tile_list, v->meta);
         const int Q = h->LD / 4;
-#define GH_X(L) ivf_scatter_kernel<L><<<dim3((unsigned)((M * Q + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, M, v->assign, v->rank, v->substart, h->part.edge_lo, h->d_own_eids, v->lmid, v->lids);
+#define GH_X(L) ivf_scatter_kernel<L><<<dim3((unsigned)((M * Q + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, M, v->assign, v->rank, v->lstart, v->wgbase, v->share, C, h->part.edge_lo, h->d_own_eids, v->lmid, v->lids);
         GH_IVF_LD(GH_X)
 #undef GH_X
         GH_LAUNCH_CHECK();

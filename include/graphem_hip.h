@@ -49,7 +49,8 @@ typedef struct {
     int32_t reorder;      /* internal vertex order: GH_REORDER_AUTO / _OFF / _BFS (no reference counterpart) */
     int32_t knn_method;   /* GH_KNN_AUTO / _SCAN / _GRID / _IVF: how the KNN of the sampled midpoints is searched */
     int32_t knn_distance; /* GH_DIST_EXACT / GH_DIST_CDIST: which distance ranks the neighbours (below) */
-    int32_t ivf_lists;    /* GH_KNN_IVF: inverted lists (0: about sqrt(own edges) / 2; always a multiple of 64 in 64 ... 2048) */
+    int32_t ivf_lists;    /* GH_KNN_IVF: inverted lists (0: about sqrt(own edges) / 2, at most 512 up to 4 components and 1024 above;
+                             always a multiple of 64 in 64 ... 2048) */
     int32_t ivf_probes;   /* GH_KNN_IVF: lists a query searches (0: lists / 16 for more than 8 components, / 32 for 5 - 8, / 64 below;
                              < 0: exact mode, every list that can hold a neighbour) */
 } gh_params;
