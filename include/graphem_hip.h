@@ -84,14 +84,14 @@ typedef struct {
  *                pipe), a query searches the ivf_probes lists whose centroids are nearest and gets the exact k+1 nearest
  *                AMONG THEIR MEMBERS (exact-difference distances, ties on the smaller id).  APPROXIMATE: a neighbour filed
  *                under an unprobed list is missed.  Measured on a million vertices / 4 M edges, 4096 queries, defaults
- *                (1024 lists, 64 probes): recall 0.992 in 16 dimensions (2.0 ms per iteration against 2.9 for SCAN), > 0.999
- *                in 6 (0.9 against 1.7); pays from a few thousand queries on, never chosen by AUTO.
+ *                (1024 lists; 64 / 32 probes): recall 0.992 in 16 dimensions (1.7 ms per iteration against 2.6 for SCAN), 1.0000
+ *                in 6 (1.0 against 1.5); pays from a few thousand queries on; AUTO never takes the approximate mode.
  *                ivf_probes < 0 selects its EXACT mode: a query probes every list that can hold one of its k+1 nearest -- with
  *                tau >= the (k+1)-th smallest distance, the lists whose centroid lies within sqrt(tau) + min(list radius,
  *                sqrt(tau) + distance to the query's nearest centroid) -- and the rows are those of SCAN, id for id.  A few
  *                lists per query up to 4 components, a few dozen at 6, most of them beyond 8 (then it costs a scan plus the
- *                index).  rr1m, SCAN / exact IVF us per iteration: D = 3 S = 4096 1088 / 766, 16384 3834 / 1203 (GRID 2260);
- *                D = 6 S = 4096 1566 / 1001, 16384 5307 / 1731; D = 8 S = 16384 5395 / 2411; D = 16 S = 16384 9088 / 6965.
+ *                index).  rr1m, SCAN / exact IVF us per iteration: D = 3 S = 4096 1123 / 657, 16384 4003 / 1009 (GRID 2236);
+ *                D = 6 S = 4096 1547 / 1061, 16384 5339 / 1769; D = 8 S = 16384 5386 / 2422; D = 16 S = 16384 9108 / 6960.
  *   GH_KNN_AUTO  exact methods only: whole-graph engines with 2-8 components, GH_DIST_EXACT, E >= 262144 and thousands of
  *                queries (sample_size >= 4096 up to 4 components, >= 8192 for 5-8) take IVF in its exact mode; else GRID when
  *                n_components <= 3 and sample_size >= 12288; else SCAN. */

@@ -195,3 +195,26 @@ def test_ivf_layout_run_and_public_class():
         gra.create_graphem(adj, n_components=D, backend="hip", verbose=False, knn_method="ivf", knn_distance="cdist")
     with pytest.raises(ValueError):     # whole-graph engines only
         _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_method="ivf", partition=(0, n // 2, 0, len(edges) // 2))
+
+
+def test_auto_takes_the_exact_index_only_where_it_pays():
+    """gh_params.knn_method = AUTO: whole-graph engines with 2-8 components, the exact distance, >= 262144 edges and
+    thousands of queries get the inverted file in its EXACT mode (room for every list); everything else keeps the scan
+    (or the grid)."""
+    from graphem_rapids_amd import _native
+    n = 70000
+    edges = _graph(n, 8, seed=2)          # 280 000 edges
+    def cfg(D, S, **kw):
+        eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, 10, S, **kw)
+        out = eng.knn_ivf_config()
+        eng.close()
+        return out
+    assert cfg(3, 4096) == (256, 256) and cfg(4, 4096) == (256, 256)      # sqrt(E) / 2 -> 256 lists, exact mode: all may be probed
+    assert cfg(6, 8192) == (256, 256) and cfg(8, 8192) == (256, 256)
+    assert cfg(3, 2048) == (0, 0) and cfg(6, 4096) == (0, 0) and cfg(9, 16384) == (0, 0)
+    assert cfg(3, 4096, knn_distance="cdist") == (0, 0)                    # the parity mode keeps the scan
+    assert cfg(3, 4096, knn_method="scan") == (0, 0)
+    small = _graph(20000, 8, seed=2)      # 80 000 edges
+    eng = _native.Engine(20000, 3, small, 1.0, 0.2, 0.5, 10, 4096)
+    assert eng.knn_ivf_config() == (0, 0)
+    eng.close()
