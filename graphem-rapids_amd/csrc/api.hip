@@ -138,7 +138,6 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     h->cdist = params->knn_distance == GH_DIST_CDIST;
     if (h->cdist && part) { delete h; return fail(GH_ERR_INVALID, "knn_distance = GH_DIST_CDIST needs the whole graph on one engine (no gh_partition)"); }
     if (h->cdist) h->prm.knn_method = GH_KNN_SCAN;   // the grid search knows exact distances only
-    if (h->prm.knn_method == GH_KNN_IVF && part) { delete h; return fail(GH_ERR_INVALID, "knn_method = GH_KNN_IVF needs the whole graph on one engine (no gh_partition)"); }
     h->Ksel = h->K + (h->cdist ? 1 : 0);
     if (part) h->part = *part;
     else h->part = gh_partition{0, n, 0, E, GH_EDGES_RANGE};

@@ -78,7 +78,7 @@ typedef struct {
  *                cells its threshold ball touches: sub-quadratic, pays from several thousand queries on.  (With more
  *                components the same search over the first three coordinates stays exact but does not pay -- measured
  *                50-80x slower than the scan at a million vertices -- and is refused unless GRAPHEM_HIP_GRID_WIDE is set.)
- *   GH_KNN_IVF   2 <= n_components <= 16, whole-graph engines, GH_DIST_EXACT: an inverted-file index rebuilt every iteration,
+ *   GH_KNN_IVF   2 <= n_components <= 16, GH_DIST_EXACT (a partitioned engine indexes the edges it owns): an inverted-file index rebuilt every iteration,
  *                the counterpart of the cuVS backend's IVF-Flat (embedder_cuvs.py:255-313, 384-430).  ivf_lists centroids
  *                (midpoints of evenly spaced edges), every midpoint filed under its nearest one (f16 scores on the matrix
  *                pipe), a query searches the ivf_probes lists whose centroids are nearest and gets the exact k+1 nearest

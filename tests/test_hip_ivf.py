@@ -193,8 +193,6 @@ def test_ivf_layout_run_and_public_class():
     assert res.shape == (n, D) and np.isfinite(res).all()
     with pytest.raises(ValueError):
         gra.create_graphem(adj, n_components=D, backend="hip", verbose=False, knn_method="ivf", knn_distance="cdist")
-    with pytest.raises(ValueError):     # whole-graph engines only
-        _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_method="ivf", partition=(0, n // 2, 0, len(edges) // 2))
 
 
 def test_auto_takes_the_exact_index_only_where_it_pays():
@@ -218,3 +216,56 @@ def test_auto_takes_the_exact_index_only_where_it_pays():
     eng = _native.Engine(20000, 3, small, 1.0, 0.2, 0.5, 10, 4096)
     assert eng.knn_ivf_config() == (0, 0)
     eng.close()
+
+
+def test_exact_index_on_row_partitions():
+    """The index covers the OWN edges of a rank, like the scan and the grid: three row-partitioned engines in the native
+    loop (loopback collectives, one thread each) with the inverted file in its exact mode reproduce the single scan engine,
+    every rank bit-identical."""
+    import threading
+    from graphem_rapids_amd import _native
+    from graphem_rapids_amd.distributed import partition_rows
+    n, D, k, S, world = 90001, 4, 10, 1024, 3
+    edges = _graph(n - 1, 8, seed=6)
+    rng = np.random.default_rng(9)
+    pos = np.vstack([rng.standard_normal((n - 1, D)).astype(np.float32), np.zeros((1, D), np.float32)])
+    stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(3)]).astype(np.int32)
+    single = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=4, knn_method="scan")
+    single.set_positions(pos)
+    single.run(3, stream)
+    ref = single.get_positions()
+    single.close()
+    lib = _native.load()
+    group = lib.gh_loopback_group_create(world)
+    engines = []
+    for r in range(world):
+        chunk, lo, hi = partition_rows(n, world, r)
+        e = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=4, partition=(lo, hi, 0, 0, _native.EDGES_HASHED),
+                           knn_method="ivf", ivf_probes=-1)
+        e.gather_layout(world, r, chunk)
+        e.comm_init_loopback(group, r)
+        e.set_positions(pos)
+        engines.append(e)
+    errors = []
+
+    def work(e):
+        try:
+            e.timing_enable(True)
+            e.run_partitioned(3, stream)
+            e.sync()
+        except Exception as exc:  # pylint: disable=broad-exception-caught
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(e,)) for e in engines]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    outs = [e.get_positions() for e in engines]
+    assert all("ivf_scan" in e.timings() for e in engines)
+    for e in engines:
+        e.comm_destroy()
+        e.close()
+    lib.gh_loopback_group_destroy(group)
+    assert np.abs(outs[0] - ref).max() <= 2e-6
+    assert all(np.array_equal(o, outs[0]) for o in outs[1:])
