@@ -15,12 +15,12 @@ timeout -k 10 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_AC
     python3 "$ROOT/bench.py" --workload "$WL" $EXTRA --sample-size "$S" --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline > /dev/null 2>&1
 find "$ROOT/$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$ROOT/$OUT/kernel_stats.csv"
 python3 - "$ROOT/$OUT" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, re, sys, collections
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob(out + "/pmc_sq/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:60]
+        k = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0][:60]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
         if r["Counter_Name"] == "SQ_WAVES": cnt[k] += 1
 with open(out + "/pmc_sq_summary.txt", "w") as o:
