@@ -127,6 +127,8 @@ struct gh_engine {
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
     int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line
     int32_t *d_ovf = nullptr;     // (S)
+    int32_t *d_sel_redo = nullptr;// (S) queries knn_select_wave_kernel left to the workgroup form (zero between launches)
+    int32_t *d_tq_count = nullptr, *d_tq_base = nullptr, *d_tq_touched = nullptr;   // (S), (S), (S, 4 k): per-query runs of the touched list (S >= 2048)
     int32_t *d_dbg_cnt = nullptr; // (2, S) candidate-list lengths seen by the last subset / final select
     uint64_t *d_partial = nullptr;// (S, K) this rank's best keys, ascending
     uint64_t *d_merged = nullptr; // (S, K) keys merged over the ranks (world > 1)

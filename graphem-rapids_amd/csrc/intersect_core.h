@@ -84,7 +84,9 @@ __device__ __forceinline__ void gh_intersect_pair_t(const float *__restrict__ po
 // gh_intersect_pair_t -- identical terms -- and adds ITS coordinate: one wave instruction = up to 4 contiguous rows.
 struct gh_pair_list {
     int n;
+    int nt, base;  // vertices this query touched first, and where their run starts in the global list
     int4 v[128];   // endpoints (p1, p2, q1, q2) of the crossing pairs of one query (k <= 127 on this path)
+    int32_t t[512];
 };
 
 template <int D, int LD>
@@ -92,8 +94,11 @@ __device__ __forceinline__ void gh_intersect_query_wide(const float *__restrict_
                                                         int32_t i, const uint64_t *best /* K keys, LDS */, int k,
                                                         float k_inter, double *__restrict__ acc,
                                                         int32_t *__restrict__ tflag, int32_t *__restrict__ touched,
-                                                        int32_t *__restrict__ tcount, gh_pair_list *pl) {
-    if (threadIdx.x == 0) pl->n = 0;
+                                                        int32_t *__restrict__ tcount, gh_pair_list *pl,
+                                                        int32_t *__restrict__ own_count = nullptr /* thousands of queries: `touched`
+                                                        is this query's OWN run of 4 k slots and its length goes here -- no atomic on
+                                                        the shared counter at all; knn_touched_compact_kernel gathers the runs */) {
+    if (threadIdx.x == 0) { pl->n = 0; pl->nt = 0; }
     __syncthreads();
     for (int c = threadIdx.x; c < k; c += blockDim.x) {
         const int32_t j = (int32_t)(uint32_t)best[c + 1];   // column 0 is dropped blindly (pt.py:421)
@@ -132,8 +137,22 @@ __device__ __forceinline__ void gh_intersect_query_wide(const float *__restrict_
         for (int dd = 1; dd < D; ++dd) term = d == dd ? diff[dd] : term;
         const int32_t me = role == 0 ? v[0] : role == 1 ? v[1] : role == 2 ? v[2] : v[3];
         if (d < D) atomicAdd(&acc[(int64_t)me * LD + d], (double)((k_inter * term) / dsq));
-        if (d == 0 && atomicExch(&tflag[me], 1) == 0) touched[atomicAdd(tcount, 1)] = me;
+        // first touch of a vertex: listed per query in LDS, ONE reservation in the global list per query below (a returning
+        // atomic per vertex on the single counter serialised at ~11 ns each: 16 K queries' 30 K first touches were 320 us of
+        // this launch, 256 queries' several hundred a third of its 14 us)
+        if (d == 0 && atomicExch(&tflag[me], 1) == 0) pl->t[atomicAdd(&pl->nt, 1)] = me;
     }
+    __syncthreads();
+    const int nt = pl->nt;
+    if (own_count) {
+        if (threadIdx.x == 0) *own_count = nt;
+        for (int i = threadIdx.x; i < nt; i += blockDim.x) touched[i] = pl->t[i];
+        return;
+    }
+    if (nt == 0) return;   // uniform: read behind the barrier
+    if (threadIdx.x == 0) pl->base = atomicAdd(tcount, nt);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) touched[pl->base + i] = pl->t[i];
 }
 
 // Dispatch on the embedding dimension: register form for the usual D, scratch form otherwise.

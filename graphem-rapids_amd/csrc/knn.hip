@@ -41,6 +41,8 @@ struct inter_args {
     double *acc;
     int32_t *tflag, *touched, *tcount;
     float *scratch;
+    int32_t *tq_count = nullptr;    // knn_select_wave_kernel: per-query runs of the touched list (S), (S, 4 k)
+    int32_t *tq_touched = nullptr;
 };
 
 // Whole workgroup; best[] in LDS, visible to all threads (the callers' extraction ends with a barrier).
@@ -53,8 +55,12 @@ __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi
     if constexpr (DT >= 2) {
         constexpr int LL = DT <= 4 ? 4 : DT <= 8 ? 8 : 16;
         if (ia.k <= 127 && blockDim.x % (4 * LL) == 0) {   // lanes = (role, coordinate)
-            gh_intersect_query_wide<DT, LL>(ia.pos, ia.edges, ia.sampled[qi], best, ia.k, ia.k_inter, ia.acc, ia.tflag, ia.touched,
-                                            ia.tcount, pl);
+            if (ia.tq_count)
+                gh_intersect_query_wide<DT, LL>(ia.pos, ia.edges, ia.sampled[qi], best, ia.k, ia.k_inter, ia.acc, ia.tflag,
+                                                ia.tq_touched + qi * 4 * ia.k, ia.tcount, pl, ia.tq_count + qi);
+            else
+                gh_intersect_query_wide<DT, LL>(ia.pos, ia.edges, ia.sampled[qi], best, ia.k, ia.k_inter, ia.acc, ia.tflag, ia.touched,
+                                                ia.tcount, pl);
             return;
         }
     }
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
                                                          int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
                                                          search_args fb, inter_args ia, int S,
                                                          const double *__restrict__ blockstats, int nblocks,
-                                                         double *__restrict__ stats) {
+                                                         double *__restrict__ stats, int32_t *__restrict__ only = nullptr) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     float *qs = reinterpret_cast<float *>(smem_raw);  // LD floats (exact search only)
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
@@ -507,6 +513,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
         if (threadIdx.x == 0) stats[qi - S] = ((dred[0] + dred[1]) + dred[2]) + dred[3];
         return;
     }
+    if (only && !only[qi]) return;   // second launch behind knn_select_wave_kernel: the queries it left
     // the first 1024 list slots are fetched before the list's length is known (the list is allocated whole: slots past the
     // end hold stale keys, masked below): one memory round trip instead of two in front of the extraction
     uint64_t pre[4];
@@ -514,7 +521,7 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     for (int j = 0; j < 4; ++j) pre[j] = cand[qi * GH_CAND_CAP + j * 256 + threadIdx.x];
     const int c = cnt[qi * GH_CNT_STRIDE];
     __syncthreads();
-    if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; }
+    if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; if (only) only[qi] = 0; }
     if (__builtin_expect(c > GH_CAND_CAP || c < K, 0)) {   // (cold: laid out behind the usual path)
         if (!final_level) return;  // tau keeps its previous (still valid, looser) value
         if (threadIdx.x == 0) ovf[qi] = 1;
@@ -533,6 +540,81 @@ __global__ __launch_bounds__(256) void knn_select_kernel(uint64_t *__restrict__ 
     } else if (threadIdx.x == 0) {
         tau[qi * QS] = gh_key_d2(best[K - 1]);
     }
+}
+
+// The same selection (final level) with ONE WAVE per query, for thousands of queries on the unfused paths: a query's
+// selection is a chain of dependent memory round trips (list length, keys, the pairs' edges, their rows, atomics) during
+// which a 256-thread workgroup mostly waits; with a wave per query four times as many queries are in flight per CU
+// (16384 queries, 1 M vertices: 320 -> 99 us together with the per-query runs of the touched list).  Takes lists of K .. 1024 keys; anything else (overflow, too few
+// candidates, longer lists) is flagged in `redo` with its counter untouched and done by knn_select_kernel right behind.
+template <int DT>
+__global__ __launch_bounds__(64) void knn_select_wave_kernel(const uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, int K,
+                                                            uint64_t *__restrict__ out_keys, int32_t *__restrict__ dbg_cnt,
+                                                            int32_t *__restrict__ redo, inter_args ia, int S) {
+    constexpr int NT = 64;
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[2 * NT];   // K <= 128 keys of one wave's extraction, or the 2 * NT keys the rank form stages
+    __shared__ gh_pair_list pairs;
+    const int64_t qi = blockIdx.x;
+    if (qi >= S) return;
+    uint64_t pre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pre[j] = cand[qi * GH_CAND_CAP + j * NT + threadIdx.x];
+    const int c = cnt[qi * GH_CNT_STRIDE];
+    if (c > 16 * NT || c < K) {
+        if (threadIdx.x == 0) redo[qi] = 1;
+        return;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; }
+    if (c <= 4 * NT && !(K > 16 && c <= 2 * NT)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pre[j] = j * NT + (int)threadIdx.x < c ? pre[j] : GH_KEY_INF;
+        block_extract_smallest<4, NT>(pre, K, best, red);
+    } else {
+        block_extract_adaptive<16, NT>(cand + qi * GH_CAND_CAP, c, K, best, red);
+    }
+    for (int i = threadIdx.x; i < K; i += NT) out_keys[qi * K + i] = best[i];
+    if (ia.pos) intersect_query<DT>(ia, qi, best, &pairs);
+}
+
+// The per-query runs knn_select_wave_kernel's intersection phase left -> the touched list: one workgroup adds the S run
+// lengths up, reserves the whole stretch with ONE atomic on the shared counter and hands every query its start; the copy
+// follows.  (A reservation per query was 16 K returning atomics on one address: 180 us of a 206 us launch.)
+__global__ __launch_bounds__(1024) void knn_touched_prefix_kernel(const int32_t *__restrict__ tq_count, int S, int32_t *__restrict__ tq_base,
+                                                                  int32_t *__restrict__ tcount) {
+    __shared__ int part[1024];
+    __shared__ int base0;
+    const int t = threadIdx.x;
+    const int per = (S + 1023) / 1024;
+    int sum = 0;
+    for (int i = 0; i < per; ++i) { const int q = t * per + i; sum += q < S ? tq_count[q] : 0; }
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    if (t == 1023) base0 = part[1023] > 0 ? atomicAdd(tcount, part[1023]) : 0;
+    __syncthreads();
+    int at = base0 + part[t] - sum;
+    for (int i = 0; i < per; ++i) {
+        const int q = t * per + i;
+        if (q >= S) break;
+        tq_base[q] = at;
+        at += tq_count[q];
+    }
+}
+__global__ __launch_bounds__(256) void knn_touched_copy_kernel(int32_t *__restrict__ tq_count, const int32_t *__restrict__ tq_base,
+                                                              const int32_t *__restrict__ tq_touched, int S, int k4,
+                                                              int32_t *__restrict__ touched) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t q = i / k4;
+    const int slot = (int)(i % k4);
+    if (q >= S) return;
+    if (slot < tq_count[q]) touched[tq_base[q] + slot] = tq_touched[q * k4 + slot];
 }
 
 // Merge the per-rank key lists (world, S, K) into the K globally best keys per query (S, K).
@@ -655,16 +737,40 @@ int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile, bool mfma) {
 // fb_mid: midpoint rows for the exact search of overflowed queries, or null (gather the endpoints).
 gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect, const float *fb_mid) {
     // the column sums of the fused kernel's workgroup partials ride along (stats_fix_kernel then skips them)
-    const bool reduce = final_level && h->new0_ready && h->rows > 0 && h->LD <= 16;
+    // (not with thousands of queries: there the wave-per-query form below is worth more than the ride, and stats_fix_kernel
+    // adds the column sums up itself)
+    const bool reduce = final_level && h->new0_ready && h->rows > 0 && h->LD <= 16 && h->S < 2048;
     gh_scope t(h, with_intersect ? "knn_select_intersect" : "knn_select");
+    // thousands of queries, no column sums riding along: a wave per query first, the workgroup form for what it leaves
+    static const bool no_wave = getenv("GRAPHEM_HIP_SELECT_BLOCK") != nullptr;   // A/B
+    const bool wave = final_level && !reduce && h->S >= 2048 && !no_wave;
+    bool wave_tq = false;
+    if (wave) {
+#define GH_SELW(DD)                                                                                                      \
+    knn_select_wave_kernel<DD><<<dim3((unsigned)h->S), dim3(64), 0, h->stream>>>(h->d_cand, h->d_cnt, h->K, h->d_partial,   \
+                                                                                 h->d_dbg_cnt + (size_t)h->S, h->d_sel_redo, \
+                                                                                 iaw, (int)h->S)
+        inter_args iaw = make_inter_args(h, with_intersect);
+        wave_tq = with_intersect && h->k <= 127 && h->D >= 2 && h->LD <= 16;   // the lanes-per-coordinate form of the phase (intersect_query)
+        if (wave_tq) { iaw.tq_count = h->d_tq_count; iaw.tq_touched = h->d_tq_touched; }
+        if (with_intersect) { GH_DISPATCH_DIM(h->D, GH_SELW) } else { GH_SELW(0); }
+#undef GH_SELW
+    }
 #define GH_SEL(DD)                                                                                                                          \
     knn_select_kernel<DD><<<dim3((unsigned)h->S + (reduce ? 2u * (unsigned)h->LD : 0u)), dim3(256), sizeof(float) * (size_t)h->LD, h->stream>>>( \
         h->d_cand, h->d_cnt, h->K, final_level ? 1 : 0, h->d_q + gh_qtau(h->D, h->LD), gh_qs(h->D, h->LD),                                     \
         h->d_partial, h->d_ovf, h->d_dbg_cnt + (size_t)(final_level ? 1 : 0) * h->S,                                                           \
         make_search_args(h, fb_mid, h->own_count, 1, 1), make_inter_args(h, with_intersect), (int)h->S,                                        \
-        h->d_blockstats, h->n_vblocks, h->d_stats)
+        h->d_blockstats, h->n_vblocks, h->d_stats, wave ? h->d_sel_redo : nullptr)
     if (with_intersect) { GH_DISPATCH_DIM(h->D, GH_SEL) } else { GH_SEL(0); }
 #undef GH_SEL
+    if (wave_tq) {
+        const int k4 = 4 * h->k;
+        knn_touched_prefix_kernel<<<dim3(1), dim3(1024), 0, h->stream>>>(h->d_tq_count, (int)h->S, h->d_tq_base, h->d_tcount);
+        knn_touched_copy_kernel<<<dim3((unsigned)(((int64_t)h->S * k4 + 255) / 256)), dim3(256), 0, h->stream>>>(
+            h->d_tq_count, h->d_tq_base, h->d_tq_touched, (int)h->S, k4, h->d_touched);
+        GH_HIP(hipMemsetAsync(h->d_tq_count, 0, sizeof(int32_t) * (size_t)h->S, h->stream));
+    }
     GH_LAUNCH_CHECK();
     h->stats_reduced = reduce;
     return GH_OK;
