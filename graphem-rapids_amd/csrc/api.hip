@@ -322,6 +322,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
             }
             h->nlong = (int)long_rows.size();
             h->long_entries = long_eptr.back();
+            for (size_t r = 0; r + 1 < long_eptr.size(); ++r) h->long_max_deg = std::max(h->long_max_deg, (int)(long_eptr[r + 1] - long_eptr[r]));
             long_erow.resize((size_t)h->long_entries);   // list entry -> index of its long row (spares long_terms_kernel a binary search)
             for (size_t r = 0; r + 1 < long_eptr.size(); ++r)
                 for (int32_t t = long_eptr[r]; t < long_eptr[r + 1]; ++t) long_erow[(size_t)t] = (int32_t)r;

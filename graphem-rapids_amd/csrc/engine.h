@@ -71,6 +71,7 @@ struct gh_engine {
     int nlong = 0;
     int long_deg = 128;               // rows with more neighbours than this are long (common.h gh_long_degree)
     int64_t long_entries = 0;
+    int long_max_deg = 0;             // longest long row (forces.hip: one launch for the long rows when moderate)
     float *d_mid = nullptr;       // (own_count, LD) midpoints of the own edges, current iteration
     float *d_Fs = nullptr;        // (rows, LD) spring forces of the own rows
     float *d_gmin = nullptr;      // (S, Gpad) group minima of the threshold subset (setup_core.h), float bits

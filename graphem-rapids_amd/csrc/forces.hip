@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void long_sum_kernel(const float *__restrict__
             t[d] = term;
         }
         const int cnt = deg - base < 64 ? deg - base : 64;
+        asm volatile("s_nop 4" ::: "memory");   // (the first DPP read of x must not follow its VALU write directly: the compiler does not see into the asm)
         // 63 steps of ONE instruction per coordinate: v_add_f32 with its first operand taken from the
         // left neighbour lane (DPP wave_shr:1); lane 0 has none and, bound_ctrl being off, keeps its
         // value.  Values only travel upwards, so a lane is final after as many steps as its index and
@@ -717,11 +718,86 @@ gh_long_args gh_make_long_args(const gh_engine *h, bool coop_mid) {
 }
 
 // Spring forces of the long own rows -> outF rows (i + f_row0); no-op for graphs without hubs.
+// Both steps in one launch for rows of moderate length (every row of a small dense graph, common.h GH_LONG_DEG_DENSE): one
+// wave per long row computes the terms of 64 list entries in registers -- lane = entry, the arithmetic of spring_pull -- and
+// adds them in list order with the same DPP chain; the neighbour rows of the next 64 entries are in flight during the
+// chain.  No terms array, one launch less (the SNAP shape at 16 components: 27.3 -> 17.4 us, 112 -> 102 us per iteration).  A hub of thousands of
+// neighbours has only one wave's gathers in flight this way, so graphs with such rows keep the two launches.
+#define GH_LONG_ONE_LAUNCH_MAX_DEG 1024
+template <int D, int LD>
+__global__ __launch_bounds__(256) void long_rows_kernel(const float *__restrict__ pos, const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ adj, const int32_t *__restrict__ long_rows,
+                                                       const int32_t *__restrict__ eptr, int nlong, int64_t row_lo, float L_min,
+                                                       float neg_k, float *__restrict__ outF, int64_t f_row0) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nlong) return;
+    const int i = long_rows[r];
+    const int deg = eptr[r + 1] - eptr[r];
+    const int32_t *list = adj + rowptr[i];
+    float px[LD], py[LD], F[D];
+    gh_load_row<LD>(pos, row_lo + i, px);
+    auto fetch = [&](int idx) {   // neighbour row of list entry idx (own row past the end: a zero term)
+        const int64_t y = idx < deg ? (int64_t)((uint32_t)list[idx] & 0x7FFFFFFFu) : row_lo + i;
+        gh_load_row<LD>(pos, y, py);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) F[d] = 0.0f;
+    fetch(lane);
+    for (int base = 0; base < deg; base += 64) {
+        float x[D], t[D], diff[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) diff[d] = py[d] - px[d];
+        const bool live = base + lane < deg;
+        const float dist = sqrtf(gh_sumsq<D>(diff)) + 1e-6f;
+        const float fm = neg_k * (dist - L_min);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            t[d] = live ? fm * (diff[d] / dist) : 0.0f;
+            x[d] = lane == 0 ? F[d] + t[d] : t[d];
+        }
+        if (base + 64 < deg) fetch(base + 64 + lane);   // in flight during the chain below
+        const int cnt = deg - base < 64 ? deg - base : 64;
+        asm volatile("s_nop 4" ::: "memory");   // the chain's first DPP read of x comes right behind the VALU writes above when the fetch is skipped
+#pragma unroll
+        for (int step = 1; step < 64; ++step) {
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+                asm volatile("v_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x[d]) : "v"(t[d]));
+            asm volatile("s_nop 1");
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            F[d] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x[d]), cnt - 1));
+    }
+    if (lane == 0) {
+        float out[LD];
+#pragma unroll
+        for (int d = 0; d < LD; ++d) out[d] = d < D ? F[d] : 0.0f;
+        gh_store_row<LD>(outF, long_rows[r] + f_row0, out);
+    }
+}
+
 gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0) {
     const gh_long_args la = gh_make_long_args(h);
     if (la.n == 0) return GH_OK;
     gh_scope t(h, "spring_long");
     const float neg_k = -h->prm.k_attr;
+    static const bool two = getenv("GRAPHEM_HIP_LONG_TWO") != nullptr;   // A/B
+    if (!two && h->long_max_deg <= GH_LONG_ONE_LAUNCH_MAX_DEG) {
+#define GH_LONG_FUSED(DD, LL)                                                                                                 \
+    case DD:                                                                                                                  \
+        long_rows_kernel<DD, LL><<<dim3((unsigned)((la.n + 3) / 4)), dim3(256), 0, h->stream>>>(                                \
+            h->d_pos, h->d_rowptr, h->d_adj, la.rows, h->d_long_eptr, la.n, h->part.row_lo, h->prm.L_min, neg_k, outF, f_row0); \
+        break;
+        switch (h->D) {
+            GH_FOR_EACH_DIM(GH_LONG_FUSED)
+            default: break;
+        }
+#undef GH_LONG_FUSED
+        GH_LAUNCH_CHECK();
+        return GH_OK;
+    }
 #define GH_LONG_CASE(DD, LL)                                                                                          \
     long_terms_kernel<DD, LL><<<dim3(grid_for(h->long_entries, 256)), dim3(256), 0, h->stream>>>(                       \
         h->d_pos, h->d_rowptr, h->d_adj, la.rows, h->d_long_eptr, h->d_long_erow, (int)h->long_entries, h->part.row_lo,     \
