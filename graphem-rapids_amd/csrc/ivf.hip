@@ -857,7 +857,8 @@ gh_status gh_ivf_search(gh_engine *h) {
     // below (there the nearest lists hold the nearest members, and at 16 K queries the sample was the probe kernel's 0.55 ms);
     // 1024 ... 8192
     const int64_t probed = (int64_t)P * (M / C);
-    const int tau_members = v->exact ? std::max(4096, 16 * h->Ksel) /* a tight threshold keeps the ball small */ : (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / (h->D > 8 ? 16 : 64)));
+    static const int tm_env = getenv("GRAPHEM_HIP_IVF_TAU_MEMBERS") ? atoi(getenv("GRAPHEM_HIP_IVF_TAU_MEMBERS")) : 0;   // tuning
+    const int tau_members = tm_env > 0 ? std::max(tm_env, 4 * h->Ksel) : v->exact ? std::max(4096, 16 * h->Ksel) /* a tight threshold keeps the ball small */ : (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / (h->D > 8 ? 16 : 64)));
 #define GH_IVF_LD(X)                          \
     switch (h->LD) {                          \
         case 4: { X(4) } break;               \
