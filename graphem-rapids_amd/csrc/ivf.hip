@@ -7,7 +7,8 @@
 // What makes it an MI355X design rather than a port of a query-major IVF search:
 //  * the coarse quantiser is a flat argmin over C centroids on the MATRIX pipe: one v_mfma_f32_32x32x16_f16 gives
 //    |c|^2 - 2 c.m for 32 centroids x 32 midpoints with single-piece f16 operands (the assignment only has to be A
-//    partition, not the nearest centroid to the last bit), the winning row rides in the four low mantissa bits of the score;
+//    partition, not the nearest centroid to the last bit), the winning group of four rows rides in the two low mantissa bits of
+//    the score through the min tree, the row among the four is settled once per midpoint;
 //  * the search is LIST-major: (query, probed list) pairs are bucketed by list, and a workgroup takes one 512-member tile
 //    of one list and runs that list's queries over it with the packed-VALU filtered scan of scan_core.h -- a list is read
 //    once per iteration (E * LD * 4 bytes in all), not once per probing query;
@@ -70,6 +71,13 @@ typedef _Float16 ivf_h8 __attribute__((ext_vector_type(8)));
 typedef float ivf_f16x __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ _Float16 ivf_half(float x) { return (_Float16)fminf(fmaxf(x, -30000.0f), 30000.0f); }
+// (This file is compiled with -fno-honor-nans, Makefile: fminf() otherwise makes the compiler quiet a possible signalling
+// NaN in every operand first -- one v_max_f32 x, x, x each, 32 of them per matrix result in the assignment's loop.  No value
+// here is ever a NaN: coordinates are finite, infinities only mark "no bound" and are never subtracted from one another.
+// Inline-asm minima are not an option: the compiler does not insert the wait states between a matrix instruction and an
+// asm statement that reads its result -- tried, wrong assignments.)
+__device__ __forceinline__ float ivf_min3(float a, float b, float c) { return fminf(fminf(a, b), c); }
+__device__ __forceinline__ float ivf_min2(float a, float b) { return fminf(a, b); }
 
 // Centroids = this iteration's midpoints of C evenly spaced own edges (a sample of the data's own density, as k-means++
 // seeding without the refinement passes: lists come out at roughly equal mass), their operand rows and norms; counters
@@ -98,8 +106,8 @@ __global__ __launch_bounds__(256) void ivf_centroid_kernel(const float *__restri
 
 // Nearest centroid of every own midpoint.  A wave holds GH_IVF_MB blocks of 32 midpoints as B operands (lane = column,
 // lane half = which 8 of the 16 coordinates) and walks the centroids 32 at a time: accumulator initialised with |c|^2,
-// one MFMA per member block, row index packed into the low 4 mantissa bits, minimum over the lane's 16 rows, running
-// best per column.  The two lane halves of a column hold different rows: combined at the end.  A workgroup walks its
+// one MFMA per member block, minimum per group of four rows with the group in the low 2 mantissa bits, minimum of the four,
+// running best per column.  The two lane halves of a column hold different rows: combined at the end.  A workgroup walks its
 // share of the midpoints in steps of 512 with the centroid table staged once; positions inside the lists: see
 // GH_IVF_CSTRIDE above.
 template <int LD>
@@ -162,10 +170,16 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict
             for (int mb = 0; mb < GH_IVF_MB; ++mb) {
                 ivf_f16x fn = cinit;
                 if (mb + 1 < GH_IVF_MB) fn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[mb + 1], cinit, 0, 0, 0);   // in the matrix pipe while block mb is reduced
-                float mn = INFINITY;
+                // minimum of each group of four rows (rows 8g + 4 half + 0..3: four CONSECUTIVE centroids), the group in the two
+                // low mantissa bits, minimum of the four: 17 vector instructions per result instead of the 27 of carrying all
+                // four index bits through 16 values; which of the four it was is settled once per midpoint at the end
+                float pg[4];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) mn = fminf(mn, __uint_as_float((__float_as_uint(f[i]) & ~15u) | (uint32_t)i));
-                asm volatile("" : "+v"(mn));
+                for (int g = 0; g < 4; ++g) {
+                    const float mg = ivf_min2(ivf_min3(f[4 * g], f[4 * g + 1], f[4 * g + 2]), f[4 * g + 3]);
+                    pg[g] = __uint_as_float((__float_as_uint(mg) & ~3u) | (uint32_t)g);
+                }
+                float mn = ivf_min2(ivf_min3(pg[0], pg[1], pg[2]), pg[3]);
                 const bool better = mn < best[mb];
                 best[mb] = better ? mn : best[mb];
                 bestcb[mb] = better ? cb : bestcb[mb];
@@ -177,13 +191,31 @@ __global__ __launch_bounds__(256) void ivf_assign_kernel(const float *__restrict
             const float ob = __shfl_xor(best[mb], 32, 64);
             const int ocb = __shfl_xor(bestcb[mb], 32, 64);
             const float mn2 = mnorm[mb] + __shfl_xor(mnorm[mb], 32, 64);
+            const uint4 own8 = __builtin_bit_cast(uint4, B[mb]);   // the other lane half's 8 coordinates of the same midpoint
+            const uint4 oth8 = make_uint4(__shfl_xor(own8.x, 32, 64), __shfl_xor(own8.y, 32, 64), __shfl_xor(own8.z, 32, 64), __shfl_xor(own8.w, 32, 64));
             const int64_t j = base + mb * 32 + col;
             if (hsel == 0 && j < hi) {
                 const bool mine = best[mb] <= ob;
-                const float bv = mine ? best[mb] : ob;
+                const float bq = mine ? best[mb] : ob;
                 const int cb = mine ? bestcb[mb] : ocb;
-                const int i = (int)(__float_as_uint(bv) & 15u);
-                const int l = cb * 32 + (i & 3) + 8 * (i >> 2) + 4 * (mine ? 0 : 1);
+                const int l0 = cb * 32 + 8 * (int)(__float_as_uint(bq) & 3u) + 4 * (mine ? 0 : 1);
+                // the four centroids of the winning group: their scores again, from the same f16 operands (fp32 fma chain: it
+                // differs from the matrix pipe's accumulation by rounding only), smallest first
+                const ivf_h8 mlo = __builtin_bit_cast(ivf_h8, own8), mhi = __builtin_bit_cast(ivf_h8, oth8);
+                float bv = INFINITY;
+                int l = l0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const ivf_h8 alo = __builtin_bit_cast(ivf_h8, Ash[(l0 + e) * 2]), ahi = __builtin_bit_cast(ivf_h8, Ash[(l0 + e) * 2 + 1]);
+                    float sc = nsh[l0 + e];
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) sc = fmaf((float)alo[d], (float)mlo[d], sc);
+                    if constexpr (LD > 8) {
+#pragma unroll
+                        for (int d = 0; d < 8; ++d) sc = fmaf((float)ahi[d], (float)mhi[d], sc);
+                    }
+                    if (sc < bv) { bv = sc; l = l0 + e; }
+                }
                 assign[j] = (uint32_t)l;
                 rank[j] = (uint32_t)atomicAdd(&hist[l], 1);   // LDS: position inside this workgroup's share of the list
                 if (r2) {
