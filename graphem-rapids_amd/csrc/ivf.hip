@@ -1,21 +1,28 @@
 // GH_KNN_IVF: an inverted-file (IVF-Flat) search of the sampled midpoints, rebuilt every iteration like the reference's
 // cuVS backend rebuilds its index (embedder_cuvs.py:255-313 builds IVF-Flat / IVF-PQ over the midpoints of the iteration,
-// :384-430 searches it).  APPROXIMATE by construction -- a query sees only the members of the `probes` lists whose
-// centroids are nearest to it -- but exact inside those lists: distances are the exact-difference fma chain every other
-// method ranks on, and the k + 1 returned ids are the k + 1 smallest (distance, id) keys among the probed members.
+// :384-430 searches it).  Two modes (gh_params.ivf_probes):
+//   >= 0  APPROXIMATE, the cuVS semantics: a query sees the members of the `probes` lists whose centroids are nearest to it
+//         and gets the k + 1 smallest (distance, id) keys among them -- exact inside those lists (the exact-difference fma
+//         chain every other method ranks on), blind outside;
+//   <  0  EXACT: a query probes every list that can hold one of its k + 1 nearest (ivf_probe_kernel<.., true>: centroid
+//         within sqrt(tau) + min(list radius, sqrt(tau) + distance to the query's nearest centroid), f16 errors on the safe
+//         side), so the rows are those of the scan, id for id.  What GH_KNN_AUTO takes for 2-8 components and thousands of
+//         queries (api.hip).
 //
 // What makes it an MI355X design rather than a port of a query-major IVF search:
 //  * the coarse quantiser is a flat argmin over C centroids on the MATRIX pipe: one v_mfma_f32_32x32x16_f16 gives
 //    |c|^2 - 2 c.m for 32 centroids x 32 midpoints with single-piece f16 operands (the assignment only has to be A
-//    partition, not the nearest centroid to the last bit), the winning group of four rows rides in the two low mantissa bits of
-//    the score through the min tree, the row among the four is settled once per midpoint;
+//    partition -- the exact mode's bounds carry the f16 error --), the winning group of four rows rides in the two low
+//    mantissa bits of the score through the min tree, the row among the four is settled once per midpoint;
+//  * list positions without device-wide atomic traffic: LDS counters per workgroup, one reservation per (workgroup, list);
 //  * the search is LIST-major: (query, probed list) pairs are bucketed by list, and a workgroup takes one 512-member tile
-//    of one list and runs that list's queries over it with the packed-VALU filtered scan of scan_core.h -- a list is read
-//    once per iteration (E * LD * 4 bytes in all), not once per probing query;
-//  * thresholds come from the query's nearest list(s): 256 group minima per query, the K-th smallest of them (the
-//    existing threshold kernel, tau_core.h) bounds the K-th smallest distance INSIDE the probed lists from above, so the
-//    filtered scan finds at least K candidates and usually few more.
-// Everything after the candidate lists (selection, intersection phase) is the code of the exact methods.
+//    of one list and runs that list's queries over it with the filtered scan of scan_core.h (matrix-pipe pre-filter for
+//    4-16 components, packed fp32 below) -- a list is read once per iteration (E * LD * 4 bytes in all), not once per
+//    probing query;
+//  * thresholds come from a sample of the query's nearest lists: 256 group minima per query, the K-th smallest of them
+//    (the existing threshold kernel, tau_core.h) bounds the K-th smallest distance from above, so the filtered scan finds
+//    at least K candidates and usually few more.
+// Everything after the candidate lists (selection, intersection phase) is the code of the other methods.
 #include <algorithm>
 #include <cstdlib>
 
