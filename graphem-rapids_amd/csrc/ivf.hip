@@ -91,9 +91,14 @@ __device__ __forceinline__ float ivf_min2(float a, float b) { return fminf(a, b)
 // of the iteration zeroed.
 template <int LD>
 __global__ __launch_bounds__(256) void ivf_centroid_kernel(const float *__restrict__ mid, int64_t M, int C, float *__restrict__ cent,
-                                                           uint4 *__restrict__ A, float *__restrict__ cnorm) {
+                                                           uint4 *__restrict__ A, float *__restrict__ cnorm,
+                                                           int32_t *__restrict__ count, int32_t *__restrict__ lqcount,
+                                                           uint32_t *__restrict__ r2) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    count[c * GH_IVF_CSTRIDE] = 0;     // the iteration's counters (only the first word of a line is ever used)
+    lqcount[c * GH_IVF_CSTRIDE] = 0;
+    if (r2) r2[c * GH_IVF_CSTRIDE] = 0;
     const int64_t j = (int64_t)c * M / C + (M / C) / 2;
     float v[16];
 #pragma unroll
@@ -907,10 +912,7 @@ gh_status gh_ivf_search(gh_engine *h) {
     {
         gh_scope t(h, "ivf_build");
         GH_HIP(hipMemsetAsync(v->lids, 0xFF, sizeof(uint32_t) * (size_t)v->cap_rows, h->stream));
-        GH_HIP(hipMemsetAsync(v->count, 0, sizeof(int32_t) * (size_t)C * GH_IVF_CSTRIDE, h->stream));
-        GH_HIP(hipMemsetAsync(v->lqcount, 0, sizeof(int32_t) * (size_t)C * GH_IVF_CSTRIDE, h->stream));
-        if (v->exact) GH_HIP(hipMemsetAsync(v->r2, 0, sizeof(uint32_t) * (size_t)C * GH_IVF_CSTRIDE, h->stream));
-#define GH_X(L) ivf_centroid_kernel<L><<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, M, C, v->cent, v->A, v->cnorm);
+#define GH_X(L) ivf_centroid_kernel<L><<<dim3((unsigned)((C + 255) / 256)), dim3(256), 0, h->stream>>>(h->d_mid, M, C, v->cent, v->A, v->cnorm, v->count, v->lqcount, v->r2);
         GH_IVF_LD(GH_X)
 #undef GH_X
         GH_LAUNCH_CHECK();
