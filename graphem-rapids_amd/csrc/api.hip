@@ -124,6 +124,8 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     h->prm = *params;
     h->k = params->n_neighbors; h->K = h->k + 1;
     h->S = std::min<int64_t>(params->sample_size, E);
+    const bool auto_method = h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID && h->prm.knn_method != GH_KNN_IVF &&
+                             !getenv("GRAPHEM_HIP_KNN");
     if (h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID && h->prm.knn_method != GH_KNN_IVF) {   // AUTO (and anything unknown)
         // exact methods only.  Whole graph, up to 8 components, thousands of queries: the inverted file in its exact mode
         // (rr1m, scan / exact IVF us per iteration: D = 3 S = 4096 1089 / 612, 16384 3730 / 793 (grid 2074); D = 6 S = 16384
@@ -349,6 +351,12 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         }
         h->own_count = h->part.edge_hi - h->part.edge_lo;
         h->mid_base = h->part.edge_lo;
+    }
+    // AUTO on a partitioned engine: the same rule with the edges this rank owns (known only now)
+    if (auto_method && part && !h->cdist && D >= 2 && D <= 8 && h->S >= (D <= 4 ? 4096 : 8192) && h->own_count >= 262144) {
+        h->prm.knn_method = GH_KNN_IVF;
+        h->prm.ivf_probes = -1;
+        h->prm.ivf_lists = 0;
     }
     // Vertex ranges of the fused spring+scan workgroups: as many consecutive own rows as hold at
     // most TILE owned edges (and at most 1024 rows, 4 per thread).

@@ -212,6 +212,12 @@ def test_auto_takes_the_exact_index_only_where_it_pays():
     assert cfg(3, 2048) == (0, 0) and cfg(6, 4096) == (0, 0) and cfg(9, 16384) == (0, 0)
     assert cfg(3, 4096, knn_distance="cdist") == (0, 0)                    # the parity mode keeps the scan
     assert cfg(3, 4096, knn_method="scan") == (0, 0)
+    from graphem_rapids_amd.distributed import partition_rows
+    big = _graph(200000, 8, seed=2)       # 800 000 edges: half of them (a rank of two) are still enough
+    chunk, lo, hi = partition_rows(200000, 2, 0)
+    eng = _native.Engine(200000, 3, big, 1.0, 0.2, 0.5, 10, 4096, partition=(lo, hi, 0, 0, _native.EDGES_HASHED))
+    assert eng.knn_ivf_config()[0] > 0 and eng.knn_ivf_config()[0] == eng.knn_ivf_config()[1]
+    eng.close()
     small = _graph(20000, 8, seed=2)      # 80 000 edges
     eng = _native.Engine(20000, 3, small, 1.0, 0.2, 0.5, 10, 4096)
     assert eng.knn_ivf_config() == (0, 0)
