@@ -725,8 +725,11 @@ static gh_status run_one_device_sampled(gh_engine *h) {
 // more than it saves on this runtime (the 1.9 - 2.8 us per replayed boundary of tools/micro/grid_barrier.hip did not
 // carry over to kernels with 200-byte argument blocks), so the enqueued loop stays the default.
 static bool graph_replay_applies(gh_engine *h) {
-    return whole_graph(h) && !h->d_gbuf && !h->g_world && !h->cdist && !h->timing && !h->d_stamps && h->fused_scan && !h->force_unfused &&
-           gh_knn_scan_path(h) && !gh_grid_path(h) && !gh_ivf_path(h) && h->S > 0 && h->k > 0 && h->K <= 128 && h->LD <= 16 &&
+    // the fused path, or the inverted-file path (its ~18 launches and memsets per iteration: the device counter is moved on
+    // by stats_reduce_kernel there)
+    const bool path = gh_ivf_path(h) || (h->fused_scan && !h->force_unfused && !gh_grid_path(h));
+    return whole_graph(h) && !h->d_gbuf && !h->g_world && !h->cdist && !h->timing && !h->d_stamps && path &&
+           gh_knn_scan_path(h) && h->S > 0 && h->k > 0 && h->K <= 128 && h->LD <= 16 &&
            getenv("GRAPHEM_HIP_GRAPH") && atoi(getenv("GRAPHEM_HIP_GRAPH")) != 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
 }
 static int graph_iters() {   // iterations per captured graph (a graph launch has a cost of its own: one iteration per graph

@@ -238,7 +238,9 @@ __global__ __launch_bounds__(256) void column_stats_kernel(const float *__restri
 
 // Fixed-order reduction of the per-workgroup partials -> (2, LD) sums.
 __global__ __launch_bounds__(256) void stats_reduce_kernel(const double *__restrict__ blockstats, int nblocks, int LD,
-                                                          double *__restrict__ stats) {
+                                                          double *__restrict__ stats,
+                                                          uint64_t *__restrict__ iter_bump = nullptr /* replayed iterations on the unfused paths: the device's iteration counter (stats_fix_kernel moves it on the fused path) */) {
+    if (iter_bump && blockIdx.x == 0 && threadIdx.x == 0) *iter_bump += 1;
     const int c = blockIdx.x;  // column of the (2*LD) record
     double s = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x) s += blockstats[(int64_t)c * nblocks + b];
@@ -893,7 +895,7 @@ gh_status gh_launch_integrate(gh_engine *h) {
     gh_scope t(h, "stats_reduce");
     if (h->LD <= 16) {
         stats_reduce_kernel<<<dim3(2 * h->LD), dim3(256), 0, h->stream>>>(h->d_blockstats, h->nblocks_update, h->LD,
-                                                                          h->d_stats);
+                                                                          h->d_stats, h->graph_capturing ? h->d_iter : nullptr);
     } else {
         column_stats_kernel<<<dim3(h->D), dim3(256), 0, h->stream>>>(h->d_new, h->rows, h->D, h->LD, h->d_stats);
     }
