@@ -583,28 +583,45 @@ __global__ __launch_bounds__(64) void knn_select_wave_kernel(const uint64_t *__r
 // follows.  (A reservation per query was 16 K returning atomics on one address: 180 us of a 206 us launch.)
 __global__ __launch_bounds__(1024) void knn_touched_prefix_kernel(const int32_t *__restrict__ tq_count, int S, int32_t *__restrict__ tq_base,
                                                                   int32_t *__restrict__ tcount) {
-    __shared__ int part[1024];
+    // query q = round * 1024 + t: consecutive threads read consecutive counts; a wave scans its 64 values with shuffles,
+    // the 16 wave totals are scanned by every thread from LDS, the running offset carries over the rounds (the first form
+    // -- a strided chunk per thread, a twenty-barrier scan -- took 26 us at 16 K queries)
+    __shared__ int wtot[16];
     __shared__ int base0;
-    const int t = threadIdx.x;
-    const int per = (S + 1023) / 1024;
-    int sum = 0;
-    for (int i = 0; i < per; ++i) { const int q = t * per + i; sum += q < S ? tq_count[q] : 0; }
-    part[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int total = 0;
+    for (int r0 = 0; r0 < S; r0 += 1024) total += r0 + t < S ? tq_count[r0 + t] : 0;   // (first pass: the grand total)
+    {
+        int v = total;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) wtot[w] = v;
     }
-    if (t == 1023) base0 = part[1023] > 0 ? atomicAdd(tcount, part[1023]) : 0;
     __syncthreads();
-    int at = base0 + part[t] - sum;
-    for (int i = 0; i < per; ++i) {
-        const int q = t * per + i;
-        if (q >= S) break;
-        tq_base[q] = at;
-        at += tq_count[q];
+    if (t == 0) {
+        int sum = 0;
+        for (int i = 0; i < 16; ++i) sum += wtot[i];
+        base0 = sum > 0 ? atomicAdd(tcount, sum) : 0;
+    }
+    __syncthreads();
+    int carry = base0;
+    for (int r0 = 0; r0 < S; r0 += 1024) {
+        const int q = r0 + t;
+        const int c = q < S ? tq_count[q] : 0;
+        int incl = c;   // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        __syncthreads();   // wtot of the previous round has been read by everyone
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        int before = 0, round_total = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { before += i < w ? wtot[i] : 0; round_total += wtot[i]; }
+        if (q < S) tq_base[q] = carry + before + incl - c;
+        carry += round_total;
     }
 }
 __global__ __launch_bounds__(256) void knn_touched_copy_kernel(int32_t *__restrict__ tq_count, const int32_t *__restrict__ tq_base,
