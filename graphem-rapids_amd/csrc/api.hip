@@ -128,8 +128,8 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
                              !getenv("GRAPHEM_HIP_KNN");
     if (h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID && h->prm.knn_method != GH_KNN_IVF) {   // AUTO (and anything unknown)
         // exact methods only.  Whole graph, up to 8 components, thousands of queries: the inverted file in its exact mode
-        // (rr1m, scan / exact IVF us per iteration: D = 3 S = 4096 1089 / 612, 16384 3730 / 793 (grid 2074); D = 6 S = 16384
-        // 5114 / 1460; D = 8 5177 / 2179; 100 K vertices D = 3 S = 4096 383 / 195; profiles/r03/knn_method_sweep.log); else the
+        // (rr1m, scan / exact IVF us per iteration: D = 3 S = 4096 1063 / 591, 16384 3691 / 766 (grid 1926); D = 6 S = 16384
+        // 5059 / 1401; D = 8 5264 / 2135; 100 K vertices D = 3 S = 4096 384 / 191; profiles/r03/knn_method_sweep.log); else the
         // grid for <= 3 components from 12288 queries on; else the scan
         const bool ivf = !part && params->knn_distance == GH_DIST_EXACT && D >= 2 && D <= 8 && h->S >= (D <= 4 ? 4096 : 8192) && E >= 262144;
         h->prm.knn_method = ivf ? GH_KNN_IVF : (D <= 3 && h->S >= 12288) ? GH_KNN_GRID : GH_KNN_SCAN;

@@ -90,8 +90,8 @@ typedef struct {
  *                tau >= the (k+1)-th smallest distance, the lists whose centroid lies within sqrt(tau) + min(list radius,
  *                sqrt(tau) + distance to the query's nearest centroid) -- and the rows are those of SCAN, id for id.  A few
  *                lists per query up to 4 components, a few dozen at 6, most of them beyond 8 (then it costs a scan plus the
- *                index).  rr1m, SCAN / exact IVF us per iteration: D = 3 S = 4096 1089 / 612, 16384 3730 / 793 (GRID 2074);
- *                D = 6 S = 4096 1497 / 968, 16384 5114 / 1460; D = 8 S = 16384 5177 / 2179; D = 16 S = 16384 9009 / 6708.
+ *                index).  rr1m, SCAN / exact IVF us per iteration: D = 3 S = 4096 1063 / 591, 16384 3691 / 766 (GRID 1926);
+ *                D = 6 S = 4096 1507 / 915, 16384 5059 / 1401; D = 8 S = 16384 5264 / 2135; D = 16 S = 16384 8827 / 6677.
  *   GH_KNN_AUTO  exact methods only: engines with 2-8 components, GH_DIST_EXACT, >= 262144 (own) edges and thousands of
  *                queries (sample_size >= 4096 up to 4 components, >= 8192 for 5-8) take IVF in its exact mode; else GRID when
  *                n_components <= 3 and sample_size >= 12288; else SCAN. */
