@@ -86,7 +86,7 @@ static void free_all(gh_engine *h) {
     gh_ivf_free(h);
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_sel_redo, h->d_tq_count, h->d_tq_base, h->d_tq_touched, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rare, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_sel_redo, h->d_tq_count, h->d_tq_base, h->d_tq_touched, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rare, h->d_cd_rows, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -1068,8 +1068,9 @@ extern "C" gh_status gh_knn_cdist_stats(gh_handle h, int32_t *full_pass_rows, in
     GH_TRY(check_handle(h));
     int32_t rare = 0, stat = 0;
     if (h->cdist && h->d_rare) {
-        GH_HIP(hipMemcpyAsync(&rare, h->d_rare, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        GH_HIP(hipMemcpyAsync(&stat, h->d_cd_stat, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        const int32_t *hdr = h->d_cd_stat + 4 * (h->cd_set ^ 1);   // the counters of the last search
+        GH_HIP(hipMemcpyAsync(&rare, hdr, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        GH_HIP(hipMemcpyAsync(&stat, hdr + 1, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
         GH_HIP(hipStreamSynchronize(h->stream));
         if (!gh_knn_scan_path(h)) rare = (int32_t)h->S;   // a graph too small for the filtered scan: every row
     }

@@ -1,0 +1,920 @@
+// GH_DIST_CDIST: neighbour rows as the reference's PyTorch-CPU backend gets them from torch.cdist + torch.topk
+// (pt.py:580-583), value for value and tie for tie.
+//
+// What ATen computes (PyTorch 2.10, ATen/native/Distance.cpp _euclidean_dist, taken for p = 2 when either side has more
+// than 25 rows; ATen/native/TopKImpl.h topk_impl_loop) -- tests/test_oracle_reference_fullsize.py pins
+// oracle/aten_cdist_topk.cpp, the CPU statement of the same, against the reference's own ids at 100 K and 1 M vertices:
+//     |x|^2 = sum over d of fl(x_d * x_d), added left to right;
+//     acc = fma(-2 q_d, m_d, acc) for d = 0 .. D-1 from 0;  acc = fl(acc + |q|^2);  acc = fl(acc + |m|^2);
+//     value = sqrt(max(acc, 0));
+//     topk = std::partial_sort of (value, index) pairs in index order with a comparator on the value alone (K * 64 <= E):
+//     equal values come out in the order the heap leaves them, which depends on every element that ever entered it.
+// The fp32 quantum of acc is ulp(|q|^2 + |m|^2): near neighbours whose exact distances differ by less swap or tie, and
+// the sampled edge's own value is not 0, so column 0 -- dropped blindly, pt.py:417-421 -- need not be the edge itself.
+//
+// How the engine gets there without an (S, E) matrix:
+//   1. the filtered scan runs unchanged with a threshold for K + 1 neighbours: the candidate list of a query holds every
+//      edge whose EXACT squared distance (fma chain) is <= tau;
+//   2. knn_select_cdist_kernel re-values the few hundred candidates with the formula above (two row gathers each),
+//      extracts the K + 1 smallest (value, id) keys and PROVES the list complete for cdist's ranking: an edge outside
+//      has exact distance > tau, hence acc > tau (1 - (7D + 15) u) - 3 (3D + 6) u |q|^2, u = 2^-24 (derivation at
+//      cdist_lower_bound); if the (K+1)-th smallest value clears that bound and the K + 1 values are pairwise
+//      different, the row is decided: ascending values, no heap order involved.  Such a row's k candidate pairs go
+//      through the intersection phase in the same launch (single-rank steps);
+//   3. the other rows -- a tie among the K + 1 smallest values (about one row in a hundred at a million vertices), or a
+//      list that could not be proven complete -- are LISTED and get partial_sort's heap replayed.  Element i enters the
+//      heap iff value_i < (K-th smallest of values 0 .. i-1), a bound that only falls with i.  Round 4: that bound is
+//      used twice so that the replay never sees more than a sliver of the E values (round 3 valued all E edges for every
+//      listed row -- 86 us of gathers at a million vertices -- and one wave walked them for 188 us):
+//        a. the candidate list already holds every edge with a safely small value; sorted by id, its K-th member sits at
+//           id P - 1 (about E K / |list| = E / stride): from id P on the heap's maximum is <= the largest of those K
+//           values, which clears the bound of (2), so every element that enters from P on IS in the list.  The select
+//           workgroup of a listed row finds P and bucket-sorts the list's tail (ids >= P) by id, in place;
+//        b. cdist_prefix_kernel values only the ids below P (chip-wide; minima per 64 ids on the side);
+//        c. cdist_replay_kernel (one workgroup per listed row; wave 0 replays, all four waves fetch) walks the prefix --
+//           skipping 64-id chunks whose minimum cannot enter, the live ones staged through LDS 128 at a time -- then
+//           the sorted tail, pops the heap into ascending order and runs the row's intersection phase.  K <= 64: the heap
+//           lives one element per lane and an element enters in ONE data-parallel step (children through ds_bpermute,
+//           the sift path through v_readlane, every lane on the path deciding for itself): ~0.1 us instead of ~0.3.
+//      A row whose list overflowed or could not be proven complete takes P = E (no tail): the round-3 full pass.
+//   EVERY row of a graph too small for the scan takes (b) + (c) with P = E.
+//   Rows of graphs with K * 64 > E (tiny ones) are ranked by std::nth_element + std::sort in ATen; their values are
+//   computed as above and equal values ordered by id, counted in gh_knn_cdist_stats when a tie is present.
+#include "common.h"
+#include "engine.h"
+#include "scan_core.h"
+#include "select_core.h"
+
+#include <algorithm>
+#include <math.h>
+
+namespace {
+
+#define GH_CD_TILE 4096    /* chunk minima staged in LDS at a time (cdist_replay_kernel) */
+#define GH_CD_BATCH 128    /* live chunks fetched together */
+#define GH_CD_ALT 8192     /* a listed row's id-keyed copy of its candidate list starts here (lists of <= 8192 keys) */
+#define GH_CD_NB 1024      /* buckets of the tail sort */
+#define GH_CD_TAIL_LDS 1024 /* tail keys the replay keeps in LDS */
+
+struct cdist_args {
+    const float *pos;          // (n, LD) rows
+    const int32_t *edges;      // (E, 2)
+    int D, LD;
+    int64_t E;
+    const float *qt;           // query records (scan_core.h gh_qs): coordinates, then tau
+    int QS, QT;
+    int mm_form;               // ATen's matmul form (S > 25 or E > 25), else its direct kernel: sqrt of the exact-difference sum
+};
+
+// The listed rows: slot t < hdr[0] is query rare[1 + t]; ids [0, P[t]) are valued by cdist_prefix_kernel, the ct[t]
+// candidates from P[t] on sit sorted by id at cand[q * GH_CAND_CAP + GH_CD_ALT ..] as (id << 32 | value bits).
+struct cdist_rows {
+    int32_t *rare;   // [1 .. S] (slot t at rare[1 + t])
+    int32_t *P;      // (S)
+    int32_t *ct;     // (S)
+    // Counters of this search: [0] listed rows, [1] rows with a tie that ATen's nth_element path decides, [2] max P over
+    // the slots.  Two sets, used alternately: a search zeroes the OTHER set (cdist_prefix_kernel) for the next one, so no
+    // memset sits in the stream (each was a 4 us fill kernel plus its launch gap; two per iteration).
+    int32_t *hdr, *hdr_next;
+};
+
+// |x|^2 as x.pow(2).sum(-1) rounds it: every square on its own, added left to right.
+__device__ __forceinline__ float cdist_norm(const float *x, int D) {
+    float s = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float sq = x[d] * x[d];
+        s = s + sq;
+    }
+    return s;
+}
+
+// The value of pair (query q with |q|^2 = qn, edge e).  LDT: the row stride at compile time (4, 8, 16: vector row
+// loads) or 0 (any stride, scalar loads).  Padding coordinates are 0 on both sides and change nothing
+// (fma(-0, 0, acc) == acc, s + 0 == s), the loops stop at D all the same.
+template <int LDT>
+__device__ __forceinline__ float cdist_pair(const cdist_args &a, const float *q, float qn, int64_t e) {
+    const int2 uv = reinterpret_cast<const int2 *>(a.edges)[e];
+    float s = 0.0f, acc = 0.0f;
+    if constexpr (LDT > 0) {
+        float pu[LDT], pv[LDT];
+        gh_load_row<LDT>(a.pos, uv.x, pu);
+        gh_load_row<LDT>(a.pos, uv.y, pv);
+#pragma unroll
+        for (int d = 0; d < LDT; ++d) {
+            if (d < a.D) {
+                const float m = (pu[d] + pv[d]) / 2.0f;   // pt.py:785
+                if (a.mm_form) {
+                    const float sq = m * m;
+                    s = s + sq;
+                    acc = fmaf(q[d] * -2.0f, m, acc);
+                } else {
+                    const float t = q[d] - m;
+                    acc = fmaf(t, t, acc);
+                }
+            }
+        }
+    } else {
+        const float *pu = a.pos + (int64_t)uv.x * a.LD, *pv = a.pos + (int64_t)uv.y * a.LD;
+        for (int d = 0; d < a.D; ++d) {
+            const float m = (pu[d] + pv[d]) / 2.0f;
+            if (a.mm_form) {
+                const float sq = m * m;
+                s = s + sq;
+                acc = fmaf(q[d] * -2.0f, m, acc);
+            } else {
+                const float t = q[d] - m;
+                acc = fmaf(t, t, acc);
+            }
+        }
+    }
+    if (a.mm_form) {
+        acc = acc + qn;   // the matmul's last two terms: fma(|q|^2, 1, acc), fma(1, |m|^2, acc)
+        acc = acc + s;
+    }
+    return sqrtf(fmaxf(acc, 0.0f)) + 0.0f;   // clamp_min(0).sqrt(); + 0: a -0 must not read as the largest key
+}
+
+// Lower bound of acc for every edge whose exact-chain squared distance exceeds tau.  With u = 2^-24, reals starred:
+//   computed norms: |qn - qn*| <= D u qn*, same for the midpoint; the D + 2 roundings of the accumulation are each
+//   <= u times a partial result <= 2 (qn* + mn*):   acc >= d2* - (3D + 4) u (qn* + mn*)   -- c = 3D + 6 below;
+//   the exact chain: d2_fl <= d2* (1 + (D + 3) u), so d2_fl > tau gives d2* > tau (1 - (D + 3) u);
+//   mn* <= 2 qn* + 2 d2*:   acc >= d2* (1 - 2 c u) - 3 c u qn*  >  tau (1 - (2c + D + 3) u) - 3 c u qn*,
+// and qn* <= qn (1 + 2 D u).  Evaluated in double with a further percent of slack.
+__device__ __forceinline__ double cdist_lower_bound(float tau, float qn, int D) {
+    const double u = 5.9604644775390625e-08, c = 3.0 * D + 6.0;
+    return (double)tau * (1.0 - 1.01 * (2.0 * c + D + 3.0) * u) - 3.05 * c * u * (double)qn;
+}
+// A value w whose square clears the bound: every edge OUTSIDE the candidate list has acc > bound >= w^2 (1 + 1e-6), hence a
+// value more than four ulps above w.
+__device__ __forceinline__ bool cdist_clears(float w, double bound) { return (double)w * (double)w * (1.0 + 1e-6) <= bound; }
+
+// One workgroup per query: candidate list (exact d2 <= tau) -> the K smallest cdist keys when the list proves enough
+// (then also the query's intersection phase, ia.pos != null); else the row is listed for the replay, with its prefix
+// length P and its tail sorted by id.  Workgroups past the S queries reduce the fused kernel's column sums (nblocks > 0).
+template <int DT>
+__global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, int K,
+                                                               cdist_args a, uint64_t *__restrict__ out_keys,
+                                                               int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
+                                                               cdist_rows rr, inter_args ia, int S,
+                                                               const double *__restrict__ blockstats, int nblocks,
+                                                               double *__restrict__ stats) {
+    constexpr int LDT = DT <= 4 ? 4 : DT <= 8 ? 8 : 16;
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t best2[GH_EXTRACT_MAX_K];
+    __shared__ uint64_t red[4 * GH_EXTRACT_MAX_K];
+    __shared__ float qs[16];
+    __shared__ gh_pair_list pairs;
+    __shared__ int bc[GH_CD_NB], bf[GH_CD_NB];
+    __shared__ uint64_t tl[1024];
+    __shared__ int wsum[4], s_bk, s_tail0;
+    const int Ks = K + 1;
+    const int64_t qi = blockIdx.x;
+    if (qi >= S) {
+        gh_reduce_stats_column(blockstats, nblocks, (int)(qi - S), stats, reinterpret_cast<double *>(red));
+        return;
+    }
+    uint64_t *list = cand + qi * GH_CAND_CAP;
+    // the first 1024 list slots are fetched before the list's length is known (as knn_select_kernel does)
+    uint64_t pre[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pre[j] = list[j * 256 + threadIdx.x];
+    const int c = cnt[qi * GH_CNT_STRIDE];
+    if (threadIdx.x < 16) qs[threadIdx.x] = (int)threadIdx.x < a.D ? a.qt[qi * a.QS + threadIdx.x] : 0.0f;
+    __syncthreads();
+    if (threadIdx.x == 0) { cnt[qi * GH_CNT_STRIDE] = 0; dbg_cnt[qi] = c; }
+    const float qn = cdist_norm(qs, a.D);
+    const double bound = cdist_lower_bound(a.qt[qi * a.QS + a.QT], qn, a.D);
+    int reason = (c > GH_CAND_CAP || c < Ks) ? 2 : 0;   // the list overflowed, or tau was not a bound for K + 1 edges
+    const bool in_regs = c <= 1024 && Ks <= 16;          // the usual case: re-valued keys never leave the registers
+    uint64_t keep[4] = {GH_KEY_INF, GH_KEY_INF, GH_KEY_INF, GH_KEY_INF};
+    if (!reason) {
+        if (in_regs) {
+            uint64_t keys[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j * 256 + (int)threadIdx.x < c) {
+                    const uint32_t id = gh_key_id(pre[j]);
+                    keep[j] = gh_key(cdist_pair<LDT>(a, qs, qn, id), id);
+                }
+                keys[j] = keep[j];
+            }
+            block_extract_smallest<4>(keys, Ks, best, red);
+        } else {
+            for (int i = threadIdx.x; i < c; i += 256) {
+                const uint32_t id = gh_key_id(list[i]);
+                list[i] = gh_key(cdist_pair<LDT>(a, qs, qn, id), id);
+            }
+            __syncthreads();
+            block_extract_list(list, c, Ks, best, best2, red);
+        }
+        int bad = 0;
+        for (int i = threadIdx.x; i + 1 < Ks; i += 256) bad |= (uint32_t)(best[i] >> 32) == (uint32_t)(best[i + 1] >> 32) ? 1 : 0;
+        if (threadIdx.x == 0 && !cdist_clears(gh_key_d2(best[Ks - 1]), bound)) bad |= 2;   // the (K+1)-th smallest VALUE (a distance, not squared)
+        // 1: a tie among the K + 1 smallest values, 2: the list is not provably complete (3: both)
+        reason = (__syncthreads_or(bad & 1) ? 1 : 0) | (__syncthreads_or(bad & 2) ? 2 : 0);
+    }
+    if (!reason) {
+        for (int i = threadIdx.x; i < K; i += 256) out_keys[qi * K + i] = best[i];
+        if (ia.pos) intersect_query<DT>(ia, qi, best, &pairs);
+        return;
+    }
+    // ---- a listed row ----
+    // Histogram of the candidates' ids over GH_CD_NB equal id ranges (low half of a counter: all of them, high half: those
+    // that do not clear the bound); P = the end of the first range by which K clearing candidates have been seen; the
+    // candidates of the later ranges are the tail, put in id order: start of the range + rank inside it (by counting).
+    // Lists of up to 1024 keys (the usual case) never leave the registers / LDS until the sorted tail is stored.
+    int64_t P = a.E;
+    int ct = 0;
+    if (reason == 1 && c <= GH_CD_ALT) {
+        uint64_t *alt = list + GH_CD_ALT;
+        const uint32_t W = (uint32_t)((a.E + GH_CD_NB - 1) / GH_CD_NB);
+        for (int i = threadIdx.x; i < GH_CD_NB; i += 256) bc[i] = 0;
+        if (threadIdx.x == 0) s_bk = -1;
+        __syncthreads();
+        auto file = [&](uint64_t key) {   // -> (id << 32 | value bits), counted in its range
+            const float v = gh_key_d2(key);
+            const uint32_t id = gh_key_id(key);
+            atomicAdd(&bc[id / W], cdist_clears(v, bound) ? 1 : 0x10001);
+            return ((uint64_t)id << 32) | __float_as_uint(v);
+        };
+        uint64_t mine[4] = {0ull, 0ull, 0ull, 0ull};
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j * 256 + (int)threadIdx.x < c) mine[j] = file(keep[j]);
+        } else {
+            for (int i = threadIdx.x; i < c; i += 256) alt[i] = file(list[i]);
+        }
+        __syncthreads();
+        int a4[4], s = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a4[u] = bc[4 * threadIdx.x + u]; s += a4[u]; }   // (both halves at once: neither passes 8192)
+        int incl = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if ((int)(threadIdx.x & 63) >= off) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        int run = incl - s;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int excl = run;
+            run += a4[u];
+            if ((excl & 0xFFFF) - (excl >> 16) < K && (run & 0xFFFF) - (run >> 16) >= K) { s_bk = 4 * threadIdx.x + u; s_tail0 = run & 0xFFFF; }
+            bc[4 * threadIdx.x + u] = excl & 0xFFFF;
+            bf[4 * threadIdx.x + u] = excl & 0xFFFF;
+        }
+        __syncthreads();
+        const int bk = s_bk;
+        if (bk >= 0) {
+            const int tail0 = s_tail0;
+            P = std::min<int64_t>(a.E, (int64_t)(bk + 1) * W);
+            ct = c - tail0;
+            if (in_regs) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int b = (int)((uint32_t)(mine[j] >> 32) / W);
+                    if (j * 256 + (int)threadIdx.x < c && b > bk) tl[atomicAdd(&bf[b], 1) - tail0] = mine[j];
+                }
+                __syncthreads();
+                for (int p = threadIdx.x; p < ct; p += 256) {
+                    const uint64_t key = tl[p];
+                    const int b = (int)((uint32_t)(key >> 32) / W);
+                    const int s0 = bc[b] - tail0, s1 = (b + 1 < GH_CD_NB ? bc[b + 1] : c) - tail0;
+                    int r = s0;
+                    for (int q = s0; q < s1; ++q) r += tl[q] < key ? 1 : 0;
+                    alt[r] = key;
+                }
+            } else {
+                for (int i = threadIdx.x; i < c; i += 256) {
+                    const uint64_t key = alt[i];
+                    const int b = (int)((uint32_t)(key >> 32) / W);
+                    if (b > bk) list[atomicAdd(&bf[b], 1) - tail0] = key;
+                }
+                __syncthreads();
+                for (int p = threadIdx.x; p < ct; p += 256) {
+                    const uint64_t key = list[p];
+                    const int b = (int)((uint32_t)(key >> 32) / W);
+                    const int s0 = bc[b] - tail0, s1 = (b + 1 < GH_CD_NB ? bc[b + 1] : c) - tail0;
+                    int r = s0;
+                    for (int q = s0; q < s1; ++q) r += list[q] < key ? 1 : 0;
+                    alt[r] = key;
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        const int slot = atomicAdd(&rr.hdr[0], 1);
+        rr.rare[1 + slot] = (int32_t)qi;
+        rr.P[slot] = (int32_t)P;
+        rr.ct[slot] = ct;
+        atomicMax(&rr.hdr[2], (int32_t)P);
+        ovf[qi] = reason;
+    }
+}
+
+// ---- values of the listed rows' prefixes -----------------------------------------------------------------------------
+// Workgroup x takes the ids [x * CH, (x + 1) * CH), CH = 256 * NPT (then x + gridDim.x, ... while below the longest
+// prefix), gathers their midpoints once (registers) and loops over the rows of this round that reach that far
+// (t = r0 + blockIdx.y, step gridDim.y): vbuf[slot][e] = value, cmin[slot][c] = the minimum over ids [64 c, 64 (c + 1)) --
+// one wave's 64 consecutive ids.
+template <int LDT, int NPT>
+__global__ __launch_bounds__(256) void cdist_prefix_kernel(cdist_args a, cdist_rows rr, int all_rows, int r0, int R,
+                                                           float *__restrict__ vbuf, int64_t vstride, float *__restrict__ cmin,
+                                                           int nchunks) {
+    constexpr int CH = 256 * NPT;
+    constexpr int LM = LDT > 0 ? LDT : 1;
+    constexpr int QW = LDT > 0 ? 16 : 1;
+    // the records of this workgroup's rows (query coordinates, prefix length) come in first, all at once, before the
+    // number of listed rows is known (slots exist for every t < S): per row they were two dependent round trips
+    __shared__ float qsh[256][QW];
+    __shared__ int64_t psh[256];
+    __shared__ int64_t qish[256];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4) rr.hdr_next[threadIdx.x] = 0;   // the next search's counters
+    const int nrare = all_rows ? all_rows : rr.hdr[0];
+    const int64_t Pmax = all_rows ? a.E : (int64_t)rr.hdr[2];
+    const int t_end = min(nrare, r0 + R);
+    if (r0 + (int)blockIdx.y >= t_end || (int64_t)blockIdx.x * CH >= Pmax) return;
+    const int lane = threadIdx.x & 63;
+    float m[NPT][LM], mn[NPT];
+    auto midpoints = [&](int64_t e0) __attribute__((always_inline)) {   // midpoints of this thread's ids from e0 on, and their norms
+        if constexpr (LDT > 0) {
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const int64_t e = e0 + j * 256 + threadIdx.x;
+                const int2 uv = e < a.E ? reinterpret_cast<const int2 *>(a.edges)[e] : make_int2(0, 0);
+                float pu[LDT], pv[LDT];
+                gh_load_row<LDT>(a.pos, uv.x, pu);
+                gh_load_row<LDT>(a.pos, uv.y, pv);
+                float s = 0.0f;
+#pragma unroll
+                for (int d = 0; d < LDT; ++d) {
+                    m[j][d] = d < a.D ? (pu[d] + pv[d]) / 2.0f : 0.0f;
+                    if (d < a.D) {
+                        const float sq = m[j][d] * m[j][d];
+                        s = s + sq;
+                    }
+                }
+                mn[j] = s;
+            }
+        }
+    };
+    // the records of this workgroup's rows (query coordinates, prefix length) come in together, once (per row they were
+    // two dependent round trips), while the first gathers are in flight
+    const int gy = (int)gridDim.y;
+    const int nrow = (t_end - r0 - (int)blockIdx.y + gy - 1) / gy;   // rows r0 + blockIdx.y + i * gy below t_end (<= 256: R <= 256 * gy)
+    for (int i = threadIdx.x; i < nrow * QW; i += 256) {
+        const int row = i / QW, d = i % QW;
+        const int t = r0 + (int)blockIdx.y + row * gy;
+        const int64_t qi = all_rows ? t : rr.rare[1 + t];
+        if constexpr (LDT > 0) qsh[row][d] = d < a.D ? a.qt[qi * a.QS + d] : 0.0f;
+        if (d == 0) { psh[row] = all_rows ? a.E : (int64_t)rr.P[t]; qish[row] = qi; }
+    }
+    midpoints((int64_t)blockIdx.x * CH);
+    __syncthreads();
+    for (int64_t e0 = (int64_t)blockIdx.x * CH; e0 < Pmax; e0 += (int64_t)gridDim.x * CH) {
+        if (e0 != (int64_t)blockIdx.x * CH) midpoints(e0);
+        for (int row = 0, t = r0 + (int)blockIdx.y; t < t_end; ++row, t += gy) {
+            if (psh[row] <= e0) continue;   // (uniform over the workgroup)
+            const int slot = t - r0;
+            float vv[NPT];
+            if constexpr (LDT > 0) {
+                float q[LDT];
+#pragma unroll
+                for (int d = 0; d < LDT; ++d) q[d] = d < 16 ? qsh[row][d] : 0.0f;
+                const float qn = cdist_norm(q, a.D);
+#pragma unroll
+                for (int j = 0; j < NPT; ++j) {
+                    const int64_t e = e0 + j * 256 + threadIdx.x;
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < LDT; ++d) {
+                        if (d < a.D) {
+                            if (a.mm_form) acc = fmaf(q[d] * -2.0f, m[j][d], acc);
+                            else { const float df = q[d] - m[j][d]; acc = fmaf(df, df, acc); }
+                        }
+                    }
+                    if (a.mm_form) { acc = acc + qn; acc = acc + mn[j]; }
+                    vv[j] = e < a.E ? sqrtf(fmaxf(acc, 0.0f)) + 0.0f : INFINITY;
+                }
+            } else {   // any dimension: rows read from memory per pair
+                const float *q = a.qt + qish[row] * a.QS;
+                const float qn = cdist_norm(q, a.D);
+#pragma unroll
+                for (int j = 0; j < NPT; ++j) {
+                    const int64_t e = e0 + j * 256 + threadIdx.x;
+                    vv[j] = e < a.E ? cdist_pair<0>(a, q, qn, e) : INFINITY;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const int64_t e = e0 + j * 256 + threadIdx.x;
+                vbuf[(int64_t)slot * vstride + e] = vv[j];
+                float mv = vv[j];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mv = fminf(mv, __shfl_xor(mv, off, 64));
+                if (lane == 0) cmin[(int64_t)slot * nchunks + (e >> 6)] = mv;
+            }
+        }
+    }
+}
+
+// Values are compared as UNSIGNED INTEGERS: a cdist value is +0 or larger (sqrt of a clamped sum, + 0), so the bit patterns
+// order like the numbers; NaN gets one pattern above +inf.  That is exactly the comparator of ATen's topk on values ("x before
+// y" iff x < y or only y is NaN) at one instruction per comparison, and it makes a heap element one 64-bit key
+// (value bits << 32 | id) -- the layout of gh_key.
+__device__ __forceinline__ uint32_t cdist_vkey(float v) { return v != v ? 0x7FC00000u : __float_as_uint(v); }
+__device__ __forceinline__ uint32_t cdist_kv(uint64_t key) { return (uint32_t)(key >> 32); }
+
+// Max-heap with the tie behaviour of libstdc++'s __adjust_heap, which std::partial_sort is built on: the hole at `top`
+// sinks to the bottom along the larger child (the RIGHT one unless it is smaller than the left), then the new element climbs
+// while its parent is smaller.  Three homes for the heap:
+//   cdist_heap_scalar  K <= 16 (n_neighbors <= 15): the keys in SCALAR registers, every index a compile-time constant: the sink
+//                   is a decision tree of s_cmp / s_mov_b64, ~25 scalar instructions per element that enters.  One wave
+//                   issues an instruction every ~4 cycles whatever its kind, so the instruction count IS the time: the
+//                   lane-parallel form below takes ~75 (0.24 us per element measured, 140 elements per row).
+//   cdist_heap_par  K <= 64: element i in lane i's registers; the whole adjustment is ONE data-parallel step.  Every
+//                   lane looks at its two children (ds_bpermute) and knows which one the hole would move to; the path is
+//                   followed through v_readlane (a few scalar steps); along the path the old values w_1 >= w_2 >= ... (heap
+//                   order) end up as: w_(t+1) moved up into position t while it is not below the new value, the new element at
+//                   the first position whose child is below it, the rest untouched -- the same array the sequential form
+//                   leaves, since the climb undoes the sink below the new element's final position.  Also builds the heap
+//                   (make_heap) and pops it (sort_heap) for the scalar form: those run once per row.
+//   cdist_heap_lds  any K: keys in LDS, lane 0 walks (the sequential form as written in libstdc++).
+struct cdist_heap_par {
+    uint64_t key;
+    int lane;
+    __device__ __forceinline__ uint64_t at(int i) const { return readlane_u64(key, i); }
+    __device__ __forceinline__ uint32_t val(int i) const { return (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), i); }
+    __device__ __forceinline__ void set(int i, uint64_t x) { if (lane == i) key = x; }
+    __device__ __forceinline__ void adjust(int top, int len, uint64_t x) {
+        const int c1 = 2 * lane + 1, c2 = 2 * lane + 2;
+        const int lo = (int)(uint32_t)key, hi = (int)(uint32_t)(key >> 32);
+        const uint32_t h1 = (uint32_t)__builtin_amdgcn_ds_bpermute((c1 & 63) << 2, hi);
+        const uint32_t h2 = (uint32_t)__builtin_amdgcn_ds_bpermute((c2 & 63) << 2, hi);
+        const uint32_t l1 = (uint32_t)__builtin_amdgcn_ds_bpermute((c1 & 63) << 2, lo);
+        const uint32_t l2 = (uint32_t)__builtin_amdgcn_ds_bpermute((c2 & 63) << 2, lo);
+        const bool right = c2 < len && !(h2 < h1);
+        const int c = right ? c2 : c1;          // where a hole at this lane moves to (lanes with c1 >= len: nowhere)
+        const uint32_t ch = right ? h2 : h1, cl = right ? l2 : l1;
+        unsigned long long path = 0ull;
+        for (int p = top;;) {                   // (scalar: p comes from v_readlane)
+            path |= 1ull << p;
+            if (2 * p + 1 >= len) break;
+            p = __builtin_amdgcn_readlane(c, p);
+        }
+        const uint32_t xv = cdist_kv(x);
+        const bool on = (path >> lane) & 1ull;
+        const bool up = on && c1 < len && !(ch < xv);                          // my child on the path moves up into me
+        const bool mine = on && !up && (lane == top || !((uint32_t)hi < xv));  // the new element stops here
+        if (up) key = ((uint64_t)ch << 32) | cl;
+        else if (mine) key = x;
+    }
+    __device__ __forceinline__ void make_heap(int K) {
+        for (int parent = (K - 2) / 2; parent >= 0; --parent) adjust(parent, K, at(parent));
+    }
+    __device__ __forceinline__ void sort_heap(int K) {   // pops the heap into ascending order
+        for (int last = K - 1; last > 0; --last) {
+            const uint64_t x = at(last);
+            set(last, at(0));
+            adjust(0, last, x);
+        }
+    }
+};
+
+#define GH_CD_KS 16
+// (value and id apart, 32 bits each: a comparison of the high halves of two packed 64-bit keys is widened by the compiler to
+// a 64-bit comparison, which the scalar unit does not have)
+struct cdist_heap_scalar {
+    uint32_t v[GH_CD_KS], id[GH_CD_KS];
+    // __push_heap: the hole at J climbs while it is below `top` in the tree and its parent is smaller than the new element
+    template <int J>
+    __device__ __forceinline__ void climb(int top, uint32_t xv, uint32_t xid) {
+        if constexpr (J == 0) {
+            v[0] = xv; id[0] = xid;
+        } else {
+            constexpr int PJ = (J - 1) / 2;
+            if (J > top && v[PJ] < xv) { v[J] = v[PJ]; id[J] = id[PJ]; climb<PJ>(top, xv, xid); }
+            else { v[J] = xv; id[J] = xid; }
+        }
+    }
+    // __adjust_heap with the hole at I (a compile-time index), heap length len <= GH_CD_KS
+    template <int I>
+    __device__ __forceinline__ void sink(int top, int len, uint32_t xv, uint32_t xid) {
+        if constexpr (2 * I + 2 < GH_CD_KS) {
+            if (2 * I + 2 < len) {   // two children: the right one unless it is smaller than the left
+                if (v[2 * I + 2] < v[2 * I + 1]) { v[I] = v[2 * I + 1]; id[I] = id[2 * I + 1]; sink<2 * I + 1>(top, len, xv, xid); }
+                else { v[I] = v[2 * I + 2]; id[I] = id[2 * I + 2]; sink<2 * I + 2>(top, len, xv, xid); }
+                return;
+            }
+        }
+        if constexpr (2 * I + 1 < GH_CD_KS) {
+            if (2 * I + 1 < len) {   // a single child (len even): it moves up, the hole ends there
+                v[I] = v[2 * I + 1]; id[I] = id[2 * I + 1];
+                climb<2 * I + 1>(top, xv, xid);
+                return;
+            }
+        }
+        climb<I>(top, xv, xid);
+    }
+    __device__ __forceinline__ void load(const cdist_heap_par &hp) {
+#pragma unroll
+        for (int i = 0; i < GH_CD_KS; ++i) {
+            v[i] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hp.key >> 32), i);
+            id[i] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hp.key, i);
+        }
+    }
+    __device__ __forceinline__ void store(cdist_heap_par &hp) const {
+        uint32_t hv = v[0], hi = id[0];
+#pragma unroll
+        for (int i = 1; i < GH_CD_KS; ++i) { hv = hp.lane == i ? v[i] : hv; hi = hp.lane == i ? id[i] : hi; }
+        hp.key = ((uint64_t)hv << 32) | hi;
+    }
+    __device__ __forceinline__ void replace_max(int K, uint32_t xv, uint32_t xid) { sink<0>(0, K, xv, xid); }
+    __device__ __forceinline__ uint32_t top() const { return v[0]; }
+};
+struct cdist_heap_lds {
+    uint64_t *hk;
+    int lane;
+    __device__ __forceinline__ uint64_t at(int i) const { return hk[i]; }
+    __device__ __forceinline__ uint32_t val(int i) const { return cdist_kv(hk[i]); }
+    // one wave works on the heap: its LDS operations complete in program order; the compiler must not reorder them
+    __device__ __forceinline__ void sync() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ void set(int i, uint64_t x) { if (lane == 0) hk[i] = x; sync(); }
+    __device__ __forceinline__ void adjust(int hole, int len, uint64_t x) {
+        const int top = hole;
+        int child = hole;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (val(child) < val(child - 1)) --child;
+            set(hole, at(child));
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            set(hole, at(child - 1));
+            hole = child - 1;
+        }
+        int parent = (hole - 1) / 2;
+        while (hole > top && val(parent) < cdist_kv(x)) {
+            set(hole, at(parent));
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        set(hole, x);
+    }
+    __device__ __forceinline__ void make_heap(int K) {
+        for (int parent = (K - 2) / 2; parent >= 0; --parent) adjust(parent, K, at(parent));
+    }
+    __device__ __forceinline__ void sort_heap(int K) {
+        for (int last = K - 1; last > 0; --last) {
+            const uint64_t x = at(last);
+            set(last, at(0));
+            adjust(0, last, x);
+        }
+    }
+};
+
+// One workgroup per listed row: std::partial_sort(first, first + K, last) over the (value, index) pairs in index order.
+// The first K pairs are heapified; then pair i enters (replacing the maximum) iff value_i < maximum -- so a chunk whose
+// minimum is not below the current maximum holds nothing that would enter and is skipped -- over the valued prefix
+// [0, P), then over the id-sorted tail of the candidate list; finally the heap is popped into ascending order.  Wave 0 owns
+// the heap (its steps are uniform over the wave; the lanes pre-test 64 values at a time); all four waves fetch.
+// HEAP: 0 = scalar registers (K <= 16), 1 = lanes (K <= 64), 2 = LDS.
+// nth_form (K * 64 > E): ATen ranks with std::nth_element + std::sort instead; the K smallest values are the same,
+// equal values are put in id order here and the row is counted in hdr[1] when any tie is present.
+// INTER: the row's k candidate pairs go through the intersection phase (pt.py:638-774) right here.
+template <int DT, int HEAP, bool INTER>
+__global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int all_rows, int r0, int R, int64_t E, int K,
+                                                          const float *__restrict__ vbuf, int64_t vstride,
+                                                          const float *__restrict__ cmin, int nchunks,
+                                                          const uint64_t *__restrict__ cand, uint64_t *__restrict__ out_keys,
+                                                          int nth_form, inter_args ia,
+                                                          unsigned long long *__restrict__ stamps /* diagnostic (GRAPHEM_HIP_STAMPS), or null */) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];   // the LDS heap (HEAP == 2)
+    __shared__ float cml[GH_CD_TILE];
+    __shared__ float stage[GH_CD_BATCH * 64];
+    __shared__ int live_ids[GH_CD_BATCH];
+    __shared__ int s_nlive;
+    __shared__ uint64_t tail_lds[GH_CD_TAIL_LDS];
+    const int t = r0 + (int)blockIdx.x;
+    // (slot records are read before the count is known: they exist for every t < S)
+    const int nrare = all_rows ? all_rows : rr.hdr[0];
+    const int64_t qi = all_rows ? t : rr.rare[1 + t];
+    const int64_t P = all_rows ? E : (int64_t)rr.P[t];
+    const int ct = all_rows ? 0 : rr.ct[t];
+    if (t >= min(nrare, r0 + R)) return;
+    const float *v = vbuf + (int64_t)(t - r0) * vstride;
+    const float *cm = cmin + (int64_t)(t - r0) * nchunks;
+    const uint64_t *tl = cand + qi * GH_CAND_CAP + GH_CD_ALT;
+    const int lane = threadIdx.x & 63;
+    // (a scalar condition: what wave 0 keeps across the kernel -- the heap above all -- then lives in scalar registers)
+    const bool wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+    // diagnostic: 16 records per slot -- wall clock (100 MHz) at start, heap built, prefix done, tail done, sorted, end;
+    // then batches, elements entered, chunks processed, P, tail length
+    if (stamps) stamps += (int64_t)t * 32;
+    int n_batches = 0, n_entered = 0, n_chunks = 0;
+#define GH_CD_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+    GH_CD_STAMP(0);
+    if (!wave0)   // the tail comes in while wave 0 builds the heap (read behind the barriers of the prefix loop)
+        for (int i = (int)threadIdx.x - 64; i < min(ct, GH_CD_TAIL_LDS); i += 192) tail_lds[i] = tl[i];
+    // the heap: built in the lane form (or in LDS); the scalar form takes it over for the replay
+    using wide_t = typename std::conditional<HEAP == 2, cdist_heap_lds, cdist_heap_par>::type;
+    wide_t hw;
+    cdist_heap_scalar hs;
+    hw.lane = lane;
+    uint32_t hmax = 0xFFFFFFFFu;
+    uint32_t eq_out = 0xFFFFFFFFu;   // nth_form: a value left outside the heap while equal to its maximum (boundary tie if it stays so)
+    if (wave0) {
+        if constexpr (HEAP == 2) {
+            hw.hk = reinterpret_cast<uint64_t *>(smem_raw);
+            for (int i = lane; i < K; i += 64) hw.hk[i] = ((uint64_t)cdist_vkey(v[i]) << 32) | (uint32_t)i;
+            hw.sync();
+        } else {
+            hw.key = ((uint64_t)(lane < K ? cdist_vkey(v[lane]) : 0xFFFFFFFFu) << 32) | (uint32_t)lane;
+        }
+        if (K >= 2) hw.make_heap(K);
+        if constexpr (HEAP == 0) hs.load(hw);
+        hmax = hw.val(0);
+    }
+    GH_CD_STAMP(1);
+    // "may hold an element that enters": minimum below the maximum (nth_form: or equal to it, for the boundary-tie count)
+    auto live = [&](float mv) { const uint32_t mk = cdist_vkey(mv); return nth_form ? !(hmax < mk) : mk < hmax; };
+    // 64 pairs (lane l: value key x, id xid, `in` = to be considered): in lane (= index) order, whatever still beats the maximum enters
+    auto process = [&](uint32_t x, int32_t xid, bool in) __attribute__((always_inline)) {
+        if (nth_form && __ballot(in && x == hmax)) eq_out = hmax;
+        unsigned long long mask = __ballot(in && x < hmax);
+        while (mask) {   // every lane of the mask holds a value below the maximum of this moment
+            const int l = __builtin_ctzll(mask);
+            const uint32_t ev = (uint32_t)__builtin_amdgcn_readlane((int)x, l), eid = (uint32_t)__builtin_amdgcn_readlane(xid, l);
+            // std::__pop_heap(first, middle, i): the maximum leaves, the new element sinks in from the root
+            const uint32_t old = hmax;
+            if constexpr (HEAP == 0) { hs.replace_max(K, ev, eid); hmax = hs.top(); }
+            else { hw.adjust(0, K, ((uint64_t)ev << 32) | eid); hmax = hw.val(0); }
+            ++n_entered;
+            if (nth_form && old == hmax) eq_out = hmax;   // one of several equal maxima was popped: it now waits outside
+            const unsigned long long later = l == 63 ? 0ull : ~((2ull << l) - 1ull);
+            mask = __ballot(in && x < hmax) & later;
+            if (nth_form && (__ballot(in && x == hmax) & later)) eq_out = hmax;
+        }
+    };
+    // ---- the valued prefix: chunk minima through LDS, GH_CD_TILE at a time; the chunks that are live under the maximum of the
+    // moment are listed (up to GH_CD_BATCH), fetched by all four waves into LDS -- every thread's loads issued together: a
+    // load per loop trip was a memory round trip per trip, most of this kernel's first version -- and processed in order,
+    // each re-tested (64 minima per ballot) against the maximum of its moment
+    const int nch = (int)((P + 63) >> 6);
+    for (int tile0 = (K >> 6) / GH_CD_TILE * GH_CD_TILE; tile0 < nch; tile0 += GH_CD_TILE) {
+        const int nt = min(GH_CD_TILE, nch - tile0);
+        __syncthreads();
+        {
+            float tmp[GH_CD_TILE / 256];
+#pragma unroll
+            for (int u = 0; u < GH_CD_TILE / 256; ++u) tmp[u] = u * 256 + (int)threadIdx.x < nt ? cm[tile0 + u * 256 + threadIdx.x] : INFINITY;
+#pragma unroll
+            for (int u = 0; u < GH_CD_TILE / 256; ++u) cml[u * 256 + threadIdx.x] = tmp[u];
+        }
+        __syncthreads();
+        int p = max(0, (K >> 6) - tile0);   // next chunk of the tile to look at (wave 0)
+        for (;;) {
+            if (wave0) {
+                int nl = 0;
+                while (p < nt && nl < GH_CD_BATCH) {
+                    const int b = p & ~63;
+                    const unsigned long long m = __ballot(b + lane < nt && live(cml[b + lane])) & (~0ull << (p - b));
+                    const int room = GH_CD_BATCH - nl;
+                    const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    const bool take = ((m >> lane) & 1ull) && rank < room;
+                    if (take) live_ids[nl + rank] = b + lane;
+                    const int have = __builtin_popcountll(m);
+                    if (have > room) {   // the batch is full: go on behind the last chunk taken
+                        const unsigned long long tk = __ballot(take);
+                        p = b + 64 - __builtin_clzll(tk);
+                        nl = GH_CD_BATCH;
+                    } else {
+                        nl += have;
+                        p = b + 64;
+                    }
+                }
+                if (lane == 0) s_nlive = nl;
+            }
+            __syncthreads();
+            const int nl = s_nlive;
+            if (nl == 0) break;
+            if (stamps && threadIdx.x == 0 && n_batches < 4) stamps[16 + 4 * n_batches] = wall_clock64();
+            ++n_batches;
+            {
+                constexpr int PT = GH_CD_BATCH * 64 / 256;   // values per thread of a full batch
+                float tmp[PT];
+#pragma unroll
+                for (int u = 0; u < PT; ++u) {
+                    const int i = u * 256 + (int)threadIdx.x;
+                    tmp[u] = i < nl * 64 ? v[((int64_t)(tile0 + live_ids[i >> 6]) << 6) + (i & 63)] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < PT; ++u) stage[u * 256 + threadIdx.x] = tmp[u];
+            }
+            __syncthreads();
+            if (stamps && threadIdx.x == 0 && n_batches <= 4) stamps[16 + 4 * (n_batches - 1) + 1] = wall_clock64();
+            if (wave0) {
+                // (the ids and minima of 64 listed chunks in registers; the values of the next live chunk are requested from
+                // LDS before the current one is processed: two dependent LDS round trips per chunk were a third of its cost)
+                for (int rb = 0; rb < nl; rb += 64) {
+                    const int my_c = rb + lane < nl ? live_ids[rb + lane] : 0;
+                    const float mv = rb + lane < nl ? cml[my_c] : INFINITY;
+                    unsigned long long m = __ballot(rb + lane < nl && live(mv));
+                    int r = m ? __builtin_ctzll(m) : 0;
+                    float xn = stage[(rb + r) * 64 + lane];
+                    while (m) {
+                        ++n_chunks;
+                        const float x = xn;
+                        const int64_t base = (int64_t)(tile0 + __builtin_amdgcn_readlane(my_c, r)) << 6;
+                        const unsigned long long later = r == 63 ? 0ull : ~((2ull << r) - 1ull);
+                        const int r2 = (m & later) ? __builtin_ctzll(m & later) : r;   // the next one as things stand
+                        xn = stage[(rb + r2) * 64 + lane];
+                        process(cdist_vkey(x), (int32_t)(base + lane), base + lane >= K && base + lane < P);
+                        m = __ballot(rb + lane < nl && live(mv)) & later;
+                        if (!m) break;
+                        r = __builtin_ctzll(m);
+                        if (r != r2) xn = stage[(rb + r) * 64 + lane];   // the maximum fell below that chunk's minimum meanwhile
+                    }
+                }
+            }
+            if (stamps && threadIdx.x == 0 && n_batches <= 4) { stamps[16 + 4 * (n_batches - 1) + 2] = wall_clock64(); stamps[16 + 4 * (n_batches - 1) + 3] = nl; }
+            __syncthreads();
+        }
+    }
+    GH_CD_STAMP(2);
+    // ---- the tail of the candidate list, sorted by id: (id << 32 | value bits)
+    if (wave0 && ct > 0) {
+        uint64_t nxt = lane < ct ? tail_lds[lane] : 0ull;   // (ct > GH_CD_TAIL_LDS: the rest straight from memory)
+        for (int b0 = 0; b0 < ct; b0 += 64) {
+            const uint64_t tk = nxt;
+            const int i = b0 + 64 + lane;
+            nxt = i >= ct ? 0ull : i < GH_CD_TAIL_LDS ? tail_lds[i] : tl[i];
+            process(cdist_vkey(__uint_as_float((uint32_t)tk)), (int32_t)(tk >> 32), b0 + lane < ct);
+        }
+    }
+    GH_CD_STAMP(3);
+    __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    if (wave0) {
+        if constexpr (HEAP == 0) hs.store(hw);
+        hw.sort_heap(K);   // std::sort_heap: ascending
+        if (nth_form) {
+            bool tie = eq_out == hw.val(K - 1);
+            for (int i = 0; i + 1 < K; ++i) tie = tie || hw.val(i) == hw.val(i + 1);
+            if (tie) {
+                if (lane == 0) atomicAdd(&rr.hdr[1], 1);
+                for (int i = 1; i < K; ++i) {   // equal values in id order (insertion sort within runs)
+                    const uint64_t x = hw.at(i);
+                    int j = i;
+                    while (j > 0 && hw.val(j - 1) == cdist_kv(x) && (uint32_t)hw.at(j - 1) > (uint32_t)x) { hw.set(j, hw.at(j - 1)); --j; }
+                    hw.set(j, x);
+                }
+            }
+        }
+        if constexpr (HEAP == 2) {
+            for (int i = lane; i < K; i += 64) out_keys[qi * K + i] = hw.hk[i];
+        } else {
+            if (lane < K) {
+                out_keys[qi * K + lane] = hw.key;
+                if (INTER) best[lane] = hw.key;
+            }
+        }
+    }
+    GH_CD_STAMP(4);
+    if constexpr (INTER) {
+        static_assert(HEAP != 2, "the fused intersection phase reads the keys of a register heap");
+        __shared__ gh_pair_list pairs;
+        __syncthreads();
+        if (ia.pos) intersect_query<DT>(ia, qi, best, &pairs);
+    }
+    GH_CD_STAMP(5);
+    if (stamps && threadIdx.x == 0) {
+        stamps[6] = n_batches; stamps[7] = n_entered; stamps[8] = n_chunks; stamps[9] = (unsigned long long)P; stamps[10] = ct;
+    }
+#undef GH_CD_STAMP
+}
+
+cdist_args make_cdist_args(gh_engine *h) {
+    return cdist_args{h->d_pos, h->d_edges, h->D, h->LD, h->E, h->d_q, gh_qs(h->D, h->LD), gh_qtau(h->D, h->LD),
+                      (h->S > 25 || h->E > 25) ? 1 : 0};
+}
+
+template <typename T>
+gh_status cdist_dev_alloc(gh_engine *h, T **p, size_t count) {
+    if (hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) {
+        *p = nullptr;
+        h->err = "hipMalloc failed (GH_DIST_CDIST buffers)";
+        return GH_ERR_NOMEM;
+    }
+    return GH_OK;
+}
+
+int64_t cdist_vstride(const gh_engine *h) { return (h->E + 1023) / 1024 * 1024; }   // whole workgroups of cdist_prefix_kernel
+
+}  // namespace
+
+// Buffers of the replay: values of up to cd_R listed rows (at most 4 GiB if every one of them needed all E values; a
+// listed row usually writes E / stride of its slot; more listed rows than cd_R take further rounds of the two kernels --
+// every round is launched, an empty one returns at once).
+gh_status gh_cdist_alloc(gh_engine *h) {
+    if (!h->cdist || h->S == 0 || h->k == 0) return GH_OK;
+    const int64_t vstride = cdist_vstride(h);
+    h->cd_nchunks = (int)(vstride / 64);
+    int64_t R = ((int64_t)1 << 30) / std::max<int64_t>(vstride, 1);
+    if (R < 16) R = 16;
+    if (R > h->S) R = h->S;
+    h->cd_R = (int)R;
+    GH_TRY_ST(cdist_dev_alloc(h, &h->d_rare, (size_t)h->S + 1));
+    GH_TRY_ST(cdist_dev_alloc(h, &h->d_cd_rows, 2 * (size_t)h->S));
+    GH_TRY_ST(cdist_dev_alloc(h, &h->d_cd_vbuf, (size_t)(R * vstride)));
+    GH_TRY_ST(cdist_dev_alloc(h, &h->d_cd_cmin, (size_t)(R * h->cd_nchunks)));
+    GH_TRY_ST(cdist_dev_alloc(h, &h->d_cd_stat, 8));
+    GH_HIP(hipMemsetAsync(h->d_rare, 0, sizeof(int32_t) * ((size_t)h->S + 1), h->stream));
+    GH_HIP(hipMemsetAsync(h->d_cd_rows, 0, sizeof(int32_t) * 2 * (size_t)h->S, h->stream));
+    GH_HIP(hipMemsetAsync(h->d_cd_stat, 0, sizeof(int32_t) * 8, h->stream));
+    return GH_OK;
+}
+
+// all_rows: the graph is too small for the filtered scan -- every query is replayed over all edges.  Otherwise the
+// candidate lists of the scan are in place.  -> d_partial (S, K): the reference's rows, column 0 included.
+// fuse_intersect (single-rank steps, K <= 64): the same launches run the intersection phase of every query they finish
+// and reduce the fused kernel's column sums (h->intersect_done / h->stats_reduced tell the caller).
+gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows, bool fuse_intersect) {
+    const cdist_args a = make_cdist_args(h);
+    const int set = h->cd_set;
+    h->cd_set ^= 1;
+    const cdist_rows rr{h->d_rare, h->d_cd_rows, h->d_cd_rows + h->S, h->d_cd_stat + 4 * set, h->d_cd_stat + 4 * (set ^ 1)};
+    const bool fuse = !all_rows && fuse_intersect && h->K <= 64 && h->D >= 2 && h->D <= 16;
+    bool reduce = false;
+    if (!all_rows) {
+        if (h->D < 2 || h->D > 16) { h->err = "GH_DIST_CDIST: the candidate selection needs 2..16 components"; return GH_ERR_RUNTIME; }
+        // the column sums of the fused kernel's workgroup partials ride along (stats_fix_kernel then skips them)
+        reduce = h->new0_ready && h->rows > 0 && h->LD <= 16 && h->S < 2048;
+        gh_scope t(h, fuse ? "knn_select_cdist_intersect" : "knn_select_cdist");
+        const inter_args ia = make_inter_args(h, fuse);
+#define GH_CSEL(DD)                                                                                                                \
+    knn_select_cdist_kernel<DD><<<dim3((unsigned)h->S + (reduce ? 2u * (unsigned)h->LD : 0u)), dim3(256), 0, h->stream>>>(          \
+        h->d_cand, h->d_cnt, h->K, a, h->d_partial, h->d_ovf, h->d_dbg_cnt + h->S, rr, ia, (int)h->S, h->d_blockstats, h->n_vblocks, \
+        h->d_stats)
+        switch (h->D) {
+            case 2: GH_CSEL(2); break;   case 3: GH_CSEL(3); break;   case 4: GH_CSEL(4); break;   case 5: GH_CSEL(5); break;
+            case 6: GH_CSEL(6); break;   case 7: GH_CSEL(7); break;   case 8: GH_CSEL(8); break;   case 9: GH_CSEL(9); break;
+            case 10: GH_CSEL(10); break; case 11: GH_CSEL(11); break; case 12: GH_CSEL(12); break; case 13: GH_CSEL(13); break;
+            case 14: GH_CSEL(14); break; case 15: GH_CSEL(15); break; default: GH_CSEL(16); break;
+        }
+#undef GH_CSEL
+        GH_LAUNCH_CHECK();
+    }
+    const int64_t vstride = cdist_vstride(h);
+    const int nth_form = (int64_t)h->K * 64 > h->E ? 1 : 0;
+    const int all = all_rows ? (int)h->S : 0;
+    const int npt = h->E >= (1 << 16) ? 4 : 1;   // ids per thread of cdist_prefix_kernel
+    const unsigned nwg = (unsigned)((h->E + 256 * npt - 1) / (256 * npt));
+    const unsigned gx = std::min(nwg, 1024u);
+    // rows of a round are spread over gridDim.y so that the chip is filled, and so that a workgroup takes at most 256 of them
+    const unsigned ys = (unsigned)std::max({1, std::min(h->cd_R, 1024 / (int)std::max(gx, 1u)), (h->cd_R + 255) / 256});
+    for (int r0 = 0; r0 < (int)h->S; r0 += h->cd_R) {
+        {
+            gh_scope t(h, "cdist_prefix");
+            const dim3 grid(gx, ys);
+#define GH_CPRE(LL, NP) cdist_prefix_kernel<LL, NP><<<grid, dim3(256), 0, h->stream>>>(a, rr, all, r0, h->cd_R, h->d_cd_vbuf, vstride, \
+                                                                                       h->d_cd_cmin, h->cd_nchunks)
+            if (npt == 4) {
+                if (h->LD == 4) GH_CPRE(4, 4); else if (h->LD == 8) GH_CPRE(8, 4); else if (h->LD == 16) GH_CPRE(16, 4); else GH_CPRE(0, 4);
+            } else {
+                if (h->LD == 4) GH_CPRE(4, 1); else if (h->LD == 8) GH_CPRE(8, 1); else if (h->LD == 16) GH_CPRE(16, 1); else GH_CPRE(0, 1);
+            }
+#undef GH_CPRE
+            GH_LAUNCH_CHECK();
+        }
+        gh_scope t(h, fuse ? "cdist_replay_intersect" : "cdist_replay");
+        const size_t smem = h->K <= 64 ? 0 : sizeof(uint64_t) * (size_t)h->K;
+        const inter_args ia = make_inter_args(h, fuse);
+#define GH_CREP(DD, HEAPv, INTv) cdist_replay_kernel<DD, HEAPv, INTv><<<dim3((unsigned)h->cd_R), dim3(256), smem, h->stream>>>( \
+        rr, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride, h->d_cd_cmin, h->cd_nchunks, h->d_cand, h->d_partial, nth_form, ia, h->d_stamps)
+#define GH_CREP_D(DD) case DD: if (h->K <= GH_CD_KS) GH_CREP(DD, 0, true); else GH_CREP(DD, 1, true); break;
+        if (fuse) {
+            switch (h->D) {
+                GH_CREP_D(2) GH_CREP_D(3) GH_CREP_D(4) GH_CREP_D(5) GH_CREP_D(6) GH_CREP_D(7) GH_CREP_D(8) GH_CREP_D(9)
+                GH_CREP_D(10) GH_CREP_D(11) GH_CREP_D(12) GH_CREP_D(13) GH_CREP_D(14) GH_CREP_D(15)
+                default: if (h->K <= GH_CD_KS) GH_CREP(16, 0, true); else GH_CREP(16, 1, true); break;
+            }
+        } else if (h->K <= GH_CD_KS) {
+            GH_CREP(0, 0, false);
+        } else if (h->K <= 64) {
+            GH_CREP(0, 1, false);
+        } else {
+            GH_CREP(0, 2, false);
+        }
+#undef GH_CREP_D
+#undef GH_CREP
+        GH_LAUNCH_CHECK();
+    }
+    h->intersect_done = fuse;
+    h->stats_reduced = reduce;
+    return GH_OK;
+}

@@ -135,14 +135,15 @@ struct gh_engine {
     uint64_t *d_merged = nullptr; // (S, K) keys merged over the ranks (world > 1)
     const uint64_t *d_keys_cur = nullptr;  // keys the intersection phase reads: d_partial or d_merged
 
-    // GH_DIST_CDIST (cdist_core.h): the reference's cdist + topk values and tie order
+    // GH_DIST_CDIST (cdist.hip): the reference's cdist + topk values and tie order
     bool cdist = false;
     int Ksel = 0;                     // keys the candidate selection extracts: K, or K + 1 with cdist (boundary ties)
-    int32_t *d_rare = nullptr;        // [0] = count, [1..S] = queries that need the pass over all edges
-    float *d_cd_vbuf = nullptr;       // (cd_R, cd_nchunks * cd_CH) cdist values of those queries against every edge
-    float *d_cd_cmin = nullptr;       // (cd_R, cd_nchunks) minimum of each chunk of cd_CH edge ids
-    int32_t *d_cd_stat = nullptr;     // [0] rows whose tie order ATen leaves to std::nth_element (not reproduced)
-    int cd_R = 0, cd_CH = 0, cd_nchunks = 0;
+    int32_t *d_rare = nullptr;        // [1..S] = the listed queries: partial_sort's heap is replayed for them
+    int32_t *d_cd_rows = nullptr;     // (2, S) per listed slot: prefix length P (ids below it are valued), tail length
+    float *d_cd_vbuf = nullptr;       // (cd_R, cd_nchunks * 64) cdist values of those queries against the edges below P
+    float *d_cd_cmin = nullptr;       // (cd_R, cd_nchunks) minimum of each chunk of 64 edge ids
+    int32_t *d_cd_stat = nullptr;     // two sets (used alternately) of [0] listed rows, [1] rows whose tie order ATen leaves to std::nth_element (not reproduced), [2] the longest prefix
+    int cd_R = 0, cd_nchunks = 0, cd_set = 0;   // cd_set: the counter set the NEXT search uses
 
     // grid KNN (grid.hip; GH_KNN_GRID)
     int grid_G = 0, grid_bits = 0;
@@ -212,9 +213,9 @@ gh_tau_args gh_make_tau_args(gh_engine *h);  // tau_core.h
 gh_status gh_knn_finish(gh_engine *h, bool have_mid, bool fuse_intersect);
 gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq, const float *d_ref, int64_t nref,
                                int D, int K, uint64_t *d_keys, std::string *err);
-// cdist_core.h (knn.hip)
+// cdist.hip
 gh_status gh_cdist_alloc(gh_engine *h);
-gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows);   // candidate lists (or nothing) -> d_partial, the reference's rows
+gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows, bool fuse_intersect);   // candidate lists (or nothing) -> d_partial, the reference's rows
 // grid.hip
 bool gh_grid_path(const gh_engine *h);
 gh_status gh_grid_alloc(gh_engine *h);
