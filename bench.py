@@ -133,6 +133,44 @@ def cpu_baseline(n, D, k, S, edges, pos, budget_s=24.0):
             "torch_cpu": legs["torch_cpu"]}
 
 
+def parity_mode(args, n, D, k, S, edges, pos, device_id):
+    """The same K steps on an engine in the mode whose neighbour rows ARE the reference's (knn_distance='cdist': torch.cdist's
+    values, torch.topk's tie order, pt.py:580-583; ids drawn on the host like torch.randperm's, before the timed region):
+    median of the same number of passes, per-kernel HIP-event durations from a further pass."""
+    from graphem_rapids_amd import _native
+    E = len(edges)
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, device_id=device_id, knn_distance="cdist")
+    eng.set_positions(pos)
+    rng = np.random.default_rng(3)
+    stream = np.stack([rng.permutation(E)[:S] for _ in range(max(args.steps, args.warmup))]).astype(np.int32) if S < E else None
+    run = lambda iters: eng.run(iters, None if stream is None else stream[:iters])
+    run(args.warmup)
+    passes = []
+    for _ in range(max(1, args.repeats)):
+        eng.sync()
+        t0 = time.perf_counter()
+        run(args.steps)
+        eng.sync()
+        passes.append(time.perf_counter() - t0)
+    dt = sorted(passes)[len(passes) // 2]
+    listed = []
+    eng.timing_enable(True)
+    eng.timing_reset()
+    run(args.steps)
+    eng.sync()
+    timings = eng.timings()
+    eng.timing_enable(False)
+    for _ in range(8):   # how many rows get partial_sort's heap replayed (ties among the k + 2 smallest values)
+        eng.step(None if stream is None else stream[0])
+        listed.append(int(eng.knn_cdist_stats()[0]))
+    eng.close()
+    return {"knn_distance": "cdist", "sampler": "host", "value": args.steps / dt, "unit": "iterations/s",
+            "ms_per_step": 1e3 * dt / args.steps, "ms_per_step_passes": [1e3 * p / args.steps for p in passes],
+            "replayed_rows_per_step_sample": listed,
+            "kernels": {name: {"avg_us": 1e3 * tot / cnt, "launches_per_step": cnt / args.steps}
+                        for name, (tot, cnt) in sorted(timings.items(), key=lambda kv: -kv[1][0])}}
+
+
 def self_launch(args):
     """One rank per GPU through torch.distributed.run, supervised: the child's JSON line is passed through; a native-loop
     attempt that fails or hangs is ended (its whole process group) and repeated with the Python-driven loop."""
@@ -181,6 +219,7 @@ def main():
     ap.add_argument("--workload", default="rr1m", choices=sorted(WORKLOADS))
     ap.add_argument("--sampler", default="device", choices=["device", "host"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the parity_mode sub-record (the same steps with knn_distance='cdist')")
     ap.add_argument("--sample-size", type=int, default=None, help="override the workload's number of sampled midpoints")
     ap.add_argument("--knn", default="auto", choices=["auto", "scan", "grid", "ivf"],
                     help="KNN search (gh_params.knn_method); ivf is approximate (recall: tools/ivf_probe.py)")
@@ -339,6 +378,8 @@ def main():
             out["rank0_us_per_step"] = {"kernels": comp, "collectives": coll,
                                         "loop": "gh_run_partitioned (C library, RCCL all-gathers on the engine's stream)"
                                         if getattr(lay, "native", False) else "python-driven (torch.distributed)"}
+        if world == 1 and not use_dist and args.knn_distance == "exact" and not args.no_parity_mode:
+            out["parity_mode"] = parity_mode(args, n, D, k, S, edges, pos, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, D, k, S, edges, pos)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -124,8 +124,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     h->prm = *params;
     h->k = params->n_neighbors; h->K = h->k + 1;
     h->S = std::min<int64_t>(params->sample_size, E);
-    const bool auto_method = h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID && h->prm.knn_method != GH_KNN_IVF &&
-                             !getenv("GRAPHEM_HIP_KNN");
+    const bool auto_method = h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID && h->prm.knn_method != GH_KNN_IVF;
     if (h->prm.knn_method != GH_KNN_SCAN && h->prm.knn_method != GH_KNN_GRID && h->prm.knn_method != GH_KNN_IVF) {   // AUTO (and anything unknown)
         // exact methods only.  Whole graph, up to 8 components, thousands of queries: the inverted file in its exact mode
         // (rr1m, scan / exact IVF us per iteration: D = 3 S = 4096 1063 / 591, 16384 3691 / 766 (grid 1926); D = 6 S = 16384
@@ -135,11 +134,14 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
         h->prm.knn_method = ivf ? GH_KNN_IVF : (D <= 3 && h->S >= 12288) ? GH_KNN_GRID : GH_KNN_SCAN;
         if (ivf) { h->prm.ivf_probes = -1; h->prm.ivf_lists = 0; }
     }
-    if (const char *e = getenv("GRAPHEM_HIP_KNN")) h->prm.knn_method = atoi(e) == GH_KNN_GRID ? GH_KNN_GRID : atoi(e) == GH_KNN_IVF ? GH_KNN_IVF : GH_KNN_SCAN;  // A/B runs
     if (params->knn_distance != GH_DIST_EXACT && params->knn_distance != GH_DIST_CDIST) { delete h; return fail(GH_ERR_INVALID, "unknown knn_distance"); }
     h->cdist = params->knn_distance == GH_DIST_CDIST;
     if (h->cdist && part) { delete h; return fail(GH_ERR_INVALID, "knn_distance = GH_DIST_CDIST needs the whole graph on one engine (no gh_partition)"); }
-    if (h->cdist) h->prm.knn_method = GH_KNN_SCAN;   // the grid search knows exact distances only
+    if (h->cdist && !auto_method && params->knn_method != GH_KNN_SCAN) {   // (an explicit request must not be dropped silently)
+        delete h;
+        return fail(GH_ERR_INVALID, "knn_distance = GH_DIST_CDIST re-values the candidates of GH_KNN_SCAN: it cannot be combined with GH_KNN_GRID / GH_KNN_IVF");
+    }
+    if (h->cdist) h->prm.knn_method = GH_KNN_SCAN;   // AUTO: the other searches know exact distances only
     h->Ksel = h->K + (h->cdist ? 1 : 0);
     if (part) h->part = *part;
     else h->part = gh_partition{0, n, 0, E, GH_EDGES_RANGE};
@@ -157,7 +159,11 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(GH_ERR_HIP); }
     h->stream = h->own_stream;
     h->pos_rows = n + GH_POS_PAD_ROWS;
-    h->force_unfused = getenv("GRAPHEM_HIP_UNFUSED") != nullptr;  // A/B switch for profiling and tests
+    // Diagnostic switches, read once here (include/graphem_hip.h lists them): GRAPHEM_HIP_NO_PRESETUP keeps the next
+    // iteration's KNN set-up out of the normalise launch (so that per-query flags survive a step for inspection),
+    // GRAPHEM_HIP_GRAPH=1 replays iterations from a hipGraph.
+    h->opt_no_presetup = getenv("GRAPHEM_HIP_NO_PRESETUP") != nullptr;
+    { const char *e = getenv("GRAPHEM_HIP_GRAPH"); h->opt_graph = e && atoi(e) != 0; }
 
     // Internal vertex order (include/graphem_hip.h GH_REORDER_*): breadth-first numbers, components in
     // order of their smallest vertex, children in pull-list (= edge id) order.
@@ -199,11 +205,9 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
             // walk their pull lists in lock-step, so a wave costs its LONGEST list.  G(n, p) at 1 M vertices (Poisson
             // degrees, mean 10): fused kernel 172.5 -> 163 us with blocks of 8 K - 32 K rows, 168 with 256, 170 - 172 with
             // 256 K or the whole graph (the breadth-first locality is gone); a regular graph is left as it is (stable sort).
-            // GRAPHEM_HIP_DEGSORT = block size (0: off).
             {
-                int64_t B = 16384;
-                if (const char *e = getenv("GRAPHEM_HIP_DEGSORT")) B = atol(e);
-                if (B > 1) {
+                const int64_t B = 16384;
+                {
                     std::vector<int32_t> inv((size_t)n);
                     for (int64_t v = 0; v < n; ++v) inv[(size_t)h->order_host[(size_t)v]] = (int32_t)v;
                     for (int64_t b0 = 0; b0 < n; b0 += B) {
@@ -426,7 +430,11 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_qscan, S * (size_t)(h->LD + 4), true);
     GH_A(d_qA, S * 16, true);
     GH_A(d_qexact, S + 1, true);
-    GH_A(d_cand, scan_path ? S * GH_CAND_CAP : 1, false);
+    if ((st = dev_alloc(h, &h->d_cand, scan_path ? S * GH_CAND_CAP : 1, false)) != GH_OK) {
+        h->err = "hipMalloc of the KNN candidate lists failed: sample_size = " + std::to_string(h->S) + " needs " +
+                 std::to_string((S * GH_CAND_CAP * sizeof(uint64_t)) >> 20) + " MiB (128 KiB per sampled midpoint)";
+        return bail(st);
+    }
     GH_A(d_cnt, S * GH_CNT_STRIDE, true);
     GH_A(d_ovf, S, true);
     GH_A(d_sel_redo, S, true);
@@ -545,6 +553,7 @@ static gh_status check_device_waits(gh_engine *h) {
         GH_HIP(hipStreamSynchronize(h->stream));
         h->tau_embedded = false;
         if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // captured with the other form
+        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
         h->err = "a workgroup of the fused spring+scan launch timed out waiting for the thresholds of its own launch; "
                  "results since the last successful gh_sync / gh_get_positions are invalid -- set the positions again. "
                  "The engine now computes the thresholds in a launch of their own (as GRAPHEM_HIP_TAU_SEPARATE=1 does); "
@@ -648,7 +657,7 @@ static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
         GH_TRY(gh_ivf_search(h));
         return gh_knn_finish(h, true, fuse_intersect);
     }
-    if (h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused) {
+    if (h->fused_scan && gh_knn_scan_path(h)) {
         GH_TRY(gh_knn_prepare(h));
         if (!h->tau_embedded) GH_TRY(gh_knn_thresholds(h));   // else: the first workgroups of the fused launch (tau_core.h)
         GH_TRY(gh_launch_spring_scan(h));
@@ -670,8 +679,7 @@ static gh_status step_merge(gh_engine *h, const uint64_t *gathered, int world) {
 // gh_knn_prepare falls back to its own kernel when the next step turns out different.
 static gh_status step_finish(gh_engine *h, int next_mode = -1, int32_t *next_ids = nullptr) {
     const bool presetup = next_mode >= 0 && h->rows == h->n && !h->d_gbuf && gh_knn_scan_path(h) &&
-                          ((h->fused_scan && !h->force_unfused) || gh_grid_path(h) || gh_ivf_path(h)) && h->S > 0 && h->k > 0 &&
-                          !getenv("GRAPHEM_HIP_NO_PRESETUP");
+                          (h->fused_scan || gh_grid_path(h) || gh_ivf_path(h)) && h->S > 0 && h->k > 0 && !h->opt_no_presetup;
     GH_TRY(gh_launch_normalise(h, true, presetup, next_mode, next_ids));  // also zeroes what the intersection phase touched
     h->iter += 1;
     return GH_OK;
@@ -727,20 +735,13 @@ static gh_status run_one_device_sampled(gh_engine *h) {
 static bool graph_replay_applies(gh_engine *h) {
     // the fused path, or the inverted-file path (its ~18 launches and memsets per iteration: the device counter is moved on
     // by stats_reduce_kernel there)
-    const bool path = gh_ivf_path(h) || (h->fused_scan && !h->force_unfused && !gh_grid_path(h));
+    const bool path = gh_ivf_path(h) || (h->fused_scan && !gh_grid_path(h));
     return whole_graph(h) && !h->d_gbuf && !h->g_world && !h->cdist && !h->timing && !h->d_stamps && path &&
            gh_knn_scan_path(h) && h->S > 0 && h->k > 0 && h->K <= 128 && h->LD <= 16 &&
-           getenv("GRAPHEM_HIP_GRAPH") && atoi(getenv("GRAPHEM_HIP_GRAPH")) != 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
+           h->opt_graph && !h->opt_no_presetup;
 }
-static int graph_iters() {   // iterations per captured graph (a graph launch has a cost of its own: one iteration per graph
-                             // was SLOWER than enqueuing, 172.2 against 166.3 us per iteration at 1 M vertices)
-    static int g = 0;
-    if (g == 0) {
-        g = 10;
-        if (const char *e = getenv("GRAPHEM_HIP_GRAPH_ITERS")) g = std::max(1, atoi(e));
-    }
-    return g;
-}
+static int graph_iters() { return 10; }   // iterations per captured graph (a graph launch has a cost of its own: one iteration per
+                                          // graph was SLOWER than enqueuing, 172.2 against 166.3 us per iteration at 1 M vertices)
 // Replays as many whole graphs (graph_iters() iterations each) as fit into `count`; *done = iterations replayed.
 static gh_status graph_replay(gh_engine *h, int32_t count, int32_t *done) {
     *done = 0;
@@ -748,12 +749,12 @@ static gh_status graph_replay(gh_engine *h, int32_t count, int32_t *done) {
     if (count < G) return GH_OK;
     if (!h->graph_exec) {
         // captured from the steady state: the previous launch has done this iteration's set-up (presetup_valid)
-        if (!h->presetup_valid || h->presetup_iter != h->iter) return GH_ERR_RUNTIME;   // (caller falls back to enqueuing)
+        if (!h->presetup_valid || h->presetup_iter != h->iter) { h->err = "graph replay: not in the steady state (enqueuing instead)"; return GH_ERR_RUNTIME; }   // (caller falls back to enqueuing)
         const bool pv = h->presetup_valid, trp = h->tcount_reset_pending;
         const int pm = h->presetup_mode;
         const int32_t *pi = h->presetup_ids;
         const uint64_t it0 = h->iter, pit = h->presetup_iter;
-        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return GH_ERR_RUNTIME; }
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); h->err = "graph replay: hipStreamBeginCapture failed (enqueuing instead)"; return GH_ERR_RUNTIME; }
         h->graph_capturing = true;
         gh_status st = GH_OK;
         for (int g = 0; g < G && st == GH_OK; ++g) st = run_one_device_sampled(h);   // (iteration numbers: offsets to the device counter)
@@ -764,11 +765,13 @@ static gh_status graph_replay(gh_engine *h, int32_t count, int32_t *done) {
         h->iter = it0; h->presetup_valid = pv; h->presetup_mode = pm; h->presetup_ids = pi; h->presetup_iter = pit;
         h->tcount_reset_pending = trp;
         h->new0_ready = false; h->stats_reduced = false; h->intersect_done = false; h->sample_pending = false;
-        if (st != GH_OK || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return GH_ERR_RUNTIME; }
+        if (st != GH_OK || e != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); if (st == GH_OK) h->err = "graph replay: capture failed (enqueuing instead)"; return GH_ERR_RUNTIME; }
         if (hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
             (void)hipGraphDestroy(g); (void)hipGetLastError(); h->graph_exec = nullptr;
+            h->err = "graph replay: hipGraphInstantiate failed (enqueuing instead)";
             return GH_ERR_RUNTIME;
         }
+        if (h->graph) (void)hipGraphDestroy(h->graph);   // (a previous capture whose executable was dropped)
         h->graph = g;
     }
     GH_HIP(hipMemcpyAsync(h->d_iter, &h->iter, sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));

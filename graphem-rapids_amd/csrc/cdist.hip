@@ -807,7 +807,8 @@ template <typename T>
 gh_status cdist_dev_alloc(gh_engine *h, T **p, size_t count) {
     if (hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) {
         *p = nullptr;
-        h->err = "hipMalloc failed (GH_DIST_CDIST buffers)";
+        h->err = "hipMalloc failed (GH_DIST_CDIST buffers: up to min(sample_size, 2^30 / E) rows of E floats; sample_size = " +
+                 std::to_string(h->S) + ", E = " + std::to_string(h->E) + ")";
         return GH_ERR_NOMEM;
     }
     return GH_OK;

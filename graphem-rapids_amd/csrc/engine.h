@@ -79,7 +79,7 @@ struct gh_engine {
     int64_t thr_stride = 0, thr_M1 = 0;  // the subset: every thr_stride-th own edge, thr_M1 of them (0: not chosen yet)
     int32_t *d_vblock = nullptr;  // (n_vblocks + 1) vertex ranges of the fused spring+scan workgroups
     int n_vblocks = 0;
-    bool force_unfused = false;   // GRAPHEM_HIP_UNFUSED set: keep the separate spring / scan kernels
+    bool opt_no_presetup = false, opt_graph = false;   // GRAPHEM_HIP_NO_PRESETUP / GRAPHEM_HIP_GRAPH (read at gh_create)
     bool fused_scan = false;      // fused spring+scan kernel usable for this graph / partition
 
     // state

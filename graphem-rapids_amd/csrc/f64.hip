@@ -397,8 +397,14 @@ static gh_status f64_download(gh_engine *h, const double *d_src, double *host) {
     GH_HIP(hipMemcpyAsync(host, d_src, sizeof(double) * (size_t)h->n * h->D, hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipStreamSynchronize(h->stream));
     int32_t failed = 0;
-    GH_HIP(hipMemcpy(&failed, h->f64->fail, sizeof(failed), hipMemcpyDeviceToHost));
-    if (failed) { h->err = "float64 KNN: more than 1024 midpoints share the float value of the K-th distance"; return GH_ERR_RUNTIME; }
+    GH_HIP(hipMemcpyAsync(&failed, h->f64->fail, sizeof(failed), hipMemcpyDeviceToHost, h->stream));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    if (failed) {   // reported once: the flag is cleared
+        GH_HIP(hipMemsetAsync(h->f64->fail, 0, sizeof(int32_t), h->stream));
+        GH_HIP(hipStreamSynchronize(h->stream));
+        h->err = "float64 KNN: more than 1024 midpoints share the float value of the K-th distance";
+        return GH_ERR_RUNTIME;
+    }
     return GH_OK;
 }
 extern "C" gh_status gh_get_positions_f64(gh_handle h, double *pos) {
@@ -460,8 +466,10 @@ extern "C" gh_status gh_intersection_forces_f64(gh_handle h, const int32_t *samp
         if (knn[i] < 0 || knn[i] >= h->E) { h->err = "neighbour edge id out of range"; return GH_ERR_INVALID; }
     std::vector<int32_t> ids((size_t)h->S);
     for (int64_t i = 0; i < h->S; ++i) ids[(size_t)i] = h->S >= h->E ? (int32_t)i : sampled[i];
-    GH_HIP(hipMemcpy(f->sampled, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice));
-    GH_HIP(hipMemcpy(f->knn, knn, sizeof(int32_t) * (size_t)h->S * h->k, hipMemcpyHostToDevice));
+    // the engine's stream is non-blocking and a run may still be in flight on it, reading and writing these buffers:
+    // everything goes through that stream (the host arrays are done with at the synchronisation of f64_download)
+    GH_HIP(hipMemcpyAsync(f->sampled, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, h->stream));
+    GH_HIP(hipMemcpyAsync(f->knn, knn, sizeof(int32_t) * (size_t)h->S * h->k, hipMemcpyHostToDevice, h->stream));
     GH_HIP(hipMemsetAsync(f->Fi, 0, sizeof(double) * (size_t)h->n * h->D, h->stream));
     f64_intersect_kernel<<<dim3(f64_grid(h->S * h->k)), dim3(256), 0, h->stream>>>(f->pos, h->D, f->edges, f->sampled, f->knn, h->S, h->k,
                                                                                   f->k_inter, f->Fi);

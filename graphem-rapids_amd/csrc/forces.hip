@@ -785,8 +785,7 @@ gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0) {
     if (la.n == 0) return GH_OK;
     gh_scope t(h, "spring_long");
     const float neg_k = -h->prm.k_attr;
-    static const bool two = getenv("GRAPHEM_HIP_LONG_TWO") != nullptr;   // A/B
-    if (!two && h->long_max_deg <= GH_LONG_ONE_LAUNCH_MAX_DEG) {
+    if (h->long_max_deg <= GH_LONG_ONE_LAUNCH_MAX_DEG) {
 #define GH_LONG_FUSED(DD, LL)                                                                                                 \
     case DD:                                                                                                                  \
         long_rows_kernel<DD, LL><<<dim3((unsigned)((la.n + 3) / 4)), dim3(256), 0, h->stream>>>(                                \
@@ -972,9 +971,7 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup, in
     gh_scope t(h, "normalise");
     const int64_t total = h->rows * h->LD / 4;  // float4 elements
     unsigned grid = grid_for(total, 1024);  // four elements per thread and round (normalise_kernel)
-    unsigned cap = 2048;
-    if (const char *e = getenv("GRAPHEM_HIP_NORM_GRID")) cap = (unsigned)std::max(64, atoi(e));
-    if (grid > cap) grid = cap;
+    if (grid > 2048) grid = 2048;
     gh_setup_args sa{};
     unsigned extra = 0;
     if (presetup) {
@@ -1042,8 +1039,7 @@ gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
     gh_scope t(h, "normalise_gathered");
     unsigned grid = grid_for(h->n * h->LD / 4, 256);
     if (grid > 2048) grid = 2048;
-    const bool presetup = next_mode >= 0 && h->fused_scan && gh_knn_scan_path(h) && !h->force_unfused && h->S > 0 &&
-                          h->k > 0 && !getenv("GRAPHEM_HIP_NO_PRESETUP");
+    const bool presetup = next_mode >= 0 && h->fused_scan && gh_knn_scan_path(h) && h->S > 0 && h->k > 0 && !h->opt_no_presetup;
     gh_setup_args sa{};
     unsigned extra = 0;
     if (presetup) {

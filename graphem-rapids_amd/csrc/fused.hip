@@ -21,39 +21,27 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-// Fused-kernel geometry: NT threads x R references per thread = owned edges per workgroup.
-// Measured on the 1M-vertex graph (D = 3): 256x8 225 us, 256x4 197 us -- the smaller tile costs
-// ~18 % more VALU work per pair but halves the LDS per workgroup, so twice as many workgroups
-// are resident and their gather / VALU phases interleave better.
-// GRAPHEM_HIP_FUSED_CFG="NT,R" overrides the LD = 4 default for experiments.
-// Small graphs get smaller tiles so that there are still >= ~1000 workgroups for 256 CUs.
-// Which form of the pre-filter.  The split-f16 MFMA form scans 1024 pairs per matrix instruction; it
-// has the larger footprint (115 VGPRs, 35 KB of LDS against 75 and 22 KB), which costs the spring
-// phase's gathers a wave of occupancy, and wins all the same: 1M vertices, 256 queries: 4410 vs 4300
-// it/s over the first 55 iterations and 4700 vs 4440 in the steady state of a long run
-// (tools/soak_s.py); 100K vertices 10760 vs 9730; 1024 queries 433 vs 566 us per iteration, 4096
-// queries 640 vs 1434 us for the kernel.  4 <= D <= 16 take the wide MFMA form (single-piece f16 operands, scan_core.h):
-// D/2 packed-VALU instructions per pair and lane against one or two matrix instructions per 1024 pairs (1M vertices,
-// D = 12: 818 -> 508 us per iteration).  GRAPHEM_HIP_MFMA=0 selects the packed-VALU form for every D.
+// Fused-kernel geometry: 256 threads x 2 references per thread = tiles of 512 owned edges per workgroup.
+// (Measured on the 1M-vertex graph, D = 3, before the matrix-pipe filter: 256x8 225 us, 256x4 197 us -- a smaller tile costs
+// more filter work per pair but less LDS per workgroup, so more workgroups are resident and their gather / filter phases
+// interleave better.)
+// The pre-filter of phase B runs on the matrix pipe for every fused dimension: split-f16 operands for D <= 3 (1024 pairs per
+// matrix instruction), single-piece f16 operands for 4 <= D <= 16 (scan_core.h).  Against the packed-fp32 VALU form it
+// replaced (rounds 1-2; removed in round 4 together with its GRAPHEM_HIP_MFMA / _FUSED_CFG switches): 1M vertices, 256
+// queries: 4700 vs 4440 it/s in the steady state of a long run; 100K vertices 10760 vs 9730; 1024 queries 433 vs 566 us per
+// iteration, 4096 queries 640 vs 1434 us for the kernel; D = 12: 818 -> 508 us per iteration.
 static bool fused_mfma(int LD, int D, int64_t S) {
     (void)S;
-    if (D > 16 || (LD != 4 && LD != 8 && LD != 16)) return false;   // D <= 3: split form; 4..16: wide form (scan_core.h)
-    if (const char *e = getenv("GRAPHEM_HIP_MFMA")) return atoi(e) != 0;
-    return true;
+    return D <= 16 && (LD == 4 || LD == 8 || LD == 16);   // D <= 3: split form; 4..16: wide form (scan_core.h)
 }
 // operand rows the threshold computation writes: only the split form has any (the wide form builds its rows at staging)
 static int fused_mfma_kb(int LD, int D, int64_t S) { return fused_mfma(LD, D, S) && D <= 3 ? 0 : -1; }
+// Workgroups of 256 threads, R = 2 references per thread: tiles of 512 owned edges (95 VGPRs / 27 KB of LDS for the split
+// form; the wide form keeps the fp32 tile in LDS for the exact checks).
 static void fused_cfg(int LD, int D, int64_t S, int64_t own_edges, int *nt, int *r) {
+    (void)LD; (void)D; (void)S; (void)own_edges;
     *nt = 256;
-    *r = LD <= 4 ? 4 : LD <= 8 ? 4 : 2;
-    if (LD <= 4 && (own_edges < 1500000 || fused_mfma(LD, D, S))) *r = 2;  // MFMA form: 95 VGPRs / 27 KB instead of 115 / 37
-    if (D > 3 && fused_mfma(LD, D, S)) { *r = 2; *nt = 256; }  // wide MFMA form: tiles of 512 (the fp32 tile stays in LDS for the exact checks)
-    if (LD <= 4 && own_edges < 400000 && !fused_mfma(LD, D, S)) *nt = 128;  // the MFMA form needs 256 threads
-    const char *e = getenv("GRAPHEM_HIP_FUSED_CFG");
-    if (e && LD <= 4) {
-        int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && (a == 128 || a == 256) && (b == 2 || b == 4 || b == 8)) { *nt = a; *r = b; }
-    }
+    *r = 2;
 }
 bool gh_fused_uses_mfma(const gh_engine *h) { return h->fused_scan && fused_mfma(h->LD, h->D, h->S); }
 int gh_fused_mfma_kb(const gh_engine *h) { return h->fused_scan ? fused_mfma_kb(h->LD, h->D, h->S) : -1; }
@@ -130,105 +118,6 @@ __device__ __forceinline__ void gh_block_stats(const double (&sx)[LD], const dou
 }
 
 
-template <int D, int LD, int R, int NT, bool LONG>
-__global__ __launch_bounds__(NT) void spring_scan_kernel(
-    const float *__restrict__ pos, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ adj,
-    const int32_t *__restrict__ first_edge, const int32_t *__restrict__ own_eids,
-    const int32_t *__restrict__ vblock, int64_t row_lo, float L_min, float neg_k, float *__restrict__ Fs,
-    float *__restrict__ out_new, double *__restrict__ blockstats, const float *__restrict__ qt,
-    const float *__restrict__ qscan, int S, uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, gh_long_args la,
-    gh_tau_args ta /* nblocks > 0: the first workgroups of the grid compute the thresholds (tau_core.h) */,
-    unsigned long long *__restrict__ stamps /* diagnostic builds of a run only (GRAPHEM_HIP_STAMPS): 8 per workgroup */) {
-    constexpr int TILE = NT * R;
-    if ((int)blockIdx.x < ta.nblocks) {
-        if (blockIdx.y == 0) gh_tau_produce<NT, -1>(ta);
-        return;
-    }
-    const bool coh = ta.nblocks > 0;
-    const int nbx = ta.xcd_tiles > 0 ? ta.xcd_tiles : (int)gridDim.x - ta.nblocks;
-    const int bx = ta.xcd_tiles > 0 ? gh_fused_tile_index((int)blockIdx.x - ta.nblocks, nbx) : (int)blockIdx.x - ta.nblocks;
-    if (bx < 0) return;   // padding workgroup of the XCD-contiguous grid
-#define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + (k)] = wall_clock64(); } while (0)
-    GH_STAMP(0);
-    constexpr int QS = D <= 3 ? 4 : LD + 4;
-    constexpr int HITBUF = TILE * LD * 4 / 16;  // hit records reuse the midpoint tile's LDS
-    __shared__ float4 tile[TILE * LD / 4];
-    __shared__ float4 qsh[(GH_SCAN_QGROUP + 1) * (QS / 4)];
-    __shared__ float taush[GH_SCAN_QGROUP];
-    __shared__ int hcount;
-    float *mids = reinterpret_cast<float *>(tile);
-
-    const int v0 = vblock[bx], v1 = vblock[bx + 1];
-    const int fe0 = first_edge[v0];
-    const int nedges = first_edge[v1] - fe0;
-    if (threadIdx.x == 0) hcount = 0;
-
-    // ---- phase A: spring forces, new0 = pos + Fs, midpoints of the owned edges to LDS
-    // (gridDim.y > 1: few, long workgroups -- small graphs with wide rows -- split the QUERIES over blockIdx.y; every
-    // slice redoes phase A for its tile, slice 0 alone stores its results)
-    __shared__ double red[(NT / 64) * 2 * LD];
-    {
-        double sx[LD], sxx[LD];
-        const bool store = blockIdx.y == 0;
-        gh_phase_a<D, LD, NT, LONG>(pos, rowptr, adj, first_edge, v0, v1, fe0, nedges, row_lo, L_min, neg_k, store ? Fs : nullptr,
-                                    store ? out_new : nullptr, mids, sx, sxx, la, Fs);
-        GH_STAMP(1);
-        gh_block_stats<LD, NT>(sx, sxx, red, store ? blockstats : nullptr, bx, nbx, v1 - v0);  // contains the barrier that ends phase A
-    }
-    GH_STAMP(2);
-
-    // ---- phase B: the tile becomes this workgroup's references
-    gh_f2 m[R / 2][D], c0[R / 2];
-    uint32_t id[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int j = r * NT + threadIdx.x;
-        float mv[LD];
-        if (j < nedges) {
-            gh_load_row<LD>(mids, j, mv);
-            id[r] = own_eids ? (uint32_t)own_eids[fe0 + j] : (uint32_t)(fe0 + j);
-        } else {
-#pragma unroll
-            for (int d = 0; d < LD; ++d) mv[d] = 0.0f;  // padding slot: c0 = +inf never passes the filter
-            id[r] = 0xFFFFFFFFu;
-        }
-        const float c = gh_ref_c0<D>(mv, j < nedges);
-        if (r & 1) c0[r / 2].y = c; else c0[r / 2].x = c;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            if (r & 1) m[r / 2][d].y = mv[d];
-            else m[r / 2][d].x = mv[d];
-        }
-    }
-    if (ta.nblocks > 0 && threadIdx.x == 0) gh_tau_wait(ta);  // thresholds of this launch: out by now, as a rule
-    __syncthreads();  // every thread has its references: the tile's LDS becomes the hit buffer
-    GH_STAMP(3);
-    uint64_t *hkey = reinterpret_cast<uint64_t *>(tile);
-    int *hq = reinterpret_cast<int *>(hkey + HITBUF);
-    const int per = (S + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int s_begin = (int)blockIdx.y * per, s_end = min(S, s_begin + per);
-    for (int s_lo = s_begin; s_lo < s_end; s_lo += GH_SCAN_QGROUP) {
-        const int nq = min(s_end - s_lo, GH_SCAN_QGROUP);
-        if (s_lo > s_begin) {
-            __syncthreads();  // the previous group's records are still being read
-            // many query groups: the parked hits leave before the buffer fills (the subset stride then need not shrink
-            // with the number of queries to keep a workgroup's hits of ALL groups under the buffer size)
-            if (hcount >= HITBUF / 4) {
-                gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
-                __syncthreads();
-                if (threadIdx.x == 0) hcount = 0;
-            }
-        }
-        gh_stage_queries<QS, (D <= 3 ? 3 : LD), NT>(qscan, qt, s_lo, nq, qsh, taush, coh);
-        __syncthreads();
-        gh_scan_queries<D, R, HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt);
-    }
-    __syncthreads();
-    GH_STAMP(4);
-    gh_flush_hits<HITBUF, NT>(hkey, hq, &hcount, cand, cnt);
-    GH_STAMP(5);
-}
-
 // MFMA form of phase B (D <= 3, 256 threads, tiles of 256*R edges): the pre-filter of scan_core.h
 // on v_mfma_f32_32x32x16_f16 with split-f16 operands.  Each wave owns 64*R references of the tile
 // as NB = 2R column blocks of 32 whose B operands live in registers for the whole scan; the
@@ -254,9 +143,9 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
         return;
     }
     const bool coh = ta.nblocks > 0;
-    const int nbx = ta.xcd_tiles > 0 ? ta.xcd_tiles : (int)gridDim.x - ta.nblocks;
-    const int bx = ta.xcd_tiles > 0 ? gh_fused_tile_index((int)blockIdx.x - ta.nblocks, nbx) : (int)blockIdx.x - ta.nblocks;
-    if (bx < 0) return;   // padding workgroup of the XCD-contiguous grid
+    const int nbx = (int)gridDim.x - ta.nblocks;
+    const int bx = (int)blockIdx.x - ta.nblocks;
+#define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + (k)] = wall_clock64(); } while (0)
     GH_STAMP(0);
     if (stamps && threadIdx.x == 0) { stamps[(int64_t)bx * 8 + 6] = vblock[bx + 1] - vblock[bx]; stamps[(int64_t)bx * 8 + 7] = first_edge[vblock[bx + 1]] - first_edge[vblock[bx]]; }
     static_assert(D <= 3, "one 16-deep contraction holds three split coordinates");
@@ -456,9 +345,8 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
         return;
     }
     const bool coh = ta.nblocks > 0;
-    const int nbx = ta.xcd_tiles > 0 ? ta.xcd_tiles : (int)gridDim.x - ta.nblocks;
-    const int bx = ta.xcd_tiles > 0 ? gh_fused_tile_index((int)blockIdx.x - ta.nblocks, nbx) : (int)blockIdx.x - ta.nblocks;
-    if (bx < 0) return;   // padding workgroup of the XCD-contiguous grid
+    const int nbx = (int)gridDim.x - ta.nblocks;
+    const int bx = (int)blockIdx.x - ta.nblocks;
 #define GH_STAMP(k) do { if (stamps && threadIdx.x == 0 && blockIdx.y == 0) stamps[(int64_t)bx * 8 + (k)] = wall_clock64(); } while (0)
     GH_STAMP(0);
     __shared__ float4 tile[TILE * LD / 4];                 // fp32 midpoints of the owned edges
@@ -651,26 +539,17 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
 
 // The thresholds of this iteration: computed by the first workgroups of the fused launch itself (h->tau_embedded), or
 // already in place (knn_tau_kernel ran; nblocks = 0).
-// XCD-contiguous tile mapping (tau_core.h gh_fused_tile_index): GRAPHEM_HIP_XCD_MAP=0/1 overrides the default.
-static int fused_xcd_tiles(const gh_engine *h) {
-    static int mode = -1;
-    if (mode < 0) { const char *e = getenv("GRAPHEM_HIP_XCD_MAP"); mode = e ? (atoi(e) != 0 ? 1 : 0) : 0; }
-    return mode && h->n_vblocks >= 64 && !h->d_stamps ? h->n_vblocks : 0;   // (the diagnostic stamps index by workgroup)
-}
 static unsigned fused_grid(const gh_engine *h, const gh_tau_args &ta) {
-    return (unsigned)((ta.xcd_tiles > 0 ? ((ta.xcd_tiles + 7) / 8) * 8 : h->n_vblocks) + ta.nblocks);
+    return (unsigned)(h->n_vblocks + ta.nblocks);
 }
 gh_tau_args fused_tau_args(gh_engine *h, int nt) {
     gh_tau_args ta{};
-    ta.xcd_tiles = fused_xcd_tiles(h);
     if (!h->tau_embedded) return ta;
-    const int xt = ta.xcd_tiles;
     ta = gh_make_tau_args(h);
     ta.flag = h->d_tau_flag;          // zeroed by this iteration's set-up (setup_core.h), S once the producers are through
     ta.target = (unsigned)h->S;
     ta.nblocks = gh_tau_blocks((int)h->S, nt);
     ta.wait_failed = h->d_wait_failed;
-    ta.xcd_tiles = xt;
     return ta;
 }
 
@@ -686,32 +565,6 @@ template <int D, int R>
 void launch_mfma(gh_engine *h) {
     if (R == 2 && h->n_vblocks <= 2048) launch_mfma_d<D, R, (R == 2)>(h);   // one round of workgroups: occupancy does not matter
     else launch_mfma_d<D, R, false>(h);
-}
-
-template <int D, int LD, int R, int NT, bool LONG>
-void launch_l(gh_engine *h) {
-    // few workgroups with a long packed-VALU scan each (wide rows on a small graph): the queries over up to 4 slices
-    // -- as many as still run all at once: a second round of workgroups costs a whole workgroup lifetime (C5 shape,
-    // D = 16: 179 VGPRs -> 2 workgroups per CU; 177 tiles x 4 slices ran as 512 + 196, 53 us; x 2 slices 354 at once)
-    unsigned ny = 1;
-    if (LD >= 8 && h->n_vblocks < 384) {
-        static int resident = 0;  // per instantiation
-        if (resident == 0) {
-            int occ = 0, cus = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, spring_scan_kernel<D, LD, R, NT, LONG>, NT, 0) != hipSuccess) occ = 1;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
-            resident = (occ > 0 ? occ : 1) * (cus > 0 ? cus : 256);
-        }
-        ny = (unsigned)(resident / (h->n_vblocks > 0 ? h->n_vblocks : 1));
-        if (ny > 4) ny = 4;
-        if (ny < 1) ny = 1;
-        if ((int64_t)ny > h->S) ny = 1;
-    }
-    const gh_tau_args ta = fused_tau_args(h, NT);
-    spring_scan_kernel<D, LD, R, NT, LONG><<<dim3(fused_grid(h, ta), ny), dim3(NT), 0, h->stream>>>(
-        h->d_pos, h->d_rowptr, h->d_adj, h->d_first_edge, h->d_own_eids, h->d_vblock, h->part.row_lo, h->prm.L_min, -h->prm.k_attr,
-        h->d_Fs, h->d_new, h->d_blockstats, h->d_q, h->d_qscan, (int)h->S, h->d_cand, h->d_cnt, gh_make_long_args(h, true), ta,
-        h->d_stamps);
 }
 
 template <int D, int LD, bool LONG>
@@ -743,26 +596,12 @@ void launch_mfmaw(gh_engine *h) {
     else launch_mfmaw_l<D, LD, false>(h);
 }
 
-template <int D, int LD, int R, int NT>
-void launch(gh_engine *h) {
-    if (gh_make_long_args(h).n > 0) launch_l<D, LD, R, NT, true>(h);
-    else launch_l<D, LD, R, NT, false>(h);
-}
-
 }  // namespace
 
 gh_status gh_launch_spring_scan(gh_engine *h) {
     if (h->n_vblocks == 0) return GH_OK;
     GH_TRY_ST(gh_launch_spring_long(h, h->d_Fs, 0));  // hubs first: their rows' forces are read back in phase A
     gh_scope t(h, "spring_scan");
-    int nt, r;
-    fused_cfg(h->LD, h->D, h->S, h->own_count, &nt, &r);
-#define GH_FUSED_D(NTT, RR)                                   \
-    switch (h->D) {                                           \
-        case 2: launch<2, 4, RR, NTT>(h); break;              \
-        case 3: launch<3, 4, RR, NTT>(h); break;              \
-        default: launch<4, 4, RR, NTT>(h); break;             \
-    }
     if (fused_mfma(h->LD, h->D, h->S) && h->D > 3) {
         switch (h->D) {
             case 4: launch_mfmaw<4, 4>(h); break;
@@ -779,40 +618,12 @@ gh_status gh_launch_spring_scan(gh_engine *h) {
             case 15: launch_mfmaw<15, 16>(h); break;
             default: launch_mfmaw<16, 16>(h); break;
         }
-    } else if (fused_mfma(h->LD, h->D, h->S) && nt == 256) {
-        if (r == 8) { if (h->D == 2) launch_mfma<2, 8>(h); else launch_mfma<3, 8>(h); }
-        else if (r == 4) { if (h->D == 2) launch_mfma<2, 4>(h); else launch_mfma<3, 4>(h); }
-        else { if (h->D == 2) launch_mfma<2, 2>(h); else launch_mfma<3, 2>(h); }
-    } else if (h->LD == 4) {
-        if (nt == 256 && r == 8) { GH_FUSED_D(256, 8) }
-        else if (nt == 256 && r == 4) { GH_FUSED_D(256, 4) }
-        else if (nt == 256 && r == 2) { GH_FUSED_D(256, 2) }
-        else if (nt == 128 && r == 8) { GH_FUSED_D(128, 8) }
-        else if (nt == 128 && r == 4) { GH_FUSED_D(128, 4) }
-        else { GH_FUSED_D(128, 2) }
-    } else if (h->LD == 8) {
-        switch (h->D) {
-            case 5: launch<5, 8, 4, 256>(h); break;
-            case 6: launch<6, 8, 4, 256>(h); break;
-            case 7: launch<7, 8, 4, 256>(h); break;
-            default: launch<8, 8, 4, 256>(h); break;
-        }
-    } else if (h->LD == 16) {
-        switch (h->D) {
-            case 9: launch<9, 16, 2, 256>(h); break;
-            case 10: launch<10, 16, 2, 256>(h); break;
-            case 11: launch<11, 16, 2, 256>(h); break;
-            case 12: launch<12, 16, 2, 256>(h); break;
-            case 13: launch<13, 16, 2, 256>(h); break;
-            case 14: launch<14, 16, 2, 256>(h); break;
-            case 15: launch<15, 16, 2, 256>(h); break;
-            default: launch<16, 16, 2, 256>(h); break;
-        }
+    } else if (fused_mfma(h->LD, h->D, h->S)) {
+        if (h->D == 2) launch_mfma<2, 2>(h); else launch_mfma<3, 2>(h);
     } else {
         h->err = "fused spring+scan launched for an unsupported dimension";
         return GH_ERR_RUNTIME;
     }
-#undef GH_FUSED_D
     GH_LAUNCH_CHECK();
     h->new0_ready = true;  // d_new = pos + Fs and d_blockstats[n_vblocks] are in place
     return GH_OK;

@@ -319,11 +319,10 @@ __global__ __launch_bounds__(256) void grid_scan_kernel(const float4 *__restrict
 }  // namespace
 
 bool gh_grid_path(const gh_engine *h) {
-    // 4..16 components (grid over three coordinates) only on request: exact, but measured 50-80x SLOWER than the scan on the
-    // 1 M-vertex graph (profiles/r03/knn_method_sweep.log) -- the three-coordinate shadow of a 6- or 16-dimensional
-    // threshold ball holds more midpoints than a candidate list takes, and every query ends in the exhaustive fallback
-    const bool wide = getenv("GRAPHEM_HIP_GRID_WIDE") != nullptr;
-    return h->prm.knn_method == GH_KNN_GRID && h->D >= 2 && h->D <= (wide ? 16 : 3) && gh_knn_scan_path(h);
+    // 2 or 3 components only.  (Round 2 also ran it over the first three of 4..16 coordinates: exact, but measured 50-80x SLOWER
+    // than the scan on the 1 M-vertex graph, profiles/r03/knn_method_sweep.log -- the three-coordinate shadow of a 6- or
+    // 16-dimensional threshold ball holds more midpoints than a candidate list takes; removed in round 4.)
+    return h->prm.knn_method == GH_KNN_GRID && h->D >= 2 && h->D <= 3 && gh_knn_scan_path(h);
 }
 
 gh_status gh_grid_alloc(gh_engine *h) {

@@ -901,8 +901,7 @@ gh_status gh_ivf_search(gh_engine *h) {
     // below (there the nearest lists hold the nearest members, and at 16 K queries the sample was the probe kernel's 0.55 ms);
     // 1024 ... 8192
     const int64_t probed = (int64_t)P * (M / C);
-    static const int tm_env = getenv("GRAPHEM_HIP_IVF_TAU_MEMBERS") ? atoi(getenv("GRAPHEM_HIP_IVF_TAU_MEMBERS")) : 0;   // tuning
-    const int tau_members = tm_env > 0 ? std::max(tm_env, 4 * h->Ksel) : v->exact ? std::max(4096, 16 * h->Ksel) /* a tight threshold keeps the ball small */ : (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / (h->D > 8 ? 16 : 64)));
+    const int tau_members = v->exact ? std::max(4096, 16 * h->Ksel) /* a tight threshold keeps the ball small */ : (int)std::min<int64_t>(8192, std::max<int64_t>(std::max(1024, 16 * h->Ksel), probed / (h->D > 8 ? 16 : 64)));
 #define GH_IVF_LD(X)                          \
     switch (h->LD) {                          \
         case 4: { X(4) } break;               \
@@ -970,8 +969,7 @@ gh_status gh_ivf_search(gh_engine *h) {
         const dim3 grid((unsigned)v->max_tiles);
 #define GH_X(DD) ivf_scan_kernel<DD><<<grid, dim3(256), 0, h->stream>>>(v->lmid, v->lids, v->tile_list, v->meta, v->qstart, v->pair_q, h->d_q, h->d_qscan, h->d_cand, h->d_cnt)
 #define GH_XM(DD, LL) ivf_scan_mfma_kernel<DD, LL><<<grid, dim3(256), 0, h->stream>>>(v->lmid, v->lids, v->tile_list, v->meta, v->qstart, v->pair_q, h->d_q, h->d_qscan, h->d_cand, h->d_cnt)
-        static const bool valu = getenv("GRAPHEM_HIP_IVF_VALU") != nullptr;   // A/B: the packed-fp32 filter for every dimension
-        if (h->D >= 4 && !valu) {
+        if (h->D >= 4) {
             switch (h->D) {
                 case 4: GH_XM(4, 4); break;
                 case 5: GH_XM(5, 8); break;

@@ -493,10 +493,6 @@ void launch_block_select(gh_engine *h, const float *mid, int64_t M, int64_t mem_
 // <= 4096), a workgroup parks its hits in LDS (mean min(S,256)*K*stride*tile/M per query group kept near 300 for a buffer of >= 512), and the
 // subset must keep well over K groups of GH_THR_GSIZE rows.
 int64_t subset_stride(int64_t Mtot, int K, int64_t S, int tile, bool mfma) {
-    if (const char *e = getenv("GRAPHEM_HIP_SUBSET_STRIDE")) {  // tuning override
-        const long v = atol(e);
-        if (v >= 2 && v <= Mtot / (4 * (int64_t)K)) return v;
-    }
     // beyond 256 queries the threshold kernel's workgroups no longer run all at once and its cost grows
     // with S like the hits do, so the balance point stops moving
     // (the MFMA form's hits cost less than half as much -- ~0.1 us per unit of stride -- so its balance sits higher)
@@ -520,8 +516,7 @@ gh_status launch_select(gh_engine *h, bool final_level, bool with_intersect, con
     const bool reduce = final_level && h->new0_ready && h->rows > 0 && h->LD <= 16 && h->S < 2048;
     gh_scope t(h, with_intersect ? "knn_select_intersect" : "knn_select");
     // thousands of queries, no column sums riding along: a wave per query first, the workgroup form for what it leaves
-    static const bool no_wave = getenv("GRAPHEM_HIP_SELECT_BLOCK") != nullptr;   // A/B
-    const bool wave = final_level && !reduce && h->S >= 2048 && !no_wave;
+    const bool wave = final_level && !reduce && h->S >= 2048;
     bool wave_tq = false;
     if (wave) {
 #define GH_SELW(DD)                                                                                                      \

@@ -23,19 +23,7 @@ struct gh_tau_args {
     int nblocks;              // workgroups at the head of the grid that compute thresholds (0: a launch of their own did)
     int32_t *wait_failed;     // set when a consumer gave up waiting (cannot happen while workgroups start in index order)
     // -- tile mapping of the fused launch (rides here: every fused kernel takes this struct)
-    int xcd_tiles;            // > 0: XCD-contiguous tiles (gh_fused_tile_index), this many; 0: tile = workgroup index
 };
-
-// Which tile a fused workgroup takes.  Workgroups are dealt to the 8 XCDs round-robin, so with tile = workgroup index
-// every XCD's L2 sees every eighth tile of the whole vertex range; with this mapping XCD x takes the CONTIGUOUS range of
-// tiles [x * per, (x + 1) * per), per = ceil(n / 8): consecutive rows -- breadth-first siblings, members of a community --
-// gather through ONE L2.  b: workgroup index among the tile workgroups; returns -1 for the padding workgroups of the
-// rounded-up grid.
-__device__ __forceinline__ int gh_fused_tile_index(int b, int n) {
-    const int per = (n + 7) >> 3;
-    const int t = (b & 7) * per + (b >> 3);
-    return (b >> 3) < per && t < n ? t : -1;
-}
 
 // One wave, one query: the minima sit NV per lane in
 // registers (more than 64 * NV groups: folded by min, which only makes groups coarser), K rounds of a

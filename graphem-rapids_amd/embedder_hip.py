@@ -146,10 +146,22 @@ class GraphEmbedderHIP:
         self.sampler = sampler
         if knn_distance not in ("auto", "exact", "cdist"):
             raise ValueError(f"Invalid knn_distance: {knn_distance}")
-        if knn_method == "ivf" and knn_distance == "cdist":
-            raise ValueError("knn_method='ivf' is approximate; knn_distance='cdist' (the parity mode) needs an exact search")
+        # knn_distance='cdist' (the parity mode) ranks the candidates of the fused brute-force scan: it cannot be combined with
+        # another search.  An explicit 'grid' / 'ivf' therefore excludes it (ValueError when both are explicit), and 'auto'
+        # resolves to 'cdist' only where knn_method='auto' / 'scan' keeps the engine on the scan anyway -- the same size
+        # rule as GH_KNN_AUTO in csrc/api.hip (thousands of sampled midpoints go to the exact inverted file / the grid).
+        big_s_ivf = (2 <= n_components <= 8 and self.sample_size >= (4096 if n_components <= 4 else 8192)
+                     and self.n_edges >= 262144)
+        big_s_grid = n_components <= 3 and self.sample_size >= 12288
+        stays_on_scan = knn_method == "scan" or (knn_method == "auto" and not (big_s_ivf or big_s_grid))
+        if knn_distance == "cdist" and knn_method in ("grid", "ivf"):
+            raise ValueError(f"knn_method='{knn_method}' cannot be combined with knn_distance='cdist' (the parity mode "
+                             "re-values the candidates of the brute-force scan); use knn_method='scan' or 'auto'")
         if knn_distance == "auto":
-            knn_distance = "cdist" if sampler == "torch" and knn_method != "ivf" else "exact"
+            knn_distance = "cdist" if sampler == "torch" and stays_on_scan else "exact"
+        elif knn_distance == "cdist" and not stays_on_scan:
+            self.logger.warning("knn_distance='cdist' keeps the KNN on the brute-force scan: with sample_size=%d the "
+                                "sub-quadratic search knn_method='auto' would choose is not used", self.sample_size)
         self.knn_distance = knn_distance
 
         # the device sampler's key: an unseeded embedder draws it from torch's global generator, so unseeded
@@ -179,12 +191,12 @@ class GraphEmbedderHIP:
             from .spectral import laplacian_embedding_hip
             try:
                 p0 = laplacian_embedding_hip(self.adjacency, self.n_components, device=str(self.device),
-                                             seed=0 if seed is None else seed)
+                                             seed=0 if seed is None else seed, dtype=np.float64 if dtype == torch.float64 else np.float32)
             except ValueError as exc:  # n_components + 1 >= n: the reference falls back to random too
                 self.logger.warning("Eigendecomposition failed: %s", exc)
-                p0 = (np.random.randn(self.n, self.n_components) * 0.1).astype(np.float32)
+                p0 = np.random.randn(self.n, self.n_components) * 0.1
         elif init == "random":
-            p0 = (np.random.randn(self.n, self.n_components) * 0.1).astype(np.float32)
+            p0 = np.random.randn(self.n, self.n_components) * 0.1   # (float64, like pt.py:369; the engine casts to its dtype)
         else:
             raise ValueError(f"Invalid init: {init}")
         self._engine.set_positions(p0)   # (a float64 engine takes the start as float64: pt.py:372-376 casts it to dtype)
@@ -229,7 +241,8 @@ class GraphEmbedderHIP:
         except Exception as exc:  # pylint: disable=broad-exception-caught
             self.logger.warning("Eigendecomposition failed: %s", exc)
             emb = np.random.randn(self.n, self.n_components) * 0.1
-        return np.ascontiguousarray(emb, dtype=np.float32)
+        # pt.py:372-376 casts the float64 eigenvectors straight to dtype: a float64 engine gets them unrounded
+        return np.ascontiguousarray(emb, dtype=np.float64 if self.dtype == torch.float64 else np.float32)
 
     # ---- positions accessors (pt.py:324-335, 835-844) -----------------------------------
     @property

@@ -198,8 +198,9 @@ def _trlan(apply_b, n, want, dev, locked, tol, max_steps, check_every, gen, stop
 
 
 def laplacian_embedding_hip(adjacency, n_components, device="cuda:0", tol=1e-6, max_steps=None, check_every=10,
-                            seed=0, return_info=False, check_multiplicity=True, method="trlan"):
-    """(n, n_components) float32: eigenvectors 1..D (ascending eigenvalue) of the normalised Laplacian.
+                            seed=0, return_info=False, check_multiplicity=True, method="trlan", dtype=np.float32):
+    """(n, n_components) of `dtype` (float32; float64 for a float64 engine, pt.py:372-376 casts the eigenvectors to the
+    embedder's dtype): eigenvectors 1..D (ascending eigenvalue) of the normalised Laplacian.
 
     tol bounds the relative Ritz residual |B y - theta y| / |theta| of every wanted pair (the start of
     a layout does not need ARPACK's machine-precision default).  A single Krylov sequence sees only one
@@ -273,7 +274,7 @@ def laplacian_embedding_hip(adjacency, n_components, device="cuda:0", tol=1e-6, 
     if not converged:  # the reference falls back to its random start on ArpackNoConvergence; say so at least
         logger.warning("laplacian_embedding_hip: not converged after %d matvecs (largest relative residual %.2e); "
                        "using the current Ritz vectors", total_steps, float(np.max(resid)))
-    emb = X[:, 1:want].to(torch.float32).cpu().numpy()          # drop the first (pt.py:365)
+    emb = X[:, 1:want].to(torch.float64 if dtype == np.float64 else torch.float32).cpu().numpy()          # drop the first (pt.py:365)
     if return_info:
         return emb, {"steps": total_steps, "runs": runs, "converged": converged, "eigenvalues": 2.0 - theta,
                      "residuals": resid, "vectors_all": X.cpu().numpy()}

@@ -64,9 +64,13 @@ typedef struct {
  *                  sqrt(max(acc, 0))  with |x|^2 = sum of rounded squares, left to right, and equal values in the
  *                  order std::partial_sort leaves them (ATen/native/TopKImpl.h; K * 64 <= E).  The sampled edge is not
  *                  special-cased: column 0 is whatever ranks first (pt.py:417-421).  Neighbour ids then equal the
- *                  reference's row by row at every size.  Costs one more launch per iteration plus, for the rows whose
- *                  K + 1 smallest values hold a tie (about 1 in 100 at a million vertices), a pass over all E edges.
- *                  Whole-graph engines only (no gh_partition); forces GH_KNN_SCAN. */
+ *                  reference's row by row at every size.  The candidates of the filtered scan are re-valued with that
+ *                  formula; for the rows whose K + 1 smallest values hold a tie (about 1 in 100 at a million vertices)
+ *                  partial_sort's heap is replayed over the ids below a prefix bound (about E / stride of them) and the
+ *                  id-sorted rest of the candidate list (csrc/cdist.hip): two more launches per iteration, 270 against
+ *                  170 us at a million vertices.  Works on the candidates of GH_KNN_SCAN only: knn_method = GH_KNN_AUTO
+ *                  takes the scan whatever the sample size, an explicit GH_KNN_GRID / GH_KNN_IVF is refused
+ *                  (GH_ERR_INVALID).  Whole-graph engines only (no gh_partition). */
 #define GH_DIST_EXACT 0
 #define GH_DIST_CDIST 1
 
@@ -76,8 +80,8 @@ typedef struct {
  *                pipe, hidden under the spring phase's gathers up to a few thousand queries;
  *   GH_KNN_GRID  n_components <= 3: a grid over the midpoints rebuilt every iteration (O(E)), then per query only the
  *                cells its threshold ball touches: sub-quadratic, pays from several thousand queries on.  (With more
- *                components the same search over the first three coordinates stays exact but does not pay -- measured
- *                50-80x slower than the scan at a million vertices -- and is refused unless GRAPHEM_HIP_GRID_WIDE is set.)
+ *                components the engine searches with GH_KNN_SCAN instead: a grid over the first three coordinates stays
+ *                exact but was measured 50-80x slower than the scan at a million vertices; removed in round 4.)
  *   GH_KNN_IVF   2 <= n_components <= 16, GH_DIST_EXACT (a partitioned engine indexes the edges it owns): an inverted-file index rebuilt every iteration,
  *                the counterpart of the cuVS backend's IVF-Flat (embedder_cuvs.py:255-313, 384-430).  ivf_lists centroids
  *                (midpoints of evenly spaced edges), every midpoint filed under its nearest one (f16 scores on the matrix
@@ -281,6 +285,16 @@ gh_status gh_timing_reset(gh_handle h);
 int32_t gh_timing_count(gh_handle h);
 gh_status gh_timing_get(gh_handle h, int32_t i, const char **name, double *total_ms, int64_t *launches);
 
+/* Environment variables the library reads -- diagnostics only, all of them at gh_create, none needed in production:
+ *   GRAPHEM_HIP_TAU_SEPARATE=1|0  thresholds always in a launch of their own / always by the first workgroups of the fused
+ *                                 launch (default: inside for <= 2048 fused workgroups);
+ *   GRAPHEM_HIP_NO_PRESETUP=1     the next iteration's KNN set-up as a launch of its own instead of inside the normalise
+ *                                 launch (the per-query flags of gh_knn_last_counts then survive a step);
+ *   GRAPHEM_HIP_REORDER=1|2       overrides gh_params.reorder (1 off, 2 breadth-first);
+ *   GRAPHEM_HIP_STAMPS=1          allocates the stamp buffer gh_debug_stamps reads;
+ *   GRAPHEM_HIP_GRAPH=1           gh_run replays iterations 2.. from a hipGraph of ten iterations (measured slower than
+ *                                 enqueuing: 170.1 against 167.9 us per iteration at a million vertices). */
+
 /* Diagnostic runs only (environment GRAPHEM_HIP_STAMPS set at gh_create): 8 wall-clock stamps (100 MHz) per workgroup
  * of the last fused spring+scan launch (tools/stamp_probe.py).  Blocking. */
 gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64_t count);
@@ -289,7 +303,7 @@ gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64_t count);
  * level and the final level saw, and whether the exact fallback had to redo the query
  * (any of the three (S,) host pointers may be NULL).  Blocking. */
 gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final_counts, int32_t *overflow);
-/* GH_DIST_CDIST engines, last KNN search: rows that needed the pass over all edges (a tie among their K + 1 smallest
+/* GH_DIST_CDIST engines, last KNN search: rows whose partial_sort heap was replayed (a tie among their K + 1 smallest
  * cdist values, or a candidate list that could not be proven complete), and rows whose tie order ATen decides with
  * std::nth_element (K * 64 > E, tiny graphs) -- there equal values come out in (value, id) order and the row is
  * counted here instead of being reproduced.  Either pointer may be NULL.  Blocking. */

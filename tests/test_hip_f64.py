@@ -59,6 +59,13 @@ def test_float64_trajectory_and_public_api():
     adj = gra.edges_to_adjacency(n, g["edges"])
     emb = gra.create_graphem(adj, n_components=3, backend="hip", verbose=False, seed=0, dtype=torch.float64, sampler="torch")
     assert emb.dtype == torch.float64 and emb._positions.dtype == torch.float64 and emb.positions.dtype == np.float64
+    # the spectral start reaches the float64 engine unrounded (pt.py:372-376 casts the float64 eigenvectors to dtype): it
+    # carries more than float32 precision and is the reference's own float64 start up to the sign of an eigenvector and
+    # ARPACK's run-to-run noise
+    start = emb.positions
+    assert np.abs(start - start.astype(np.float32).astype(np.float64)).max() > 0
+    for d in range(D):
+        assert min(np.abs(start[:, d] - g["p0"][:, d]).max(), np.abs(start[:, d] + g["p0"][:, d]).max()) <= 1e-6
     emb.positions = g["pos_0"]
     torch.manual_seed(7)
     ids = torch.randperm(len(g["edges"]))[:S].numpy()

@@ -5,13 +5,13 @@ out=${1:-gpurun_out/final}
 mkdir -p $out
 python bench.py --steps 50 --warmup 5 > $out/bench_default_rr1m.json 2> $out/bench_default_rr1m.err || exit 1
 for wl in rr100k er1m rr4m rr16m snap16 rr1m_d6 rr1m_d12 pp1m; do
-  python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_$wl.json 2>/dev/null || echo "$wl failed"
+  python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_$wl.json 2>/dev/null || echo "$wl failed"
 done
-python bench.py --knn-distance cdist --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_cdist_rr1m.json 2>/dev/null || echo "cdist failed"
-python bench.py --knn-distance cdist --workload rr100k --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_cdist_rr100k.json 2>/dev/null || echo "cdist 100k failed"
-python bench.py --dist --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_dist_world1_python_rr1m.json 2>/dev/null || echo "dist python failed"
-python bench.py --dist --loop native --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_dist_world1_native_rr1m.json 2>/dev/null || echo "dist native failed"
-python bench.py --dist --loop native --workload rr4m --steps 50 --warmup 5 --no-cpu-baseline > $out/bench_dist_world1_native_rr4m.json 2>/dev/null || echo "dist native rr4m failed"
+python bench.py --knn-distance cdist --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_cdist_rr1m.json 2>/dev/null || echo "cdist failed"
+python bench.py --knn-distance cdist --workload rr100k --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_cdist_rr100k.json 2>/dev/null || echo "cdist 100k failed"
+python bench.py --dist --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_dist_world1_python_rr1m.json 2>/dev/null || echo "dist python failed"
+python bench.py --dist --loop native --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_dist_world1_native_rr1m.json 2>/dev/null || echo "dist native failed"
+python bench.py --dist --loop native --workload rr4m --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_dist_world1_native_rr4m.json 2>/dev/null || echo "dist native rr4m failed"
 (python tools/bench_init.py 100000; python tools/bench_init.py 1000000) > $out/bench_init.log 2>&1
 python tools/cdist_probe.py rr1m 30 > $out/cdist_probe_rr1m.log 2>&1
 python -m pytest tests/test_hip_reference_fullsize.py tests/test_hip_f64.py tests/test_spectral_init.py -q -m gpu -s > $out/gpu_tests_fullsize_f64_spectral.log 2>&1

@@ -8,7 +8,7 @@ for S in "$@"; do
   methods="scan grid ivf ivfx"; [ "$dim" != "0" ] && [ "$dim" -gt 3 ] && methods="scan ivf ivfx"
   for m in $methods; do
     knn="--knn $m"; [ "$m" = "ivfx" ] && knn="--knn ivf --ivf-probes -1"   # ivfx: the inverted file in its exact mode
-    python bench.py --workload $wl $extra --sample-size $S $knn --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline 2>/dev/null | python -c "
+    python bench.py --workload $wl $extra --sample-size $S $knn --steps 10 --warmup 2 --repeats 1 --no-cpu-baseline --no-parity-mode 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$wl dim=$dim S=$S $m: %9.1f us/iter ' % (1e3*d['ms_per_step']), {k: round(v['avg_us'],1) for k,v in d['kernels'].items()})"
   done
 done

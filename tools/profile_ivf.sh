@@ -8,11 +8,11 @@ EXTRA=""; [ "$DIM" != "0" ] && EXTRA="--dim $DIM"
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace" -- \
-    python3 "$ROOT/bench.py" --workload "$WL" $EXTRA --sample-size "$S" --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline \
+    python3 "$ROOT/bench.py" --workload "$WL" $EXTRA --sample-size "$S" --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-parity-mode \
     > "$ROOT/$OUT/bench_under_rocprof.json" 2> "$ROOT/$OUT/bench_under_rocprof.err"
 timeout -k 10 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAVES \
     --output-format csv -d "$ROOT/$OUT/pmc_sq" -- \
-    python3 "$ROOT/bench.py" --workload "$WL" $EXTRA --sample-size "$S" --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline > /dev/null 2>&1
+    python3 "$ROOT/bench.py" --workload "$WL" $EXTRA --sample-size "$S" --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-parity-mode > /dev/null 2>&1
 find "$ROOT/$OUT/trace" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$ROOT/$OUT/kernel_stats.csv"
 python3 - "$ROOT/$OUT" <<'PY'
 import csv, glob, re, sys, collections
