@@ -268,7 +268,7 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, rank=rank, world=world,
-                                device_id=local_rank, native=args.loop == "native")
+                                device_id=local_rank, native=args.loop == "native", knn_distance=args.knn_distance)
         lay.set_positions(pos)
         run = lay.run
         sync = lay.sync

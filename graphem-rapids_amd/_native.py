@@ -17,7 +17,7 @@ GH_OK, GH_ERR_INVALID, GH_ERR_RUNTIME, GH_ERR_K_TOO_LARGE, GH_ERR_HIP, GH_ERR_NO
 SYMBOLS = [
     "gh_create", "gh_destroy", "gh_last_error", "gh_set_positions", "gh_get_positions", "gh_positions_device",
     "gh_row_stride", "gh_step", "gh_run", "gh_sync", "gh_spring_forces", "gh_knn_midpoints",
-    "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_step_merge",
+    "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_knn_partial_cols", "gh_knn_merged_device", "gh_step_merge",
     "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
     "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts", "gh_set_stream",
     "gh_positions_rows_allocated", "gh_knn_points", "gh_stats_rows", "gh_spmv_symnorm",
@@ -125,6 +125,10 @@ def load():
     L.gh_integrate_normalise.restype = ctypes.c_int
     L.gh_knn_partial_device.argtypes = [vp]
     L.gh_knn_partial_device.restype = vp
+    L.gh_knn_partial_cols.argtypes = [vp]
+    L.gh_knn_partial_cols.restype = i32
+    L.gh_knn_merged_device.argtypes = [vp]
+    L.gh_knn_merged_device.restype = vp
     L.gh_step_merge.argtypes = [vp, vp, i32]
     L.gh_step_merge.restype = ctypes.c_int
     L.gh_stats_partial_device.argtypes = [vp]
@@ -399,6 +403,15 @@ class Engine:
 
     def knn_partial_device_ptr(self):
         return self.lib.gh_knn_partial_device(self.handle)
+
+    def knn_merged_device_ptr(self):
+        """(S, k + 1) keys of the global KNN after step_merge (0 before the first merge)."""
+        return self.lib.gh_knn_merged_device(self.handle)
+
+    def knn_partial_cols(self):
+        """64-bit words per query of the record a rank sends after part 1 of a split step: k + 1 keys; a
+        knn_distance='cdist' engine on a row partition sends k + 2 keys and a flag (include/graphem_hip.h)."""
+        return int(self.lib.gh_knn_partial_cols(self.handle))
 
     def stats_partial_device_ptr(self):
         return self.lib.gh_stats_partial_device(self.handle)

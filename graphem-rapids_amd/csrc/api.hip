@@ -136,7 +136,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     }
     if (params->knn_distance != GH_DIST_EXACT && params->knn_distance != GH_DIST_CDIST) { delete h; return fail(GH_ERR_INVALID, "unknown knn_distance"); }
     h->cdist = params->knn_distance == GH_DIST_CDIST;
-    if (h->cdist && part) { delete h; return fail(GH_ERR_INVALID, "knn_distance = GH_DIST_CDIST needs the whole graph on one engine (no gh_partition)"); }
+    h->cd_part = h->cdist && part != nullptr;
     if (h->cdist && !auto_method && params->knn_method != GH_KNN_SCAN) {   // (an explicit request must not be dropped silently)
         delete h;
         return fail(GH_ERR_INVALID, "knn_distance = GH_DIST_CDIST re-values the candidates of GH_KNN_SCAN: it cannot be combined with GH_KNN_GRID / GH_KNN_IVF");
@@ -442,7 +442,7 @@ extern "C" gh_status gh_create(gh_handle *out, int device_id, int64_t n, int32_t
     GH_A(d_tq_base, S >= 2048 ? S : 1, true);
     GH_A(d_tq_touched, S >= 2048 ? 4 * S * (size_t)std::max(h->k, 1) : 1, false);
     GH_A(d_dbg_cnt, 2 * S, true);
-    GH_A(d_partial, S * (size_t)h->K, true);
+    GH_A(d_partial, S * (size_t)(h->K + (h->cd_part ? 2 : 0)), true);
     GH_A(d_merged, S * (size_t)h->K, true);
     GH_A(d_iscratch, S * (size_t)h->k * h->LD, false);
     h->nblocks_update = (int)((h->rows + 255) / 256);
@@ -852,6 +852,8 @@ extern "C" gh_status gh_set_stream(gh_handle h, void *hip_stream, int32_t use_ow
 }
 extern "C" int64_t gh_positions_rows_allocated(gh_handle h) { return h ? h->pos_rows : 0; }
 extern "C" uint64_t *gh_knn_partial_device(gh_handle h) { return h ? h->d_partial : nullptr; }
+extern "C" const uint64_t *gh_knn_merged_device(gh_handle h) { return h ? h->d_keys_cur : nullptr; }
+extern "C" int32_t gh_knn_partial_cols(gh_handle h) { return h ? h->K + (h->cd_part ? 2 : 0) : 0; }
 extern "C" gh_status gh_step_merge(gh_handle h, const uint64_t *gathered, int32_t world) {
     GH_TRY(check_handle(h));
     GH_TRY(reject_f64(h, "gh_step_merge"));
@@ -875,7 +877,6 @@ extern "C" gh_status gh_gather_layout(gh_handle h, int32_t world, int32_t rank, 
         return GH_ERR_INVALID;
     }
     if (h->d_gbuf || h->g_world) { h->err = "rank / gather layout already set"; return GH_ERR_INVALID; }
-    if (h->cdist) { h->err = "GH_DIST_CDIST engines do not take a gather layout"; return GH_ERR_INVALID; }
     const int64_t stats_bytes = (int64_t)sizeof(double) * (2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
     const int64_t slot = (chunk * h->LD * (int64_t)sizeof(float) + stats_bytes + 15) / 16 * 16;
     GH_HIP(hipStreamSynchronize(h->stream));
@@ -896,7 +897,6 @@ extern "C" gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, in
         return GH_ERR_INVALID;
     }
     if (h->d_gbuf || h->g_world) { h->err = "rank / gather layout already set"; return GH_ERR_INVALID; }
-    if (h->cdist) { h->err = "GH_DIST_CDIST engines do not take a rank layout"; return GH_ERR_INVALID; }
     GH_TRY(dev_alloc(h, &h->d_stats_comb, (size_t)2 * h->LD, true));
     h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
     return GH_OK;
@@ -961,8 +961,15 @@ extern "C" gh_status gh_knn_midpoints(gh_handle h, const int32_t *sampled, int32
     if (!sampled && h->S < h->E) { h->err = "sampled is NULL"; return GH_ERR_INVALID; }
     GH_TRY(set_sample(h, sampled, nullptr));
     GH_TRY(step_begin(h, false));  // the same kernels a step runs (spring forces are a by-product)
+    const uint64_t *d_keys = h->d_partial;
+    if (h->cd_part) {   // a GH_DIST_CDIST engine created with a (whole-graph) partition: its rows are decided at the merge
+        h->intersect_done = true;   // (no intersection phase here)
+        GH_TRY(gh_knn_merge(h, h->d_partial, 1));
+        h->intersect_done = false;
+        d_keys = h->d_merged;
+    }
     std::vector<uint64_t> keys((size_t)h->S * h->K);
-    GH_HIP(hipMemcpyAsync(keys.data(), h->d_partial, sizeof(uint64_t) * keys.size(), hipMemcpyDeviceToHost, h->stream));
+    GH_HIP(hipMemcpyAsync(keys.data(), d_keys, sizeof(uint64_t) * keys.size(), hipMemcpyDeviceToHost, h->stream));
     GH_HIP(hipStreamSynchronize(h->stream));
     for (int64_t s = 0; s < h->S; ++s)  // column 0 dropped blindly (pt.py:421)
         for (int c = 1; c < h->K; ++c) knn[s * h->k + (c - 1)] = (int32_t)(keys[(size_t)s * h->K + c] & 0xFFFFFFFFu);

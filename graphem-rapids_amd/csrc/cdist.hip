@@ -157,7 +157,10 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
                                                                int32_t *__restrict__ ovf, int32_t *__restrict__ dbg_cnt,
                                                                cdist_rows rr, inter_args ia, int S,
                                                                const double *__restrict__ blockstats, int nblocks,
-                                                               double *__restrict__ stats) {
+                                                               double *__restrict__ stats,
+                                                               int part_mode /* a row partition: only this rank's K + 1 best keys and
+                                                               whether they are provably its K + 1 best -> out_keys (S, K + 2); ties
+                                                               and listing are decided after the ranks' keys are merged */) {
     constexpr int LDT = DT <= 4 ? 4 : DT <= 8 ? 8 : 16;
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t best2[GH_EXTRACT_MAX_K];
@@ -212,6 +215,13 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
         if (threadIdx.x == 0 && !cdist_clears(gh_key_d2(best[Ks - 1]), bound)) bad |= 2;   // the (K+1)-th smallest VALUE (a distance, not squared)
         // 1: a tie among the K + 1 smallest values, 2: the list is not provably complete (3: both)
         reason = (__syncthreads_or(bad & 1) ? 1 : 0) | (__syncthreads_or(bad & 2) ? 2 : 0);
+    }
+    if (part_mode) {
+        // (reason bit 1 = a tie: for the merged list to judge; the keys are this rank's K + 1 smallest either way)
+        const bool have = c <= GH_CAND_CAP && c >= Ks;
+        for (int i = threadIdx.x; i < Ks; i += 256) out_keys[qi * (Ks + 1) + i] = have ? best[i] : GH_KEY_INF;
+        if (threadIdx.x == 0) { out_keys[qi * (Ks + 1) + Ks] = have && !(reason & 2) ? 1ull : 0ull; ovf[qi] = reason; }
+        return;
     }
     if (!reason) {
         for (int i = threadIdx.x; i < K; i += 256) out_keys[qi * K + i] = best[i];
@@ -314,6 +324,49 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
         atomicMax(&rr.hdr[2], (int32_t)P);
         ovf[qi] = reason;
     }
+}
+
+// Row partitions: the ranks' K + 1 best cdist keys (and whether each rank could prove them its K + 1 best) -> the global
+// rows.  A query whose merged K + 1 smallest values are pairwise different, every rank's list proven, is decided: ascending
+// values (its k candidate pairs go through the intersection phase here).  Any other query is LISTED and partial_sort's heap
+// is replayed over ALL edges (P = E, no tail: the candidate lists are spread over the ranks) -- on every rank alike, every
+// rank holding all positions and the whole edge list, so no further collective is needed and all ranks get the same rows.
+template <int DT>
+__global__ __launch_bounds__(256) void knn_merge_cdist_kernel(const uint64_t *__restrict__ gathered /* (world, S, K + 2) */, int world,
+                                                              int64_t S, int K, int64_t E, uint64_t *__restrict__ merged, cdist_rows rr,
+                                                              inter_args ia) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint64_t *buf = reinterpret_cast<uint64_t *>(smem_raw);
+    __shared__ gh_pair_list pairs;
+    const int Ks = K + 1;
+    const int64_t qi = blockIdx.x;
+    const int total = world * Ks;
+    const int n2 = next_pow2(total < 2 ? 2 : total);
+    int bad = 0;
+    for (int i = threadIdx.x; i < n2; i += 256) {
+        uint64_t key = GH_KEY_INF;
+        if (i < total) {
+            const int w = i / Ks, c = i % Ks;
+            key = gathered[((int64_t)w * S + qi) * (Ks + 1) + c];
+        }
+        buf[i] = key;
+    }
+    for (int w = threadIdx.x; w < world; w += 256) bad |= gathered[((int64_t)w * S + qi) * (Ks + 1) + Ks] == 1ull ? 0 : 1;
+    __syncthreads();
+    block_sort(buf, n2);
+    for (int i = threadIdx.x; i + 1 < Ks; i += 256) bad |= (uint32_t)(buf[i] >> 32) == (uint32_t)(buf[i + 1] >> 32) ? 1 : 0;
+    if (__syncthreads_or(bad)) {
+        if (threadIdx.x == 0) {
+            const int slot = atomicAdd(&rr.hdr[0], 1);
+            rr.rare[1 + slot] = (int32_t)qi;
+            rr.P[slot] = (int32_t)E;
+            rr.ct[slot] = 0;
+            atomicMax(&rr.hdr[2], (int32_t)E);
+        }
+        return;
+    }
+    for (int c = threadIdx.x; c < K; c += 256) merged[qi * K + c] = buf[c];
+    if (ia.pos) intersect_query<DT>(ia, qi, buf, &pairs);
 }
 
 // ---- values of the listed rows' prefixes -----------------------------------------------------------------------------
@@ -840,36 +893,9 @@ gh_status gh_cdist_alloc(gh_engine *h) {
     return GH_OK;
 }
 
-// all_rows: the graph is too small for the filtered scan -- every query is replayed over all edges.  Otherwise the
-// candidate lists of the scan are in place.  -> d_partial (S, K): the reference's rows, column 0 included.
-// fuse_intersect (single-rank steps, K <= 64): the same launches run the intersection phase of every query they finish
-// and reduce the fused kernel's column sums (h->intersect_done / h->stats_reduced tell the caller).
-gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows, bool fuse_intersect) {
-    const cdist_args a = make_cdist_args(h);
-    const int set = h->cd_set;
-    h->cd_set ^= 1;
-    const cdist_rows rr{h->d_rare, h->d_cd_rows, h->d_cd_rows + h->S, h->d_cd_stat + 4 * set, h->d_cd_stat + 4 * (set ^ 1)};
-    const bool fuse = !all_rows && fuse_intersect && h->K <= 64 && h->D >= 2 && h->D <= 16;
-    bool reduce = false;
-    if (!all_rows) {
-        if (h->D < 2 || h->D > 16) { h->err = "GH_DIST_CDIST: the candidate selection needs 2..16 components"; return GH_ERR_RUNTIME; }
-        // the column sums of the fused kernel's workgroup partials ride along (stats_fix_kernel then skips them)
-        reduce = h->new0_ready && h->rows > 0 && h->LD <= 16 && h->S < 2048;
-        gh_scope t(h, fuse ? "knn_select_cdist_intersect" : "knn_select_cdist");
-        const inter_args ia = make_inter_args(h, fuse);
-#define GH_CSEL(DD)                                                                                                                \
-    knn_select_cdist_kernel<DD><<<dim3((unsigned)h->S + (reduce ? 2u * (unsigned)h->LD : 0u)), dim3(256), 0, h->stream>>>(          \
-        h->d_cand, h->d_cnt, h->K, a, h->d_partial, h->d_ovf, h->d_dbg_cnt + h->S, rr, ia, (int)h->S, h->d_blockstats, h->n_vblocks, \
-        h->d_stats)
-        switch (h->D) {
-            case 2: GH_CSEL(2); break;   case 3: GH_CSEL(3); break;   case 4: GH_CSEL(4); break;   case 5: GH_CSEL(5); break;
-            case 6: GH_CSEL(6); break;   case 7: GH_CSEL(7); break;   case 8: GH_CSEL(8); break;   case 9: GH_CSEL(9); break;
-            case 10: GH_CSEL(10); break; case 11: GH_CSEL(11); break; case 12: GH_CSEL(12); break; case 13: GH_CSEL(13); break;
-            case 14: GH_CSEL(14); break; case 15: GH_CSEL(15); break; default: GH_CSEL(16); break;
-        }
-#undef GH_CSEL
-        GH_LAUNCH_CHECK();
-    }
+// The replay of the listed rows (or of all S queries: all_rows), cd_R rows per round: values of their prefixes, then one
+// workgroup per row -> out_keys (S, K).  fuse: the rows' intersection phase rides in the replay launch.
+static gh_status cdist_replay_rounds(gh_engine *h, const cdist_args &a, const cdist_rows &rr, bool all_rows, bool fuse, uint64_t *out_keys) {
     const int64_t vstride = cdist_vstride(h);
     const int nth_form = (int64_t)h->K * 64 > h->E ? 1 : 0;
     const int all = all_rows ? (int)h->S : 0;
@@ -896,7 +922,7 @@ gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows, bool fuse_intersect) 
         const size_t smem = h->K <= 64 ? 0 : sizeof(uint64_t) * (size_t)h->K;
         const inter_args ia = make_inter_args(h, fuse);
 #define GH_CREP(DD, HEAPv, INTv) cdist_replay_kernel<DD, HEAPv, INTv><<<dim3((unsigned)h->cd_R), dim3(256), smem, h->stream>>>( \
-        rr, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride, h->d_cd_cmin, h->cd_nchunks, h->d_cand, h->d_partial, nth_form, ia, h->d_stamps)
+        rr, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride, h->d_cd_cmin, h->cd_nchunks, h->d_cand, out_keys, nth_form, ia, h->d_stamps)
 #define GH_CREP_D(DD) case DD: if (h->K <= GH_CD_KS) GH_CREP(DD, 0, true); else GH_CREP(DD, 1, true); break;
         if (fuse) {
             switch (h->D) {
@@ -915,7 +941,81 @@ gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows, bool fuse_intersect) 
 #undef GH_CREP
         GH_LAUNCH_CHECK();
     }
+    return GH_OK;
+}
+
+// all_rows: the graph is too small for the filtered scan -- every query is replayed over all edges.  Otherwise the
+// candidate lists of the scan are in place.  -> d_partial (S, K): the reference's rows, column 0 included.
+// fuse_intersect (single-rank steps, K <= 64): the same launches run the intersection phase of every query they finish
+// and reduce the fused kernel's column sums (h->intersect_done / h->stats_reduced tell the caller).
+// A row-partitioned engine (h->cd_part) stops after its own candidates: -> d_partial (S, K + 2): this rank's K + 1 best cdist
+// keys of every query and 1 where they are provably its K + 1 best; gh_knn_merge_cdist finishes after the ranks' all-gather.
+gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows, bool fuse_intersect) {
+    const cdist_args a = make_cdist_args(h);
+    if (h->cd_part && all_rows) {   // too few own edges for the scan: nothing proven, every row is replayed after the merge
+        GH_HIP(hipMemsetAsync(h->d_partial, 0xFF, sizeof(uint64_t) * (size_t)h->S * (h->K + 2), h->stream));
+        h->intersect_done = false;
+        h->stats_reduced = false;
+        return GH_OK;
+    }
+    const int set = h->cd_part ? h->cd_set ^ 1 : h->cd_set;   // (a partitioned engine's search takes its counter set at the merge)
+    if (!h->cd_part) h->cd_set ^= 1;
+    const cdist_rows rr{h->d_rare, h->d_cd_rows, h->d_cd_rows + h->S, h->d_cd_stat + 4 * set, h->d_cd_stat + 4 * (set ^ 1)};
+    const bool fuse = !all_rows && !h->cd_part && fuse_intersect && h->K <= 64 && h->D >= 2 && h->D <= 16;
+    bool reduce = false;
+    if (!all_rows) {
+        if (h->D < 2 || h->D > 16) { h->err = "GH_DIST_CDIST: the candidate selection needs 2..16 components"; return GH_ERR_RUNTIME; }
+        // the column sums of the fused kernel's workgroup partials ride along (stats_fix_kernel then skips them)
+        reduce = h->new0_ready && h->rows > 0 && h->LD <= 16 && h->S < 2048;
+        gh_scope t(h, fuse ? "knn_select_cdist_intersect" : "knn_select_cdist");
+        const inter_args ia = make_inter_args(h, fuse);
+        const int part_mode = h->cd_part ? 1 : 0;
+#define GH_CSEL(DD)                                                                                                                \
+    knn_select_cdist_kernel<DD><<<dim3((unsigned)h->S + (reduce ? 2u * (unsigned)h->LD : 0u)), dim3(256), 0, h->stream>>>(          \
+        h->d_cand, h->d_cnt, h->K, a, h->d_partial, h->d_ovf, h->d_dbg_cnt + h->S, rr, ia, (int)h->S, h->d_blockstats, h->n_vblocks, \
+        h->d_stats, part_mode)
+        switch (h->D) {
+            case 2: GH_CSEL(2); break;   case 3: GH_CSEL(3); break;   case 4: GH_CSEL(4); break;   case 5: GH_CSEL(5); break;
+            case 6: GH_CSEL(6); break;   case 7: GH_CSEL(7); break;   case 8: GH_CSEL(8); break;   case 9: GH_CSEL(9); break;
+            case 10: GH_CSEL(10); break; case 11: GH_CSEL(11); break; case 12: GH_CSEL(12); break; case 13: GH_CSEL(13); break;
+            case 14: GH_CSEL(14); break; case 15: GH_CSEL(15); break; default: GH_CSEL(16); break;
+        }
+#undef GH_CSEL
+        GH_LAUNCH_CHECK();
+    }
+    if (!h->cd_part) GH_TRY_ST(cdist_replay_rounds(h, a, rr, all_rows, fuse, h->d_partial));
     h->intersect_done = fuse;
     h->stats_reduced = reduce;
+    return GH_OK;
+}
+
+// Row partitions, after the all-gather of the ranks' keys: gathered (world, S, K + 2) -> d_merged (S, K), the reference's rows
+// (knn_merge_cdist_kernel; the listed rows replayed over all edges), with the intersection phase of every query when
+// K <= 64 and 2..16 components (h->intersect_done).
+gh_status gh_knn_merge_cdist(gh_engine *h, const uint64_t *gathered, int world) {
+    const cdist_args a = make_cdist_args(h);
+    const int set = h->cd_set;
+    h->cd_set ^= 1;
+    const cdist_rows rr{h->d_rare, h->d_cd_rows, h->d_cd_rows + h->S, h->d_cd_stat + 4 * set, h->d_cd_stat + 4 * (set ^ 1)};
+    const bool fuse = !h->intersect_done && h->K <= 64 && h->D >= 2 && h->D <= 16;
+    const int total = world * (h->K + 1);
+    int n2 = 2;
+    while (n2 < total) n2 <<= 1;
+    if ((size_t)n2 * sizeof(uint64_t) > 48 * 1024) {
+        h->err = "world * (n_neighbors + 2) too large for the merge kernel";
+        return GH_ERR_INVALID;
+    }
+    {
+        gh_scope t(h, fuse ? "knn_merge_cdist_intersect" : "knn_merge_cdist");
+        const inter_args ia = make_inter_args(h, fuse);
+#define GH_CMRG(DD) knn_merge_cdist_kernel<DD><<<dim3((unsigned)h->S), dim3(256), sizeof(uint64_t) * (size_t)n2, h->stream>>>( \
+        gathered, world, h->S, h->K, h->E, h->d_merged, rr, ia)
+        if (fuse) { GH_DISPATCH_DIM(h->D, GH_CMRG) } else { GH_CMRG(0); }
+#undef GH_CMRG
+        GH_LAUNCH_CHECK();
+    }
+    GH_TRY_ST(cdist_replay_rounds(h, a, rr, false, fuse, h->d_merged));
+    h->d_keys_cur = h->d_merged;
+    if (fuse) h->intersect_done = true;
     return GH_OK;
 }

@@ -157,7 +157,7 @@ static gh_status comm_common(gh_engine *h, int world, int rank) {
     h->comm->world = world;
     h->comm->rank = rank;
     const size_t stats_doubles = (size_t)world * (2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
-    if (hipMalloc(reinterpret_cast<void **>(&h->comm->d_gathered), sizeof(uint64_t) * (size_t)world * h->S * h->K + 16) != hipSuccess ||
+    if (hipMalloc(reinterpret_cast<void **>(&h->comm->d_gathered), sizeof(uint64_t) * (size_t)world * h->S * (h->K + (h->cd_part ? 2 : 0)) + 16) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&h->comm->d_stats_all), sizeof(double) * stats_doubles + 16) != hipSuccess) {
         if (h->comm->d_gathered) (void)hipFree(h->comm->d_gathered);
         delete h->comm; h->comm = nullptr;
@@ -229,7 +229,7 @@ extern "C" gh_status gh_run_partitioned(gh_handle h, int32_t iters, const int32_
     if (!h->comm) { h->err = "no communicator: call gh_comm_init_rccl / gh_comm_init_loopback first"; return GH_ERR_INVALID; }
     if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
     gh_comm *c = h->comm;
-    const size_t key_bytes = sizeof(uint64_t) * (size_t)h->S * h->K;
+    const size_t key_bytes = sizeof(uint64_t) * (size_t)h->S * (h->K + (h->cd_part ? 2 : 0));   // (a GH_DIST_CDIST partition sends K + 1 keys and a flag)
     const int32_t *d_ids = nullptr;
     GH_TRY_ST(gh_upload_sample_stream(h, iters, sample_stream, &d_ids));   // nullptr: device sampler / arange on every rank
     // a rank that fails leaves the loop: the loopback group must not wait for it (RCCL has its own abort paths)

@@ -137,6 +137,7 @@ struct gh_engine {
 
     // GH_DIST_CDIST (cdist.hip): the reference's cdist + topk values and tie order
     bool cdist = false;
+    bool cd_part = false;             // ... on a row partition: d_partial holds (S, K + 2) per-rank records, the rows are decided at the merge (cdist.hip)
     int Ksel = 0;                     // keys the candidate selection extracts: K, or K + 1 with cdist (boundary ties)
     int32_t *d_rare = nullptr;        // [1..S] = the listed queries: partial_sort's heap is replayed for them
     int32_t *d_cd_rows = nullptr;     // (2, S) per listed slot: prefix length P (ids below it are valued), tail length
@@ -215,6 +216,7 @@ gh_status gh_knn_points_device(hipStream_t stream, const float *d_q, int64_t nq,
                                int D, int K, uint64_t *d_keys, std::string *err);
 // cdist.hip
 gh_status gh_cdist_alloc(gh_engine *h);
+gh_status gh_knn_merge_cdist(gh_engine *h, const uint64_t *gathered, int world);   // row partitions: the ranks' (S, K + 2) records -> d_merged, the reference's rows
 gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows, bool fuse_intersect);   // candidate lists (or nothing) -> d_partial, the reference's rows
 // grid.hip
 bool gh_grid_path(const gh_engine *h);

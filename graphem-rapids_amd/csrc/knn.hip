@@ -675,6 +675,7 @@ gh_status gh_knn_local(gh_engine *h, bool fuse_intersect) {
 }
 
 gh_status gh_knn_merge(gh_engine *h, const uint64_t *gathered, int world) {
+    if (h->cd_part) return gh_knn_merge_cdist(h, gathered, world);   // (S, K + 2) records per rank: the rows are decided now (cdist.hip)
     if (world == 1) {  // nothing to merge: the intersection phase reads this rank's keys directly
         h->d_keys_cur = gathered;
         return GH_OK;

@@ -99,18 +99,19 @@ class HipShardEngine:
     the native loop runs on the engine's own stream and run_partitioned() returns only when it has drained, so the
     views are safe to read afterwards."""
 
-    def __init__(self, n, D, edges, L_min, k_attr, k_inter, k, S, seed, partition, device_id):
+    def __init__(self, n, D, edges, L_min, k_attr, k_inter, k, S, seed, partition, device_id, knn_distance="exact"):
         from . import _native
         from .embedder_hip import device_view
         self.eng = _native.Engine(n, D, edges, L_min, k_attr, k_inter, k, S, seed=seed, device_id=device_id,
-                                  partition=partition)
+                                  partition=partition, knn_distance=knn_distance)
         self.device = torch.device("cuda", device_id)
         self.eng.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         e = self.eng
         self.ld = e.ld
         rows = e.positions_rows_allocated()
         self.pos = device_view(e.positions_device_ptr(), (rows, e.ld), torch.float32, self.device, e)
-        self.partial = device_view(e.knn_partial_device_ptr(), (e.S, k + 1), torch.int64, self.device, e)
+        self.key_cols = e.knn_partial_cols()   # k + 1 keys per query; knn_distance='cdist': k + 2 keys and a flag
+        self.partial = device_view(e.knn_partial_device_ptr(), (e.S, self.key_cols), torch.int64, self.device, e)
         self.stats = device_view(e.stats_partial_device_ptr(), (e.stats_rows(), e.ld), torch.float64, self.device, e)
         self.gbuf = None
 
@@ -148,6 +149,13 @@ class HipShardEngine:
     def step_merge(self, gathered, world):
         self.eng.step_merge(gathered.data_ptr(), world)
 
+    def merged_knn(self):
+        """(S, k) neighbour edge ids of the last merge (column 0 dropped, pt.py:421), as a host array."""
+        from .embedder_hip import device_view
+        e = self.eng
+        keys = device_view(e.knn_merged_device_ptr(), (e.S, e.k + 1), torch.int64, self.device, e)
+        return (keys[:, 1:] & 0xFFFFFFFF).to(torch.int32).cpu().numpy()
+
     def step_finish(self):
         self.eng.step_finish()
 
@@ -167,7 +175,7 @@ class HipShardEngine:
 class PartitionedLayout:
     def __init__(self, n, D, edges, L_min=1.0, k_attr=0.2, k_inter=0.5, n_neighbors=10, sample_size=256, seed=0,
                  rank=None, world=None, device_id=0, engine_factory=None, group=None, edge_ownership="auto", native=False,
-                 finish="own"):
+                 finish="own", knn_distance="exact"):
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.group = group
@@ -185,8 +193,14 @@ class PartitionedLayout:
             self.edge_lo, self.edge_hi = partition_edges(edges, self.row_lo, self.row_hi)
             part = (self.row_lo, self.row_hi, self.edge_lo, self.edge_hi, 0)
         factory = engine_factory or HipShardEngine
+        if knn_distance not in ("exact", "cdist"):
+            raise ValueError(f"knn_distance must be 'exact' or 'cdist', got {knn_distance!r}")
+        self.knn_distance = knn_distance
+        # knn_distance='cdist' (parity mode, the reference's torch.cdist + torch.topk rows, pt.py:580-583): a rank sends its
+        # k + 2 best cdist keys per query and whether they are provably its best; the merge decides the rows whose values
+        # are pairwise different and replays partial_sort's heap for the others over all edges, identically on every rank
         self.engine = factory(self.n, self.D, edges, L_min, k_attr, k_inter, n_neighbors, min(sample_size, len(edges)),
-                              seed, part, device_id)
+                              seed, part, device_id, **({"knn_distance": "cdist"} if knn_distance == "cdist" else {}))
         if finish not in ("own", "gathered"):
             raise ValueError(f"finish must be 'own' or 'gathered', got {finish!r}")
         self.finish = finish
@@ -196,7 +210,8 @@ class PartitionedLayout:
             self.engine.gather_layout(self.world, self.rank, self.chunk)
         self.K = n_neighbors + 1
         self.S = min(sample_size, len(edges))
-        self.gathered = torch.empty((self.world, self.S, self.K), dtype=torch.int64, device=self.engine.pos.device)
+        self.key_cols = getattr(self.engine, "key_cols", self.K)
+        self.gathered = torch.empty((self.world, self.S, self.key_cols), dtype=torch.int64, device=self.engine.pos.device)
         # the loop in the C library over its own RCCL communicator: opt-in (module docstring)
         self.native = bool(native) and hasattr(self.engine, "comm_init_rccl")
         if self.native:
@@ -260,7 +275,7 @@ class PartitionedLayout:
         e = self.engine
         e.step_begin(sampled)
         # output in concatenated form (world*S, K): accepted by both the RCCL and the gloo backend
-        dist.all_gather_into_tensor(self.gathered.view(self.world * self.S, self.K), e.partial, group=self.group)
+        dist.all_gather_into_tensor(self.gathered.view(self.world * self.S, self.key_cols), e.partial, group=self.group)
         e.step_merge(self.gathered, self.world)
         if self.finish == "own":
             dist.all_gather_into_tensor(e.stats_all.view(-1), e.stats.view(-1), group=self.group)   # concatenated form: RCCL and gloo

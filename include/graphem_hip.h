@@ -70,7 +70,13 @@ typedef struct {
  *                  id-sorted rest of the candidate list (csrc/cdist.hip): two more launches per iteration, 270 against
  *                  170 us at a million vertices.  Works on the candidates of GH_KNN_SCAN only: knn_method = GH_KNN_AUTO
  *                  takes the scan whatever the sample size, an explicit GH_KNN_GRID / GH_KNN_IVF is refused
- *                  (GH_ERR_INVALID).  Whole-graph engines only (no gh_partition). */
+ *                  (GH_ERR_INVALID).  On a row partition (gh_partition given) a rank sends, instead of its K best keys, a
+ *                  record of K + 2 words per query (gh_knn_partial_cols): its K + 1 best cdist keys and 1 where it could
+ *                  prove them its K + 1 best; gh_step_merge decides the queries whose merged K + 1 smallest values are
+ *                  pairwise different and replays partial_sort's heap over ALL edges for the others -- every rank holds
+ *                  all positions and the whole edge list, so every rank gets the same rows and no further collective is
+ *                  needed (the single engine's prefix / tail shortcut needs one candidate list; there it is spread over
+ *                  the ranks). */
 #define GH_DIST_EXACT 0
 #define GH_DIST_CDIST 1
 
@@ -218,7 +224,13 @@ int64_t gh_positions_rows_allocated(gh_handle h);
 /* Part 1: spring pull for own rows, KNN scan of own edges.  Afterwards
  * gh_knn_partial_device() holds this rank's S x (k+1) best (dist2, id) keys. */
 gh_status gh_step_begin(gh_handle h, const int32_t *sampled);
-uint64_t *gh_knn_partial_device(gh_handle h);      /* (S, k+1) uint64 keys, ascending */
+uint64_t *gh_knn_partial_device(gh_handle h);      /* (S, gh_knn_partial_cols) uint64: k+1 keys, ascending */
+/* 64-bit words per query of that record: k + 1; a GH_DIST_CDIST engine on a partition: k + 3 (its k + 2 best cdist keys,
+ * then 1 where they are provably its k + 2 best).  gathered of gh_step_merge is (world, S, gh_knn_partial_cols). */
+int32_t gh_knn_partial_cols(gh_handle h);
+/* After gh_step_merge: the (S, k+1) keys of the global KNN the intersection phase read (column 0 included; the id of a
+ * neighbour is the low 32 bits of its key).  Device pointer owned by the handle; NULL before the first merge. */
+const uint64_t *gh_knn_merged_device(gh_handle h);
 /* Part 2: gathered = (world, S, k+1) keys from all ranks (device pointer; may alias a
  * caller buffer).  Merges them, computes intersection forces, integrates own rows and
  * leaves this rank's column sums in gh_stats_partial_device(). */

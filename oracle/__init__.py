@@ -42,6 +42,8 @@ def lib():
         L.go_knn_midpoints_cdist_mm.restype = i32
         L.go_knn_midpoints_aten.argtypes = [_f32p, i32, _i32p, i64, _i32p, i64, i32, _i32p, ctypes.c_void_p]
         L.go_knn_midpoints_aten.restype = i32
+        L.go_cdist_values_aten.argtypes = [_f32p, i32, _i32p, i64, _i32p, i64, _f32p]
+        L.go_cdist_values_aten.restype = i32
         L.go_intersection_forces.argtypes = [_f32p, i64, i32, _i32p, _i32p, i64, _i32p, i32, f32, _f32p,
                                              ctypes.POINTER(i64)]
         L.go_intersection_forces.restype = None
@@ -123,6 +125,15 @@ def knn_midpoints_aten(pos, edges, sampled, k, return_col0=False):
     if err == 1:
         raise RuntimeError("selected index k out of range")
     return (knn, col0) if return_col0 else knn
+
+
+def cdist_values_aten(pos, edges, sampled):
+    """(S, E) float32: ATen's cdist values of the sampled midpoints against every midpoint (the numbers
+    knn_midpoints_aten ranks; oracle/aten_cdist_topk.cpp go_cdist_values_aten)."""
+    pos, edges, sampled = _c(pos, np.float32), _c(edges, np.int32), _c(sampled, np.int32)
+    out = np.empty((sampled.shape[0], edges.shape[0]), dtype=np.float32)
+    lib().go_cdist_values_aten(pos, pos.shape[1], edges, edges.shape[0], sampled, sampled.shape[0], out)
+    return out
 
 
 def step_aten(pos, edges, sampled, k, L_min=1.0, k_attr=0.2, k_inter=0.5, colmajor=False):

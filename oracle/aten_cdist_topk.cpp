@@ -105,3 +105,41 @@ extern "C" int go_knn_midpoints_aten(const float *pos, int D, const int32_t *edg
     }
     return 0;
 }
+
+/* The (S, E) cdist values themselves, as ATen computes them (the formula of go_knn_midpoints_aten above): what a rank of a
+ * row-partitioned run ranks its own edges by (tests/cpu_shard_engine.py, the CPU stand-in of a rank's engine). */
+extern "C" int go_cdist_values_aten(const float *pos, int D, const int32_t *edges, int64_t E, const int32_t *sampled, int64_t S,
+                                    float *out /* (S, E) */) {
+    std::vector<float> mid((size_t)E * D), nrm((size_t)E);
+    for (int64_t e = 0; e < E; ++e) {
+        const float *p1 = pos + (size_t)edges[2 * e] * D, *p2 = pos + (size_t)edges[2 * e + 1] * D;
+        float s = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const float m = (p1[d] + p2[d]) / 2.0f;
+            mid[(size_t)e * D + d] = m;
+            const float sq = m * m;
+            s = s + sq;
+        }
+        nrm[(size_t)e] = s;
+    }
+    const bool mm_form = S > 25 || E > 25;
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < S; ++r) {
+        const float *q = mid.data() + (size_t)sampled[r] * D;
+        const float qn = nrm[(size_t)sampled[r]];
+        for (int64_t e = 0; e < E; ++e) {
+            const float *m = mid.data() + (size_t)e * D;
+            float acc = 0.0f;
+            if (mm_form) {
+                for (int d = 0; d < D; ++d) acc = std::fmaf(q[d] * -2.0f, m[d], acc);
+                acc = std::fmaf(qn, 1.0f, acc);
+                acc = std::fmaf(1.0f, nrm[(size_t)e], acc);
+                out[(size_t)r * E + e] = std::sqrt(acc < 0.0f ? 0.0f : acc);
+            } else {
+                for (int d = 0; d < D; ++d) { const float t = q[d] - m[d]; acc = std::fmaf(t, t, acc); }
+                out[(size_t)r * E + e] = std::sqrt(acc);
+            }
+        }
+    }
+    return 0;
+}

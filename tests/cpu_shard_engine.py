@@ -11,8 +11,10 @@ import oracle
 class CpuShardEngine:
     PAD_ROWS = 1024
 
-    def __init__(self, n, D, edges, L_min, k_attr, k_inter, k, S, seed, partition, device_id):
+    def __init__(self, n, D, edges, L_min, k_attr, k_inter, k, S, seed, partition, device_id, knn_distance="exact"):
         self.n, self.D, self.k, self.S = n, D, k, S
+        self.cdist = knn_distance == "cdist"   # a rank then sends its k + 2 best cdist keys and a "provably my best" flag
+        self.key_cols = k + 3 if self.cdist else k + 1
         self.edges = np.ascontiguousarray(edges, dtype=np.int32)
         self.prm = (L_min, k_attr, k_inter)
         self.row_lo, self.row_hi, edge_lo, edge_hi = partition[:4]
@@ -23,7 +25,7 @@ class CpuShardEngine:
             self.own_ids = np.arange(edge_lo, edge_hi, dtype=np.int64)
         self.ld = 4 if D <= 4 else 8 if D <= 8 else 16 if D <= 16 else (D + 3) // 4 * 4
         self.pos = torch.zeros((n + self.PAD_ROWS, self.ld), dtype=torch.float32)
-        self.partial = torch.zeros((S, k + 1), dtype=torch.int64)
+        self.partial = torch.zeros((S, self.key_cols), dtype=torch.int64)
         self.stats = torch.zeros((2, self.ld), dtype=torch.float64)
         self.seed, self.iter = seed, 0
         self.gbuf = None
@@ -81,6 +83,17 @@ class CpuShardEngine:
         mid = oracle.midpoints(p, self.edges)
         q = mid[self.sampled]
         loc = mid[self.own_ids]
+        if self.cdist:   # this rank's k + 2 smallest (cdist value, id) keys among its own edges; always "proven" here
+            keys = np.full((self.S, self.k + 3), np.iinfo(np.int64).max, dtype=np.int64)
+            if len(self.own_ids):
+                v = oracle.cdist_values_aten(p, self.edges, self.sampled)[:, self.own_ids]
+                key = (v.view(np.uint32).astype(np.int64) << 32) | self.own_ids[None, :]
+                key.sort(axis=1)
+                m = min(self.k + 2, key.shape[1])
+                keys[:, :m] = key[:, :m]
+            keys[:, self.k + 2] = 1 if len(self.own_ids) >= self.k + 2 else 0
+            self.partial[:] = torch.from_numpy(keys)
+            return
         keys = np.full((self.S, self.k + 1), np.iinfo(np.int64).max, dtype=np.int64)  # INF key pattern 0x7FFF..: sorts last
         if len(loc):
             d2 = ((q[:, None, :] - loc[None, :, :]) ** 2).sum(-1, dtype=np.float32)
@@ -92,10 +105,24 @@ class CpuShardEngine:
         self.partial[:] = torch.from_numpy(keys)
 
     def step_merge(self, gathered, world):
-        g = gathered.numpy().transpose(1, 0, 2).reshape(self.S, -1)  # (S, world*K)
-        g = np.sort(g, axis=1)[:, : self.k + 1]
-        knn = (g[:, 1:] & 0xFFFFFFFF).astype(np.int32)               # drop column 0 (pt.py:421)
         p = self._p()
+        if self.cdist:
+            # rows whose merged k + 2 smallest values are pairwise different (every rank's list proven): ascending values;
+            # the others: partial_sort's heap over all edges = the oracle's ATen rows (csrc/cdist.hip knn_merge_cdist_kernel)
+            ga = gathered.numpy()
+            flags_ok = (ga[:, :, self.k + 2] == 1).all(axis=0)
+            g = np.sort(ga[:, :, : self.k + 2].transpose(1, 0, 2).reshape(self.S, -1), axis=1)[:, : self.k + 2]
+            vals = g >> 32
+            decided = flags_ok & (vals[:, 1:] != vals[:, :-1]).all(axis=1)
+            knn = (g[:, 1: self.k + 1] & 0xFFFFFFFF).astype(np.int32)
+            if not decided.all():
+                rows = np.nonzero(~decided)[0]
+                knn[rows] = oracle.knn_midpoints_aten(p, self.edges, self.sampled[rows], self.k)
+            self.last_knn, self.last_listed = knn.copy(), int((~decided).sum())
+        else:
+            g = gathered.numpy().transpose(1, 0, 2).reshape(self.S, -1)  # (S, world*K)
+            g = np.sort(g, axis=1)[:, : self.k + 1]
+            knn = (g[:, 1:] & 0xFFFFFFFF).astype(np.int32)               # drop column 0 (pt.py:421)
         Fi = oracle.intersection_forces(p, self.edges, self.sampled, knn, self.prm[2])[self.row_lo:self.row_hi]
         tot = self.Fs + Fi
         self.new = p[self.row_lo:self.row_hi] + tot

@@ -33,10 +33,13 @@ def _worker(rank, world, port, case, out_dir):
     n, D, edges, pos, stream, k, S = case[:7]
     lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=3, rank=rank, world=world,
                             engine_factory=CpuShardEngine, edge_ownership=case[7] if len(case) > 7 else "auto",
-                            finish=case[8] if len(case) > 8 else "own")
+                            finish=case[8] if len(case) > 8 else "own", knn_distance=case[9] if len(case) > 9 else "exact")
     lay.set_positions(pos)
     lay.run(len(stream), stream)
     np.save(os.path.join(out_dir, f"pos_w{world}_r{rank}.npy"), lay.get_positions())
+    if len(case) > 9 and case[9] == "cdist":   # the rows of the last step, and how many of them needed the heap replayed
+        np.save(os.path.join(out_dir, f"knn_w{world}_r{rank}.npy"), lay.engine.last_knn)
+        np.save(os.path.join(out_dir, f"listed_w{world}_r{rank}.npy"), np.array([lay.engine.last_listed]))
     lay.set_positions(pos)
     lay.run(2)  # engine-drawn samples must agree across ranks too
     np.save(os.path.join(out_dir, f"auto_w{world}_r{rank}.npy"), lay.get_positions())
@@ -69,6 +72,32 @@ def test_partitioned_layout_matches_single_rank_and_oracle(world, rule, finish, 
         assert np.abs(got - ref).max() < 1e-4                        # and == the oracle
         auto = np.load(tmp_path / f"auto_w{world}_r{r}.npy")
         assert np.array_equal(auto, np.load(tmp_path / f"auto_w{world}_r0.npy"))  # every rank holds the same positions
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind", ["gauss", "lattice"])
+def test_parity_mode_on_row_partitions(world, kind, tmp_path):
+    """knn_distance='cdist' on row partitions: every rank sends its k + 2 best cdist keys and a flag, the merge decides the
+    rows without a tie and hands the others to partial_sort's replay over all edges -- the rows must be the reference's
+    (oracle.knn_midpoints_aten: torch.cdist + torch.topk, pt.py:580-583) on every rank, ties included (the lattice case
+    has them in every row), and the positions those of the oracle's ATen-mode steps."""
+    import oracle
+    # E = 4808 >= 64 (k + 1): partial_sort's regime.  (One step from the lattice: its ties are gone after a normalisation.)
+    n, D, edges, pos, stream, k, S = _case(n=1203, deg=8, k=6, S=48, iters=1 if kind == "lattice" else 2)
+    if kind == "lattice":
+        pos = (np.random.default_rng(5).integers(-5, 6, size=(n, D)) / 4.0).astype(np.float32)
+    case = (n, D, edges, pos, stream, k, S, "hashed", "own", "cdist")
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    ref = pos
+    for t in range(len(stream)):
+        last_state = ref
+        ref = oracle.step_aten(ref, edges, stream[t], k)
+    want = oracle.knn_midpoints_aten(last_state, edges, stream[-1], k)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"knn_w{world}_r{r}.npy"), want), f"rank {r}: not the reference's rows"
+        assert np.abs(np.load(tmp_path / f"pos_w{world}_r{r}.npy") - ref).max() < 1e-4
+        if kind == "lattice":
+            assert int(np.load(tmp_path / f"listed_w{world}_r{r}.npy")[0]) > 0   # the tie path was really taken
 
 
 def test_hashed_ownership_partitions_the_edges_evenly():

@@ -128,14 +128,124 @@ def test_tiny_graphs_where_aten_ranks_with_nth_element():
     eng.close()
 
 
-def test_cdist_engines_refuse_partitions():
+PART_CASES = [
+    # world, n, D, k, S, positions
+    (2, 30000, 3, 10, 256, "lattice_fine"),   # own edges >= 16384: the ranks scan, re-value and prove their lists
+    (3, 30000, 3, 10, 256, "start"),
+    (8, 30000, 3, 10, 128, "lattice_fine"),   # 15 K own edges: too few for the scan -- nothing proven, every row replayed
+    (3, 50000, 2, 5, 256, "lattice_fine"),
+    (2, 40000, 6, 20, 128, "lattice_fine"),   # K = 21: the lane heap
+    (3, 5000, 3, 10, 64, "lattice"),
+]
+
+
+@pytest.mark.parametrize("world,n,D,k,S,kind", PART_CASES)
+def test_cdist_on_row_partitions_gives_the_references_rows(world, n, D, k, S, kind):
+    """knn_distance='cdist' with gh_partition: `world` engines on this GPU, the all-gather of the
+    ranks' (S, k + 3) records emulated by a device copy.  The merged rows must be the single cdist engine's = ATen's
+    (oracle.knn_midpoints_aten), row for row on every rank, ties included; one whole step must land on the oracle's
+    ATen-mode step."""
+    import torch
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd.distributed import HipShardEngine, partition_rows
+    from graphem_rapids_amd import _native
+    rng = np.random.default_rng(n + 17 * world + k)
+    edges = np.ascontiguousarray(gra.random_regular_edges(n, 8, seed=D + k), dtype=np.int32)
+    E = len(edges)
+    pos = _positions(kind, n, D, rng)
+    sampled = rng.permutation(E)[:S].astype(np.int32)
+    want = oracle.knn_midpoints_aten(pos, edges, sampled, k)
+    shards = []
+    for r in range(world):
+        chunk, lo, hi = partition_rows(n, world, r)
+        sh = HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, (lo, hi, 0, 0, _native.EDGES_HASHED), 0, knn_distance="cdist")
+        assert sh.key_cols == k + 3
+        sh.rank_layout(world, r, chunk)
+        sh.set_positions(pos)
+        shards.append(sh)
+    for sh in shards:
+        sh.step_begin(sampled)
+    gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()
+    for sh in shards:
+        sh.step_merge(gathered, world)
+    listed = []
+    for r, sh in enumerate(shards):
+        knn = sh.merged_knn()
+        bad = np.nonzero(~(knn == want).all(axis=1))[0]
+        assert len(bad) == 0, f"rank {r}: {len(bad)} rows differ; first: row {bad[0]}\n  hip  {knn[bad[0]]}\n  aten {want[bad[0]]}"
+        full, unresolved = sh.eng.knn_cdist_stats()
+        assert unresolved == 0
+        listed.append(full)
+    assert len(set(listed)) == 1          # every rank lists the same rows
+    if kind.startswith("lattice"):
+        assert listed[0] > 0              # the tie path was really taken
+    stats_all = torch.stack([sh.stats.clone() for sh in shards]).contiguous()
+    for sh in shards:
+        sh.step_finish_own(stats_all)
+    blocks = torch.stack([sh.pos_blocks[r].clone() for r, sh in enumerate(shards)])
+    for sh in shards:
+        sh.pos_blocks.copy_(blocks)
+    torch.cuda.synchronize()
+    ref = oracle.step_aten(pos, edges, sampled, k)
+    outs = [sh.get_positions() for sh in shards]
+    assert np.abs(outs[0] - ref).max() <= 1e-4
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+    for sh in shards:
+        sh.eng.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_native_partitioned_loop_in_parity_mode(world):
+    """gh_run_partitioned (csrc/comm.hip) with knn_distance='cdist': `world` engines, one host thread each, collectives by
+    the in-process loopback backend: three iterations from a lattice (ties in every row of the first one) must follow the
+    single cdist engine, and every rank must end with identical bits."""
+    import threading
     import graphem_rapids_amd as gra
     from graphem_rapids_amd import _native
-    n = 20000
-    edges = gra.random_regular_edges(n, 8, seed=1).astype(np.int32)
-    with pytest.raises(ValueError, match="whole graph"):
-        _native.Engine(n, 3, edges, 1.0, 0.2, 0.5, 10, 256, knn_distance="cdist",
-                       partition=(0, n // 2, 0, 0, _native.EDGES_HASHED))
+    from graphem_rapids_amd.distributed import partition_rows
+    n, D, k, S = 40000, 3, 10, 256
+    edges = np.ascontiguousarray(gra.random_regular_edges(n, 8, seed=2), dtype=np.int32)
+    rng = np.random.default_rng(world)
+    pos = _positions("lattice_fine", n, D, rng)
+    stream = np.stack([rng.permutation(len(edges))[:S] for _ in range(3)]).astype(np.int32)
+    single = _engine(n, D, edges, k, S)
+    single.set_positions(pos)
+    single.run(3, stream)
+    ref = single.get_positions()
+    single.close()
+    lib = _native.load()
+    group = lib.gh_loopback_group_create(world)
+    engines = []
+    for r in range(world):
+        chunk, lo, hi = partition_rows(n, world, r)
+        e = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_distance="cdist", partition=(lo, hi, 0, 0, _native.EDGES_HASHED))
+        e.rank_layout(world, r, chunk)
+        e.comm_init_loopback(group, r)
+        e.set_positions(pos)
+        engines.append(e)
+    errors = []
+
+    def work(e):
+        try:
+            e.run_partitioned(3, stream)
+            e.sync()
+        except Exception as exc:  # pylint: disable=broad-exception-caught
+            errors.append(exc)
+    threads = [threading.Thread(target=work, args=(e,)) for e in engines]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in threads), errors
+    outs = [e.get_positions() for e in engines]
+    for e in engines:
+        e.comm_destroy()
+        e.close()
+    lib.gh_loopback_group_destroy(group)
+    assert np.abs(outs[0] - ref).max() <= 2e-6
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
 
 
 def test_public_api_defaults_to_cdist_with_the_torch_sampler():
