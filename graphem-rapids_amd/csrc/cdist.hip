@@ -26,10 +26,11 @@
 //      heap iff value_i < (K-th smallest of values 0 .. i-1), a bound that only falls with i.  Round 4: that bound is
 //      used twice so that the replay never sees more than a sliver of the E values (round 3 valued all E edges for every
 //      listed row -- 86 us of gathers at a million vertices -- and one wave walked them for 188 us):
-//        a. the candidate list already holds every edge with a safely small value; sorted by id, its K-th member sits at
-//           id P - 1 (about E K / |list| = E / stride): from id P on the heap's maximum is <= the largest of those K
-//           values, which clears the bound of (2), so every element that enters from P on IS in the list.  The select
-//           workgroup of a listed row finds P and bucket-sorts the list's tail (ids >= P) by id, in place;
+//        a. the candidate list already holds every edge with a safely small value; by the id P where K of them (clearing
+//           the bound of (2)) have been seen -- about E K / |list| = E / stride, rounded up to one of 1024 equal id
+//           ranges -- the heap's maximum is <= the largest of those K values, so every element that enters from P on
+//           IS in the list.  The select workgroup of a listed row finds P from a histogram of the list's ids and puts the
+//           list's tail (ids >= P) in id order (range start + rank inside the range), in registers / LDS;
 //        b. cdist_prefix_kernel values only the ids below P (chip-wide; minima per 64 ids on the side);
 //        c. cdist_replay_kernel (one workgroup per listed row; wave 0 replays, all four waves fetch) walks the prefix --
 //           skipping 64-id chunks whose minimum cannot enter, the live ones staged through LDS 128 at a time -- then
@@ -38,8 +39,11 @@
 //           the sift path through v_readlane, every lane on the path deciding for itself): ~0.1 us instead of ~0.3.
 //      A row whose list overflowed or could not be proven complete takes P = E (no tail): the round-3 full pass.
 //   EVERY row of a graph too small for the scan takes (b) + (c) with P = E.
-//   Rows of graphs with K * 64 > E (tiny ones) are ranked by std::nth_element + std::sort in ATen; their values are
-//   computed as above and equal values ordered by id, counted in gh_knn_cdist_stats when a tie is present.
+//   Rows of graphs with K * 64 > E (tiny ones) are ranked by std::nth_element + std::sort in ATen: cdist_nth_kernel replays
+//   libstdc++'s introselect and introsort on their values (E <= 8000; beyond, equal values are ordered by id and a row with a
+//   tie is counted in gh_knn_cdist_stats).
+//   Row partitions: a rank stops at (2) with its K + 1 best keys and a proof flag; after the all-gather
+//   knn_merge_cdist_kernel decides the rows without a tie and lists the others, which every rank replays with P = E.
 #include "common.h"
 #include "engine.h"
 #include "scan_core.h"
@@ -851,6 +855,137 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
 #undef GH_CD_STAMP
 }
 
+// ---- tiny graphs: K * 64 > E -------------------------------------------------------------------------------------------
+// There ATen's topk (ATen/native/TopKImpl.h topk_impl_loop) ranks with std::nth_element(first, first + K - 1, last) followed by
+// std::sort(first, first + K - 1): equal values come out in the order libstdc++'s introselect and introsort leave them.  One
+// wave per row replays both on the row's (value, index) pairs in LDS -- the algorithms as written in bits/stl_algo.h
+// (__introselect, __unguarded_partition_pivot, __move_median_to_first, __unguarded_partition, __insertion_sort,
+// __introsort_loop, __final_insertion_sort), control flow uniform over the wave, lane 0 storing, all lanes reading; the two
+// scans of a partition step look at 64 elements per ballot.  E <= GH_CD_NTH_MAX (64 KB of LDS); beyond that -- K > 125 on a
+// graph of a few thousand edges -- the heap replay above ranks the row and counts it when a tie is present.
+// A depth limit that runs out (libstdc++ then switches to heap select / heap sort; adversarial inputs only) is not followed:
+// the partitioning simply goes on and the row is counted in hdr[1].
+#define GH_CD_NTH_MAX 8000
+struct cdist_nth {
+    uint64_t *a;   // LDS: (value key << 32 | index)
+    int n, lane;
+    bool gave_up;
+    __device__ __forceinline__ void fence() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    __device__ __forceinline__ uint64_t ld(int i) const { return a[i]; }
+    __device__ __forceinline__ uint32_t v(int i) const { return (uint32_t)(a[i] >> 32); }
+    __device__ __forceinline__ void st(int i, uint64_t x) { if (lane == 0) a[i] = x; fence(); }
+    __device__ __forceinline__ void swap(int i, int j) { const uint64_t x = ld(i), y = ld(j); st(i, y); st(j, x); }
+    __device__ __forceinline__ static int lg(int x) { return 31 - __builtin_clz(x); }
+    // std::__move_median_to_first(result, a, b, c)
+    __device__ __forceinline__ void median_to_first(int result, int ia, int ib, int ic) {
+        const uint32_t va = v(ia), vb = v(ib), vc = v(ic);
+        if (va < vb) {
+            if (vb < vc) swap(result, ib);
+            else if (va < vc) swap(result, ic);
+            else swap(result, ia);
+        } else if (va < vc) swap(result, ia);
+        else if (vb < vc) swap(result, ic);
+        else swap(result, ib);
+    }
+    // std::__unguarded_partition(first, last, pivot): the scans stop at elements not below / not above the pivot, which
+    // exist inside [first - 1, last] by construction (the median sits at first - 1, an element not below it at or before last)
+    __device__ __forceinline__ int partition(int first, int last, int pivot) {
+        const uint32_t pv = v(pivot);
+        for (;;) {
+            for (;;) {   // while (comp(first, pivot)) ++first;
+                const int i = first + lane;
+                const unsigned long long m = __ballot(i >= n || !(v(i < n ? i : n - 1) < pv));
+                if (m) { first += __builtin_ctzll(m); break; }
+                first += 64;
+            }
+            --last;
+            for (;;) {   // while (comp(pivot, last)) --last;
+                const int i = last - lane;
+                const unsigned long long m = __ballot(i < 0 || !(pv < v(i >= 0 ? i : 0)));
+                if (m) { last -= __builtin_ctzll(m); break; }
+                last -= 64;
+            }
+            if (!(first < last)) return first;
+            swap(first, last);
+            ++first;
+        }
+    }
+    __device__ __forceinline__ int partition_pivot(int first, int last) {   // std::__unguarded_partition_pivot
+        const int mid = first + (last - first) / 2;
+        median_to_first(first, first + 1, mid, last - 1);
+        return partition(first + 1, last, first);
+    }
+    __device__ __forceinline__ void linear_insert(int last) {   // std::__unguarded_linear_insert
+        const uint64_t val = ld(last);
+        int next = last - 1;
+        while ((uint32_t)(val >> 32) < v(next)) { st(last, ld(next)); last = next; --next; }
+        st(last, val);
+    }
+    __device__ __forceinline__ void insertion_sort(int first, int last) {   // std::__insertion_sort
+        if (first == last) return;
+        for (int i = first + 1; i != last; ++i) {
+            if (v(i) < v(first)) {
+                const uint64_t val = ld(i);
+                for (int j = i; j > first; --j) st(j, ld(j - 1));   // std::move_backward(first, i, i + 1)
+                st(first, val);
+            } else {
+                linear_insert(i);
+            }
+        }
+    }
+    __device__ __forceinline__ void nth_element(int nth) {   // std::nth_element(0, nth, n): __introselect
+        if (n == 0 || nth == n) return;
+        int first = 0, last = n, depth = lg(n) * 2;
+        while (last - first > 3) {
+            if (depth == 0) gave_up = true; else --depth;
+            const int cut = partition_pivot(first, last);
+            if (cut <= nth) first = cut; else last = cut;
+        }
+        insertion_sort(first, last);
+    }
+    __device__ __forceinline__ void sort(int cnt) {   // std::sort(0, cnt): __introsort_loop + __final_insertion_sort
+        if (cnt <= 0) return;
+        // the recursion of __introsort_loop as an explicit stack: the two sides of a cut are disjoint ranges, sorted
+        // independently of each other, so the order they are taken in does not matter
+        int sf[48], sl[48], sd[48], sp = 0;
+        sf[0] = 0; sl[0] = cnt; sd[0] = lg(cnt) * 2; sp = 1;
+        while (sp > 0) {
+            --sp;
+            int first = sf[sp], last = sl[sp], depth = sd[sp];
+            while (last - first > 16) {
+                if (depth == 0) gave_up = true; else --depth;
+                const int cut = partition_pivot(first, last);
+                if (sp < 48) { sf[sp] = cut; sl[sp] = last; sd[sp] = depth; ++sp; } else gave_up = true;
+                last = cut;
+            }
+        }
+        if (cnt > 16) {
+            insertion_sort(0, 16);
+            for (int i = 16; i != cnt; ++i) linear_insert(i);   // std::__unguarded_insertion_sort
+        } else {
+            insertion_sort(0, cnt);
+        }
+    }
+};
+__global__ __launch_bounds__(64) void cdist_nth_kernel(int S, int r0, int R, int64_t E, int K, const float *__restrict__ vbuf, int64_t vstride,
+                                                       uint64_t *__restrict__ out_keys, int32_t *__restrict__ hdr) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int t = r0 + (int)blockIdx.x;
+    if (t >= min(S, r0 + R)) return;
+    const float *v = vbuf + (int64_t)(t - r0) * vstride;
+    cdist_nth q;
+    q.a = reinterpret_cast<uint64_t *>(smem_raw);
+    q.n = (int)E;
+    q.lane = threadIdx.x;
+    q.gave_up = false;
+    for (int i = threadIdx.x; i < q.n; i += 64) q.a[i] = ((uint64_t)cdist_vkey(v[i]) << 32) | (uint32_t)i;
+    q.fence();
+    q.nth_element(K - 1);
+    q.sort(K - 1);
+    for (int i = threadIdx.x; i < K; i += 64) out_keys[(int64_t)t * K + i] = q.a[i];
+    if (q.gave_up && threadIdx.x == 0) atomicAdd(&hdr[1], 1);
+}
+
 cdist_args make_cdist_args(gh_engine *h) {
     return cdist_args{h->d_pos, h->d_edges, h->D, h->LD, h->E, h->d_q, gh_qs(h->D, h->LD), gh_qtau(h->D, h->LD),
                       (h->S > 25 || h->E > 25) ? 1 : 0};
@@ -917,6 +1052,13 @@ static gh_status cdist_replay_rounds(gh_engine *h, const cdist_args &a, const cd
             }
 #undef GH_CPRE
             GH_LAUNCH_CHECK();
+        }
+        if (nth_form && all_rows && h->E <= GH_CD_NTH_MAX) {   // tiny graphs: ATen's nth_element + sort, replayed
+            gh_scope t(h, "cdist_nth");
+            cdist_nth_kernel<<<dim3((unsigned)h->cd_R), dim3(64), sizeof(uint64_t) * (size_t)h->E, h->stream>>>(
+                (int)h->S, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride, out_keys, rr.hdr);
+            GH_LAUNCH_CHECK();
+            continue;
         }
         gh_scope t(h, fuse ? "cdist_replay_intersect" : "cdist_replay");
         const size_t smem = h->K <= 64 ? 0 : sizeof(uint64_t) * (size_t)h->K;

@@ -316,9 +316,11 @@ gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64_t count);
  * (any of the three (S,) host pointers may be NULL).  Blocking. */
 gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final_counts, int32_t *overflow);
 /* GH_DIST_CDIST engines, last KNN search: rows whose partial_sort heap was replayed (a tie among their K + 1 smallest
- * cdist values, or a candidate list that could not be proven complete), and rows whose tie order ATen decides with
- * std::nth_element (K * 64 > E, tiny graphs) -- there equal values come out in (value, id) order and the row is
- * counted here instead of being reproduced.  Either pointer may be NULL.  Blocking. */
+ * cdist values, or a candidate list that could not be proven complete), and rows NOT reproduced.  Tiny graphs
+ * (K * 64 > E), where ATen ranks with std::nth_element + std::sort, get libstdc++'s introselect and introsort replayed
+ * (E <= 8000: tie order reproduced; the second count then only holds rows whose introselect depth limit ran out, which
+ * adversarial inputs alone do); with K * 64 > E > 8000 (more than 125 neighbours on a graph of a few thousand edges)
+ * equal values come out in (value, id) order and a row with a tie is counted.  Either pointer may be NULL.  Blocking. */
 gh_status gh_knn_cdist_stats(gh_handle h, int32_t *full_pass_rows, int32_t *unresolved_tie_rows);
 /* GH_KNN_IVF engines: the number of inverted lists and of lists probed per query the engine settled on (0, 0 when the
  * engine searches another way).  Either pointer may be NULL. */

@@ -102,29 +102,36 @@ def test_cdist_rows_equal_atens_on_random_graphs(n, deg, D, k, S, kind):
     eng.close()
 
 
-def test_tiny_graphs_where_aten_ranks_with_nth_element():
-    """K * 64 > E: ATen's topk takes std::nth_element + std::sort.  Without a tie the rows are the same; rows with a tie
-    are put in (value, id) order and COUNTED (gh_knn_cdist_stats) rather than reproduced."""
+@pytest.mark.parametrize("n,deg,D,k,kind", [
+    (120, 4, 3, 10, "gauss"),          # E = 240 < 64 * 11
+    (120, 4, 3, 10, "lattice"),        # ties in every row: introselect's and introsort's order of equal values
+    (300, 4, 2, 10, "lattice"),        # E = 600
+    (200, 6, 3, 10, "lattice_fine"),
+    (1500, 4, 3, 60, "lattice"),       # K = 61: E = 3000 < 3904; K - 1 > 16: the introsort loop partitions
+    (3000, 4, 3, 100, "lattice_fine"), # K = 101: E = 6000 < 6464
+    (50, 4, 16, 5, "lattice"),
+])
+def test_tiny_graphs_where_aten_ranks_with_nth_element(n, deg, D, k, kind):
+    """K * 64 > E: ATen's topk takes std::nth_element + std::sort.  The engine replays libstdc++'s introselect and
+    introsort on the row's (value, index) pairs (csrc/cdist.hip cdist_nth_kernel): rows with ties come out in ATen's
+    order too (round 3 put them in id order and counted them)."""
     import graphem_rapids_amd as gra
-    n, k = 120, 10
-    edges = np.ascontiguousarray(gra.random_regular_edges(n, 4, seed=1), dtype=np.int32)   # E = 240 < 704
+    edges = np.ascontiguousarray(gra.random_regular_edges(n, deg, seed=1), dtype=np.int32)
     E = len(edges)
-    rng = np.random.default_rng(0)
-    pos = rng.standard_normal((n, 3)).astype(np.float32)
-    eng = _engine(n, 3, edges, k, E)
+    assert (k + 1) * 64 > E
+    rng = np.random.default_rng(n + k)
+    pos = _positions(kind, n, D, rng)
+    eng = _engine(n, D, edges, k, E)
     eng.set_positions(pos)
+    ids = np.arange(E, dtype=np.int32)
     knn = eng.knn_midpoints(None)
     full, unresolved = eng.knn_cdist_stats()
-    want = oracle.knn_midpoints_aten(pos, edges, np.arange(E, dtype=np.int32), k)
-    assert full == E and unresolved == 0 and np.array_equal(knn, want)
-    lat = (rng.integers(-2, 3, size=(n, 3)) / 2.0).astype(np.float32)
-    eng.set_positions(lat)
-    knn = eng.knn_midpoints(None)
-    full, unresolved = eng.knn_cdist_stats()
-    want = oracle.knn_midpoints_aten(lat, edges, np.arange(E, dtype=np.int32), k)
-    assert unresolved > 0
-    same = (knn == want).all(axis=1)
-    assert same.sum() >= E - unresolved     # every row without a tie is ATen's
+    want = oracle.knn_midpoints_aten(pos, edges, ids, k)
+    bad = np.nonzero(~(knn == want).all(axis=1))[0]
+    assert len(bad) == 0, f"{len(bad)} of {E} rows differ; first: row {bad[0]}\n  hip  {knn[bad[0]]}\n  aten {want[bad[0]]}"
+    assert full == E and unresolved == 0
+    eng.step(None)
+    assert np.abs(eng.get_positions() - oracle.step_aten(pos, edges, ids, k)).max() <= 1e-4
     eng.close()
 
 
