@@ -15,7 +15,8 @@
 // How the engine gets there without an (S, E) matrix:
 //   1. the filtered scan runs unchanged with a threshold for K + 1 neighbours: the candidate list of a query holds every
 //      edge whose EXACT squared distance (fma chain) is <= tau;
-//   2. knn_select_cdist_kernel re-values the few hundred candidates with the formula above (two row gathers each),
+//   2. a candidate is parked with the formula's value in its key (the scan has both midpoints at hand: scan_core.h
+//      gh_aten_cdist; round 3 re-valued the lists in the selection launch: two dependent row gathers); knn_select_cdist_kernel
 //      extracts the K + 1 smallest (value, id) keys and PROVES the list complete for cdist's ranking: an edge outside
 //      has exact distance > tau, hence acc > tau (1 - (7D + 15) u) - 3 (3D + 6) u |q|^2, u = 2^-24 (derivation at
 //      cdist_lower_bound); if the (K+1)-th smallest value clears that bound and the K + 1 values are pairwise
@@ -195,23 +196,16 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
     const bool in_regs = c <= 1024 && Ks <= 16;          // the usual case: re-valued keys never leave the registers
     uint64_t keep[4] = {GH_KEY_INF, GH_KEY_INF, GH_KEY_INF, GH_KEY_INF};
     if (!reason) {
+        // (the scan parked every candidate with ATen's cdist value in its key already: scan_core.h gh_aten_cdist)
         if (in_regs) {
             uint64_t keys[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (j * 256 + (int)threadIdx.x < c) {
-                    const uint32_t id = gh_key_id(pre[j]);
-                    keep[j] = gh_key(cdist_pair<LDT>(a, qs, qn, id), id);
-                }
+                if (j * 256 + (int)threadIdx.x < c) keep[j] = pre[j];
                 keys[j] = keep[j];
             }
             block_extract_smallest<4>(keys, Ks, best, red);
         } else {
-            for (int i = threadIdx.x; i < c; i += 256) {
-                const uint32_t id = gh_key_id(list[i]);
-                list[i] = gh_key(cdist_pair<LDT>(a, qs, qn, id), id);
-            }
-            __syncthreads();
             block_extract_list(list, c, Ks, best, best2, red);
         }
         int bad = 0;

@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void spring_scan_mfma_kernel(
             d2 = fmaf(df, df, d2);
         }
         if (d2 <= qr.w) {
+            if (ta.cdist) d2 = gh_aten_cdist<D>(q, m);   // parity mode: the key carries the value the reference ranks
             const uint32_t id = ids[j];
             const int p = atomicAdd(&hcount, 1);
             if (p < HITBUF) { hkey[p] = gh_key(d2, id); hq[p] = s_lo + s; }
@@ -412,6 +413,12 @@ __global__ __launch_bounds__(256) void spring_scan_mfmaw_kernel(
             d2 = fmaf(df, df, d2);
         }
         if (d2 <= taush[s]) {
+            if (ta.cdist) {   // parity mode: the key carries the value the reference ranks
+                float q[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) q[d] = -0.5f * qv[d];
+                d2 = gh_aten_cdist<D>(q, mv);
+            }
             const uint32_t id = ids[j];
             const int p = atomicAdd(&hcount, 1);
             if (p < HITBUF) { hkey[p] = gh_key(d2, id); hq[p] = s_lo + s; }
@@ -544,8 +551,10 @@ static unsigned fused_grid(const gh_engine *h, const gh_tau_args &ta) {
 }
 gh_tau_args fused_tau_args(gh_engine *h, int nt) {
     gh_tau_args ta{};
+    ta.cdist = h->cdist ? 1 : 0;
     if (!h->tau_embedded) return ta;
     ta = gh_make_tau_args(h);
+    ta.cdist = h->cdist ? 1 : 0;
     ta.flag = h->d_tau_flag;          // zeroed by this iteration's set-up (setup_core.h), S once the producers are through
     ta.target = (unsigned)h->S;
     ta.nblocks = gh_tau_blocks((int)h->S, nt);

@@ -209,7 +209,7 @@ template <int D, int R>
 __global__ __launch_bounds__(256) void knn_scan_kernel(
     const float *__restrict__ mid, int64_t e_lo, const int32_t *__restrict__ eids, int64_t M, int64_t mem_stride, int64_t stride,
     const float *__restrict__ qt, const float *__restrict__ qscan, int S, int qgroup,
-    uint64_t *__restrict__ cand, int32_t *__restrict__ cnt) {
+    uint64_t *__restrict__ cand, int32_t *__restrict__ cnt, int cdist /* GH_DIST_CDIST: keys carry ATen's cdist value */) {
     static_assert(R % 2 == 0, "references are processed in packed pairs");
     constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void knn_scan_kernel(
         }
     }
     __syncthreads();
-    gh_scan_queries<D, R, GH_SCAN_HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt);
+    gh_scan_queries<D, R, GH_SCAN_HITBUF>(m, c0, id, qsh, nq, s_lo, taush, hkey, hq, &hcount, cand, cnt, nullptr, cdist);
     __syncthreads();
     gh_flush_hits<GH_SCAN_HITBUF>(hkey, hq, &hcount, cand, cnt);
 }
@@ -443,7 +443,8 @@ void launch_scan(gh_engine *h, const float *mid, int64_t M, int64_t mem_stride, 
     if (qgroup > GH_SCAN_QGROUP) qgroup = GH_SCAN_QGROUP;
     groups = (int)((h->S + qgroup - 1) / qgroup);
     knn_scan_kernel<D, R><<<dim3((unsigned)tiles, (unsigned)groups), dim3(256), 0, h->stream>>>(
-        mid, h->part.edge_lo, h->d_own_eids, M, mem_stride, id_stride, h->d_q, h->d_qscan, (int)h->S, qgroup, h->d_cand, h->d_cnt);
+        mid, h->part.edge_lo, h->d_own_eids, M, mem_stride, id_stride, h->d_q, h->d_qscan, (int)h->S, qgroup, h->d_cand, h->d_cnt,
+        h->cdist ? 1 : 0);
 }
 
 template <int R>

@@ -70,6 +70,30 @@ __device__ __forceinline__ float gh_ref_c0(const float *mv, bool valid) {
     return fmaf(-gh_filter_eps(D), rn, rn);
 }
 
+// GH_DIST_CDIST (cdist.hip): the value ATen's torch.cdist gives the pair (its matmul form, taken whenever either side has
+// more than 25 rows -- always on the scan path): |x|^2 = sum of rounded squares left to right; acc = fma(-2 q_d, m_d, acc) from
+// 0; acc += |q|^2; acc += |m|^2; sqrt(max(acc, 0)).  A candidate that passed the exact test d2 <= tau is parked with THIS value
+// in its key, so that the selection ranks what the reference ranks without gathering the pair's rows again (round 3 re-valued
+// the candidates in the selection launch: two dependent gathers, 27 against 15 us).
+template <int D>
+__device__ __forceinline__ float gh_aten_cdist(const float *q, const float *m) {
+    float qn = 0.0f, mn = 0.0f, acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float sq = q[d] * q[d];
+        qn = qn + sq;
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float sq = m[d] * m[d];
+        mn = mn + sq;
+        acc = fmaf(q[d] * -2.0f, m[d], acc);
+    }
+    acc = acc + qn;
+    acc = acc + mn;
+    return sqrtf(fmaxf(acc, 0.0f)) + 0.0f;   // (+ 0: a -0 must not read as the largest key)
+}
+
 // R reference midpoints per thread, held as R/2 packed pairs so the arithmetic runs on
 // v_pk_fma_f32 (two references per VALU instruction: measured, a plain fp32 VALU op occupies a
 // SIMD for 4 cycles, so packed math is the only way past half of the fp32 vector peak).  The query
@@ -89,7 +113,8 @@ __device__ __forceinline__ void gh_scan_queries(const gh_f2 (&m)[R / 2][D], cons
                                                 const uint32_t (&id)[R], const float4 *qsh, int nq, int s_lo,
                                                 const float *taush, uint64_t *hkey, int *hq,
                                                 int *hcount, uint64_t *__restrict__ cand,
-                                                int32_t *__restrict__ cnt, const int *qmap = nullptr /* LDS: query of slot s (ivf.hip) */) {
+                                                int32_t *__restrict__ cnt, const int *qmap = nullptr /* LDS: query of slot s (ivf.hip) */,
+                                                int cdist = 0 /* GH_DIST_CDIST: keys carry ATen's cdist value */) {
     constexpr int LD = D <= 4 ? 4 : D <= 8 ? 8 : 16;
     constexpr int QS = D <= 3 ? 4 : LD + 4;
     constexpr int QT = D <= 3 ? 3 : LD;
@@ -132,6 +157,12 @@ __device__ __forceinline__ void gh_scan_queries(const gh_f2 (&m)[R / 2][D], cons
                         d2 = fmaf(df, df, d2);
                     }
                     if (d2 <= tau) {
+                        if (cdist) {
+                            float mr[D];
+#pragma unroll
+                            for (int d = 0; d < D; ++d) mr[d] = (r & 1) ? m[r / 2][d].y : m[r / 2][d].x;
+                            d2 = gh_aten_cdist<D>(q, mr);
+                        }
                         const int p = atomicAdd(hcount, 1);
                         if (p < HITBUF) { hkey[p] = gh_key(d2, id[r]); hq[p] = sg; }
                         else gh_append_candidate(cand, cnt, sg, gh_key(d2, id[r]));

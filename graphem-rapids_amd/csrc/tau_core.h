@@ -22,7 +22,8 @@ struct gh_tau_args {
     unsigned target;          // value of *flag once this launch's S queries are out (= S)
     int nblocks;              // workgroups at the head of the grid that compute thresholds (0: a launch of their own did)
     int32_t *wait_failed;     // set when a consumer gave up waiting (cannot happen while workgroups start in index order)
-    // -- tile mapping of the fused launch (rides here: every fused kernel takes this struct)
+    // -- rides here because every fused kernel takes this struct
+    int cdist;                // GH_DIST_CDIST: the parked candidates carry ATen's cdist value in their keys (scan_core.h gh_aten_cdist)
 };
 
 // One wave, one query: the minima sit NV per lane in
