@@ -17,7 +17,7 @@ GH_OK, GH_ERR_INVALID, GH_ERR_RUNTIME, GH_ERR_K_TOO_LARGE, GH_ERR_HIP, GH_ERR_NO
 SYMBOLS = [
     "gh_create", "gh_destroy", "gh_last_error", "gh_set_positions", "gh_get_positions", "gh_positions_device",
     "gh_row_stride", "gh_step", "gh_run", "gh_sync", "gh_spring_forces", "gh_knn_midpoints",
-    "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_knn_partial_cols", "gh_knn_merged_device", "gh_step_merge",
+    "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_knn_partial_cols", "gh_knn_merged_device", "gh_rows_packed_device", "gh_step_unpack_rows", "gh_step_merge",
     "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
     "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts", "gh_set_stream",
     "gh_positions_rows_allocated", "gh_knn_points", "gh_stats_rows", "gh_spmv_symnorm",
@@ -129,6 +129,10 @@ def load():
     L.gh_knn_partial_cols.restype = i32
     L.gh_knn_merged_device.argtypes = [vp]
     L.gh_knn_merged_device.restype = vp
+    L.gh_rows_packed_device.argtypes = [vp]
+    L.gh_rows_packed_device.restype = vp
+    L.gh_step_unpack_rows.argtypes = [vp]
+    L.gh_step_unpack_rows.restype = ctypes.c_int
     L.gh_step_merge.argtypes = [vp, vp, i32]
     L.gh_step_merge.restype = ctypes.c_int
     L.gh_stats_partial_device.argtypes = [vp]
@@ -368,6 +372,13 @@ class Engine:
 
     def step_finish_own(self, stats_all_ptr, world):
         self._chk(self.lib.gh_step_finish_own(self.handle, ctypes.c_void_p(stats_all_ptr), int(world)))
+
+    def rows_packed_device_ptr(self):
+        """(world, chunk, D) float32: the finished blocks without pad columns (0 when D == ld or world == 1)."""
+        return self.lib.gh_rows_packed_device(self.handle)
+
+    def step_unpack_rows(self):
+        self._chk(self.lib.gh_step_unpack_rows(self.handle))
 
     def gather_buffer_device_ptr(self):
         return self.lib.gh_gather_buffer_device(self.handle)

@@ -86,7 +86,7 @@ static void free_all(gh_engine *h) {
     gh_ivf_free(h);
     void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_sel_redo, h->d_tq_count, h->d_tq_base, h->d_tq_touched, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rare, h->d_cd_rows, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_sel_redo, h->d_tq_count, h->d_tq_base, h->d_tq_touched, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rows_packed, h->d_rare, h->d_cd_rows, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -898,8 +898,16 @@ extern "C" gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, in
     }
     if (h->d_gbuf || h->g_world) { h->err = "rank / gather layout already set"; return GH_ERR_INVALID; }
     GH_TRY(dev_alloc(h, &h->d_stats_comb, (size_t)2 * h->LD, true));
+    // fewer components than the row stride (3 of 4, 5..7 of 8, 9..15 of 16): the finished blocks travel unpadded
+    if (h->D < h->LD && world > 1) GH_TRY(dev_alloc(h, &h->d_rows_packed, (size_t)world * chunk * h->D, true));
     h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
     return GH_OK;
+}
+extern "C" float *gh_rows_packed_device(gh_handle h) { return h ? h->d_rows_packed : nullptr; }
+extern "C" gh_status gh_step_unpack_rows(gh_handle h) {
+    GH_TRY(check_handle(h));
+    if (!h->d_stats_comb || h->d_gbuf) { h->err = "gh_rank_layout has not been called"; return GH_ERR_INVALID; }
+    return gh_launch_unpack_rows(h);
 }
 extern "C" gh_status gh_step_finish_own(gh_handle h, const double *stats_all, int32_t world) {
     GH_TRY(check_handle(h));

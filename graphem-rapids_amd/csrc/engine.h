@@ -124,6 +124,8 @@ struct gh_engine {
     int64_t g_slot = 0, g_chunk = 0;  // slot bytes, rows per rank
     int g_world = 0, g_rank = 0;
     double *d_stats_comb = nullptr;   // form C (gh_rank_layout): the ranks' statistics added in rank order, (2, LD)
+    float *d_rows_packed = nullptr;   // form C, D < LD: (world, chunk, D) the finished blocks WITHOUT the pad columns -- what travels
+                                      // (12 instead of 16 bytes per row at 3 components); gh_step_unpack_rows expands it into d_pos
     int32_t *d_qexact = nullptr;  // [0] = count, [1..] = queries outside the f16 range (scanned exactly)
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
     int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line
@@ -247,6 +249,7 @@ gh_status gh_launch_normalise(gh_engine *h, bool with_cleanup, bool presetup = f
                               int32_t *next_ids = nullptr);
 gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode = -1);
 gh_status gh_launch_normalise_own(gh_engine *h, const double *stats_all, int world);   // form C: own rows from every rank's statistics
+gh_status gh_launch_unpack_rows(gh_engine *h);   // form C: the gathered packed blocks of the OTHER ranks -> their rows of d_pos
 struct gh_long_args;
 gh_long_args gh_make_long_args(const gh_engine *h, bool coop_mid = false);   // common.h; coop_mid: fused kernels
 gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0);  // spring forces of the hub rows  // gathered slots of every rank -> all n rows of d_pos

@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
                                                        const int32_t *__restrict__ tcount, int nfix, int g_norm,
                                                        int n_setup, gh_setup_args sa, int32_t *__restrict__ qexact,
                                                        unsigned long long *__restrict__ stamps /* diagnostic, or null */,
-                                                       int stat_world = 1) {
+                                                       int stat_world = 1,
+                                                       float *__restrict__ packed = nullptr /* form C: the same rows without pad columns, (rows, D) */) {
     if (stamps && (blockIdx.x >= GH_STAMP_EXTRA)) stamps = nullptr;
     if (stamps) stamps += (int64_t)blockIdx.x * 8;
 #define GH_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
@@ -426,6 +427,13 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
         o.z = d0 + 2 < D ? (v.z - ms[d0 + 2]) / ms[LD + d0 + 2] : 0.0f;
         o.w = d0 + 3 < D ? (v.w - ms[d0 + 3]) / ms[LD + d0 + 3] : 0.0f;
         dst[t] = o;
+        if (packed) {   // the copy that travels (gh_step_unpack_rows on the receiving ranks)
+            float *pk = packed + (t * 4 / LD) * D + d0;
+            if (d0 + 0 < D) pk[0] = o.x;
+            if (d0 + 1 < D) pk[1] = o.y;
+            if (d0 + 2 < D) pk[2] = o.z;
+            if (d0 + 3 < D) pk[3] = o.w;
+        }
     };
     int64_t t = nb * (int64_t)blockDim.x + threadIdx.x;
     for (; t + 3 * step < total4; t += 4 * step) {
@@ -1028,7 +1036,28 @@ gh_status gh_launch_normalise_own(gh_engine *h, const double *stats_all, int wor
     gh_setup_args sa{};
     normalise_kernel<0><<<dim3(grid), dim3(256), smem, h->stream>>>(
         h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, stats_all, h->d_pos, h->d_acc, h->d_tflag, h->d_touched,
-        h->d_tcount, nfix, (int)grid, 0, sa, h->d_qexact, nullptr, sworld);
+        h->d_tcount, nfix, (int)grid, 0, sa, h->d_qexact, nullptr, sworld,
+        h->d_rows_packed ? h->d_rows_packed + (size_t)h->g_rank * h->g_chunk * h->D : nullptr);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+
+// Form C with fewer components than the row stride: the blocks travel without their pad columns.  After the all-gather of
+// d_rows_packed (world, chunk, D): the other ranks' rows -> d_pos (the own block was written in place by the normalise launch).
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const float *__restrict__ packed, int64_t n, int D, int LD, int64_t own_lo,
+                                                         int64_t own_hi, float *__restrict__ pos) {
+    const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;   // element (row, d) of the padded array
+    if (t >= n * LD) return;
+    const int64_t row = t / LD;
+    const int d = (int)(t % LD);
+    if (row >= own_lo && row < own_hi) return;
+    pos[t] = d < D ? packed[row * D + d] : 0.0f;
+}
+gh_status gh_launch_unpack_rows(gh_engine *h) {
+    if (!h->d_rows_packed) return GH_OK;
+    gh_scope t(h, "unpack_rows");
+    unpack_rows_kernel<<<dim3(grid_for(h->n * h->LD, 256)), dim3(256), 0, h->stream>>>(h->d_rows_packed, h->n, h->D, h->LD, h->part.row_lo,
+                                                                                       h->part.row_hi, h->d_pos);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

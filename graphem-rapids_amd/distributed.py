@@ -18,7 +18,9 @@ most of the edges).  Every rank holds all n positions and the whole edge list.  
     gather  (RCCL)    all-gather of the ranks' column statistics          18*ld*8 B per rank
     part 3  (local)   normalise the OWN rows into their block of the position array; the per-rank sums
                       are added in rank order, so every rank derives the same mean / std
-    gather  (RCCL)    in-place all-gather of the finished position blocks     chunk*ld*4 B per rank
+    gather  (RCCL)    in-place all-gather of the finished position blocks     chunk*D*4 B per rank
+                      (without their pad columns when D < ld -- 12 instead of 16 B per row at D = 3 --, then
+                      expanded into the position array by gh_step_unpack_rows; chunk*ld*4 B when D == ld)
   finish="gathered" (two collectives, every rank normalises all n rows -- 22-51 us per rank at 1 M vertices):
     gather  (RCCL)    in-place all-gather of slots [un-normalised rows | statistics]
     part 3  (local)   normalise ALL n rows from the gathered slots
@@ -130,6 +132,13 @@ class HipShardEngine:
         self.world, self.rank, self.chunk = world, rank, chunk
         self.stats_all = torch.zeros((world, e.stats_rows(), e.ld), dtype=torch.float64, device=self.device)
         self.pos_blocks = self.pos[: world * chunk].view(world, chunk * e.ld)
+        # fewer components than the row stride: the finished blocks travel without their pad columns (12 B per row at D = 3)
+        from .embedder_hip import device_view
+        ptr = e.rows_packed_device_ptr()
+        self.packed_blocks = device_view(ptr, (world, chunk * e.D), torch.float32, self.device, e) if ptr else None
+
+    def step_unpack_rows(self):
+        self.eng.step_unpack_rows()
 
     def step_finish_own(self, stats_all):
         self.eng.step_finish_own(stats_all.data_ptr(), self.world)
@@ -280,6 +289,11 @@ class PartitionedLayout:
         if self.finish == "own":
             dist.all_gather_into_tensor(e.stats_all.view(-1), e.stats.view(-1), group=self.group)   # concatenated form: RCCL and gloo
             e.step_finish_own(e.stats_all)
+            packed = getattr(e, "packed_blocks", None)
+            if packed is not None:   # the blocks without their pad columns, then expanded into the position array
+                dist.all_gather_into_tensor(packed.view(-1), packed[self.rank], group=self.group)
+                e.step_unpack_rows()
+                return
             # in-place all-gather of the finished blocks: rank r's rows are block r of the position array
             dist.all_gather_into_tensor(e.pos_blocks.view(-1), e.pos_blocks[self.rank], group=self.group)
             return

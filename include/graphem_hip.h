@@ -260,9 +260,16 @@ gh_status gh_step_finish_gathered(gh_handle h);
  * block r = rows [r*chunk, (r+1)*chunk), chunk * ld floats (gh_positions_rows_allocated() >= world * chunk).
  *   gh_rank_layout(h, world, rank, chunk)   once after gh_create (instead of gh_gather_layout)
  *   gh_step_finish_own(h, stats_all, world) stats_all: (world, gh_stats_rows, ld) doubles, device
- * The position array is complete again only after the caller's all-gather. */
+ * The position array is complete again only after the caller's all-gather.
+ * With fewer components than the row stride (3 of 4, 5..7 of 8, 9..15 of 16) and world > 1 the blocks can travel WITHOUT
+ * their pad columns (12 instead of 16 bytes per row at 3 components: a quarter off the largest collective of the iteration):
+ * gh_step_finish_own also writes the own block into slot `rank` of gh_rows_packed_device(), a (world, chunk, D) float
+ * array; the caller all-gathers THAT in place instead of the position blocks and calls gh_step_unpack_rows, which expands
+ * the other ranks' blocks into the position array.  gh_rows_packed_device() is NULL when D == ld or world == 1. */
 gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk);
 gh_status gh_step_finish_own(gh_handle h, const double *stats_all, int32_t world);
+float *gh_rows_packed_device(gh_handle h);
+gh_status gh_step_unpack_rows(gh_handle h);
 
 /* ---- the whole partitioned run as ONE call (no host language in the loop) ----------------------
  * After gh_create(partition) + gh_rank_layout(world, rank, chunk) (form C: all-gathers of the keys, of the statistics

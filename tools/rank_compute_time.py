@@ -31,6 +31,8 @@ for world in (1, 2, 4, 8):
                     sh.stats_all[w].copy_(sh.stats)        # stand-in for the all-gather of the statistics
                 sh.stats_all[1:].zero_()                   # (one rank's sums count once: rows of the others are absent anyway)
                 sh.step_finish_own(sh.stats_all)
+                if sh.packed_blocks is not None:           # the receiving side of the unpadded block exchange
+                    sh.step_unpack_rows()
             else:
                 sh.gbuf.copy_(sh.gbuf[rank].expand_as(sh.gbuf).clone())
                 sh.step_finish_gathered()
@@ -43,7 +45,7 @@ for world in (1, 2, 4, 8):
         torch.cuda.synchronize()
         tm = {a: round(1e3 * b[0] / b[1], 2) for a, b in sh.eng.timings().items()}
         rec = {"world": world, "rank": rank, "own_rows": hi - lo, "kernel_us": tm, "kernels_total_us": round(sum(tm.values()), 1),
-               "bytes_sent_rows": (hi - lo) * sh.ld * 4 if world > 1 else 0}
+               "bytes_sent_rows": (hi - lo) * (D if D < sh.ld else sh.ld) * 4 if world > 1 else 0}
         out["rows"].append(rec)
         print(f"world={world} rank {rank}: kernels {rec['kernels_total_us']} us", tm, file=sys.stderr, flush=True)
         sh.eng.close()
