@@ -580,16 +580,17 @@ __global__ __launch_bounds__(256) void intersect_kernel(const float *__restrict_
                                                        const uint64_t *__restrict__ keys, int64_t S, int k,
                                                        float k_inter, double *__restrict__ acc,
                                                        int32_t *__restrict__ tflag, int32_t *__restrict__ touched,
-                                                       int32_t *__restrict__ tcount, float *__restrict__ scratch) {
+                                                       int32_t *__restrict__ tcount, float *__restrict__ scratch, int32_t own_lo,
+                                                       int32_t own_hi) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= S * k) return;
     const int64_t r = t / k;
     // neighbour c of query r is key column c+1: column 0 is dropped blindly (pt.py:421)
     const int32_t i = sampled[r], j = (int32_t)gh_key_id(keys[r * (k + 1) + (t - r * k) + 1]);
     if constexpr (DT >= 2)
-        gh_intersect_pair_t<DT, (DT <= 4 ? 4 : DT <= 8 ? 8 : 16)>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount);
+        gh_intersect_pair_t<DT, (DT <= 4 ? 4 : DT <= 8 ? 8 : 16)>(pos, edges, i, j, k_inter, acc, tflag, touched, tcount, own_lo, own_hi);
     else
-        gh_intersect_pair(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, scratch + t * LD);
+        gh_intersect_pair(pos, D, LD, edges, i, j, k_inter, acc, tflag, touched, tcount, scratch + t * LD, own_lo, own_hi);
 }
 
 // acc (double) -> dense fp32 F for the touched vertices (per-phase entry point).
@@ -920,19 +921,21 @@ gh_status gh_launch_spring_only(gh_engine *h, float *d_F) {
 gh_status gh_launch_intersect(gh_engine *h) {
     const int64_t P = h->S * h->k;
     if (P == 0) return GH_OK;
+    // a row partition accumulates only what lands on its own rows
+    const int32_t own_lo = h->rows != h->n ? (int32_t)h->part.row_lo : 0, own_hi = h->rows != h->n ? (int32_t)h->part.row_hi : 0x7FFFFFFF;
     gh_scope t(h, "intersect");
 #define GH_INTER_ONE(DD, LL)                                                                                       \
     case DD:                                                                                                       \
         intersect_kernel<DD><<<dim3(grid_for(P, 256)), dim3(256), 0, h->stream>>>(                                   \
             h->d_pos, h->D, h->LD, h->d_edges, h->d_sampled_cur, h->d_keys_cur, h->S, h->k, h->prm.k_inter, h->d_acc, \
-            h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch);                                                 \
+            h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch, own_lo, own_hi);                                 \
         break;
     switch (h->D) {
         GH_FOR_EACH_DIM(GH_INTER_ONE)
         default:
             intersect_kernel<0><<<dim3(grid_for(P, 256)), dim3(256), 0, h->stream>>>(
                 h->d_pos, h->D, h->LD, h->d_edges, h->d_sampled_cur, h->d_keys_cur, h->S, h->k, h->prm.k_inter, h->d_acc,
-                h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch);
+                h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch, own_lo, own_hi);
     }
 #undef GH_INTER_ONE
     GH_LAUNCH_CHECK();

@@ -18,7 +18,9 @@ __device__ inline void gh_intersect_pair(const float *__restrict__ pos, int D, i
                                          const int32_t *__restrict__ edges, int32_t i, int32_t j, float k_inter,
                                          double *__restrict__ acc, int32_t *__restrict__ tflag,
                                          int32_t *__restrict__ touched, int32_t *__restrict__ tcount,
-                                         float *__restrict__ diff) {
+                                         float *__restrict__ diff, int32_t own_lo = 0, int32_t own_hi = 0x7FFFFFFF /* a row
+                                         partition accumulates only what lands on its own rows [own_lo, own_hi): nothing else is
+                                         read by its integrate step, and the double-precision atomics are the phase's cost */) {
     if (!(i < j)) return;
     const int32_t v[4] = {edges[2 * (int64_t)i], edges[2 * (int64_t)i + 1], edges[2 * (int64_t)j], edges[2 * (int64_t)j + 1]};
     if (v[0] == v[2] || v[0] == v[3] || v[1] == v[2] || v[1] == v[3]) return;
@@ -29,6 +31,7 @@ __device__ inline void gh_intersect_pair(const float *__restrict__ pos, int D, i
     const float o3 = gh_orient2d(q1, q2, p1), o4 = gh_orient2d(q1, q2, p2);
     if (!(o1 * o2 < 0.0f && o3 * o4 < 0.0f)) return;
     for (int role = 0; role < 4; ++role) {
+        if (v[role] < own_lo || v[role] >= own_hi) continue;
         const float *x = pos + (int64_t)v[role] * LD;
         for (int d = 0; d < D; ++d) {
             const float cen = (((p1[d] + p2[d]) + q1[d]) + q2[d]) / 4.0f;
@@ -47,7 +50,7 @@ template <int D, int LD>
 __device__ __forceinline__ void gh_intersect_pair_t(const float *__restrict__ pos, const int32_t *__restrict__ edges,
                                                     int32_t i, int32_t j, float k_inter, double *__restrict__ acc,
                                                     int32_t *__restrict__ tflag, int32_t *__restrict__ touched,
-                                                    int32_t *__restrict__ tcount) {
+                                                    int32_t *__restrict__ tcount, int32_t own_lo = 0, int32_t own_hi = 0x7FFFFFFF) {
     if (!(i < j)) return;
     const int2 ei = reinterpret_cast<const int2 *>(edges)[i], ej = reinterpret_cast<const int2 *>(edges)[j];
     const int32_t v[4] = {ei.x, ei.y, ej.x, ej.y};
@@ -63,6 +66,7 @@ __device__ __forceinline__ void gh_intersect_pair_t(const float *__restrict__ po
     for (int d = 0; d < D; ++d) cen[d] = (((x[0][d] + x[1][d]) + x[2][d]) + x[3][d]) / 4.0f;
 #pragma unroll
     for (int role = 0; role < 4; ++role) {
+        if (v[role] < own_lo || v[role] >= own_hi) continue;
         float diff[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) diff[d] = x[role][d] - cen[d];
@@ -97,7 +101,8 @@ __device__ __forceinline__ void gh_intersect_query_wide(const float *__restrict_
                                                         int32_t *__restrict__ tcount, gh_pair_list *pl,
                                                         int32_t *__restrict__ own_count = nullptr /* thousands of queries: `touched`
                                                         is this query's OWN run of 4 k slots and its length goes here -- no atomic on
-                                                        the shared counter at all; knn_touched_compact_kernel gathers the runs */) {
+                                                        the shared counter at all; knn_touched_compact_kernel gathers the runs */,
+                                                        int32_t own_lo = 0, int32_t own_hi = 0x7FFFFFFF) {
     if (threadIdx.x == 0) { pl->n = 0; pl->nt = 0; }
     __syncthreads();
     for (int c = threadIdx.x; c < k; c += blockDim.x) {
@@ -136,6 +141,7 @@ __device__ __forceinline__ void gh_intersect_query_wide(const float *__restrict_
 #pragma unroll
         for (int dd = 1; dd < D; ++dd) term = d == dd ? diff[dd] : term;
         const int32_t me = role == 0 ? v[0] : role == 1 ? v[1] : role == 2 ? v[2] : v[3];
+        if (me < own_lo || me >= own_hi) continue;   // (a row partition: another rank's row)
         if (d < D) atomicAdd(&acc[(int64_t)me * LD + d], (double)((k_inter * term) / dsq));
         // first touch of a vertex: listed per query in LDS, ONE reservation in the global list per query below (a returning
         // atomic per vertex on the single counter serialised at ~11 ns each: 16 K queries' 30 K first touches were 320 us of

@@ -21,6 +21,7 @@ struct inter_args {
     float *scratch;
     int32_t *tq_count = nullptr;    // knn_select_wave_kernel: per-query runs of the touched list (S), (S, 4 k)
     int32_t *tq_touched = nullptr;
+    int32_t own_lo = 0, own_hi = 0x7FFFFFFF;   // a row partition accumulates only what lands on its own rows
 };
 
 // Whole workgroup; best[] in LDS, visible to all threads (the callers' extraction ends with a barrier).
@@ -35,10 +36,10 @@ __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi
         if (ia.k <= 127 && blockDim.x % (4 * LL) == 0) {   // lanes = (role, coordinate)
             if (ia.tq_count)
                 gh_intersect_query_wide<DT, LL>(ia.pos, ia.edges, ia.sampled[qi], best, ia.k, ia.k_inter, ia.acc, ia.tflag,
-                                                ia.tq_touched + qi * 4 * ia.k, ia.tcount, pl, ia.tq_count + qi);
+                                                ia.tq_touched + qi * 4 * ia.k, ia.tcount, pl, ia.tq_count + qi, ia.own_lo, ia.own_hi);
             else
                 gh_intersect_query_wide<DT, LL>(ia.pos, ia.edges, ia.sampled[qi], best, ia.k, ia.k_inter, ia.acc, ia.tflag, ia.touched,
-                                                ia.tcount, pl);
+                                                ia.tcount, pl, nullptr, ia.own_lo, ia.own_hi);
             return;
         }
     }
@@ -47,10 +48,10 @@ __device__ __forceinline__ void intersect_query(const inter_args &ia, int64_t qi
         const int32_t j = (int32_t)gh_key_id(best[c + 1]);
         if constexpr (DT >= 2)
             gh_intersect_pair_t<DT, (DT <= 4 ? 4 : DT <= 8 ? 8 : 16)>(ia.pos, ia.edges, ia.sampled[qi], j, ia.k_inter, ia.acc, ia.tflag,
-                                                                     ia.touched, ia.tcount);
+                                                                     ia.touched, ia.tcount, ia.own_lo, ia.own_hi);
         else
             gh_intersect_pair(ia.pos, ia.D, ia.LD, ia.edges, ia.sampled[qi], j, ia.k_inter, ia.acc, ia.tflag, ia.touched, ia.tcount,
-                              ia.scratch + (qi * ia.k + c) * ia.LD);
+                              ia.scratch + (qi * ia.k + c) * ia.LD, ia.own_lo, ia.own_hi);
     }
 }
 // host side: run X<DT> for the engine's dimension (0 past 16)
@@ -254,6 +255,7 @@ inline inter_args make_inter_args(gh_engine *h, bool on) {
     if (on) {
         ia = inter_args{h->d_pos, h->d_edges, h->d_sampled_cur, h->D, h->LD, h->k, h->prm.k_inter,
                         h->d_acc, h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch};
+        if (h->rows != h->n) { ia.own_lo = (int32_t)h->part.row_lo; ia.own_hi = (int32_t)h->part.row_hi; }
     }
     return ia;
 }

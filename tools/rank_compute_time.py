@@ -32,6 +32,12 @@ for world in (1, 2, 4, 8):
                 sh.stats_all[1:].zero_()                   # (one rank's sums count once: rows of the others are absent anyway)
                 sh.step_finish_own(sh.stats_all)
                 if sh.packed_blocks is not None:           # the receiving side of the unpadded block exchange
+                    # (stand-in for the all-gather: the other ranks' blocks = their current rows, so that the layout this
+                    # rank keeps computing on stays a layout; torch copies, not on the engine's timers)
+                    pk = sh.packed_blocks.view(world, chunk, D)
+                    own = pk[rank].clone()
+                    pk.copy_(sh.pos[: world * chunk].view(world, chunk, sh.ld)[:, :, :D])
+                    pk[rank].copy_(own)
                     sh.step_unpack_rows()
             else:
                 sh.gbuf.copy_(sh.gbuf[rank].expand_as(sh.gbuf).clone())
