@@ -17,7 +17,7 @@ GH_OK, GH_ERR_INVALID, GH_ERR_RUNTIME, GH_ERR_K_TOO_LARGE, GH_ERR_HIP, GH_ERR_NO
 SYMBOLS = [
     "gh_create", "gh_destroy", "gh_last_error", "gh_set_positions", "gh_get_positions", "gh_positions_device",
     "gh_row_stride", "gh_step", "gh_run", "gh_sync", "gh_spring_forces", "gh_knn_midpoints",
-    "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_knn_partial_cols", "gh_knn_merged_device", "gh_rows_packed_device", "gh_step_unpack_rows", "gh_step_merge",
+    "gh_intersection_forces", "gh_integrate_normalise", "gh_step_begin", "gh_knn_partial_device", "gh_knn_partial_cols", "gh_knn_merged_device", "gh_rows_packed_device", "gh_step_unpack_rows", "gh_set_packed_rows", "gh_step_merge",
     "gh_stats_partial_device", "gh_step_finish", "gh_timing_enable", "gh_timing_reset", "gh_timing_count",
     "gh_timing_get", "gh_device_count", "gh_version", "gh_knn_last_counts", "gh_set_stream",
     "gh_positions_rows_allocated", "gh_knn_points", "gh_stats_rows", "gh_spmv_symnorm",
@@ -133,6 +133,8 @@ def load():
     L.gh_rows_packed_device.restype = vp
     L.gh_step_unpack_rows.argtypes = [vp]
     L.gh_step_unpack_rows.restype = ctypes.c_int
+    L.gh_set_packed_rows.argtypes = [vp, i32]
+    L.gh_set_packed_rows.restype = ctypes.c_int
     L.gh_step_merge.argtypes = [vp, vp, i32]
     L.gh_step_merge.restype = ctypes.c_int
     L.gh_stats_partial_device.argtypes = [vp]
@@ -379,6 +381,10 @@ class Engine:
 
     def step_unpack_rows(self):
         self._chk(self.lib.gh_step_unpack_rows(self.handle))
+
+    def set_packed_rows(self, on):
+        """Finished blocks travel without pad columns + expansion kernel (default: from 2 M vertices on)."""
+        self._chk(self.lib.gh_set_packed_rows(self.handle, 1 if on else 0))
 
     def gather_buffer_device_ptr(self):
         return self.lib.gh_gather_buffer_device(self.handle)

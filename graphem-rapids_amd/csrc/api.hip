@@ -899,14 +899,24 @@ extern "C" gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, in
     if (h->d_gbuf || h->g_world) { h->err = "rank / gather layout already set"; return GH_ERR_INVALID; }
     GH_TRY(dev_alloc(h, &h->d_stats_comb, (size_t)2 * h->LD, true));
     // fewer components than the row stride (3 of 4, 5..7 of 8, 9..15 of 16): the finished blocks travel unpadded
-    if (h->D < h->LD && world > 1) GH_TRY(dev_alloc(h, &h->d_rows_packed, (size_t)world * chunk * h->D, true));
+    if (h->D < h->LD && world > 1) {
+        GH_TRY(dev_alloc(h, &h->d_rows_packed, (size_t)world * chunk * h->D, true));
+        h->packed_exchange = h->n >= ((int64_t)1 << 21);
+    }
     h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
     return GH_OK;
 }
-extern "C" float *gh_rows_packed_device(gh_handle h) { return h ? h->d_rows_packed : nullptr; }
+extern "C" gh_status gh_set_packed_rows(gh_handle h, int32_t on) {
+    GH_TRY(check_handle(h));
+    if (on && !h->d_rows_packed) { h->err = "no packed block exchange for this engine (needs gh_rank_layout with world > 1 and fewer components than the row stride)"; return GH_ERR_INVALID; }
+    h->packed_exchange = on != 0;
+    return GH_OK;
+}
+extern "C" float *gh_rows_packed_device(gh_handle h) { return h && h->packed_exchange ? h->d_rows_packed : nullptr; }
 extern "C" gh_status gh_step_unpack_rows(gh_handle h) {
     GH_TRY(check_handle(h));
     if (!h->d_stats_comb || h->d_gbuf) { h->err = "gh_rank_layout has not been called"; return GH_ERR_INVALID; }
+    if (!h->packed_exchange) { h->err = "the packed block exchange is not in use (gh_set_packed_rows)"; return GH_ERR_INVALID; }
     return gh_launch_unpack_rows(h);
 }
 extern "C" gh_status gh_step_finish_own(gh_handle h, const double *stats_all, int32_t world) {

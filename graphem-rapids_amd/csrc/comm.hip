@@ -249,7 +249,7 @@ extern "C" gh_status gh_run_partitioned(gh_handle h, int32_t iters, const int32_
             } else {           // form C
                 GH_TRY_ST(comm_all_gather(h, h->d_stats, c->d_stats_all, stats_bytes, "allgather_stats"));
                 GH_TRY_ST(gh_step_finish_own(h, c->d_stats_all, c->world));
-                if (h->d_rows_packed) {   // the blocks travel without their pad columns (12 instead of 16 bytes per row at D = 3)
+                if (h->packed_exchange) {   // the blocks travel without their pad columns (12 instead of 16 bytes per row at D = 3)
                     const size_t block = sizeof(float) * (size_t)h->g_chunk * h->D;
                     GH_TRY_ST(comm_all_gather(h, reinterpret_cast<unsigned char *>(h->d_rows_packed) + (size_t)c->rank * block, h->d_rows_packed, block, "allgather_rows"));
                     GH_TRY_ST(gh_launch_unpack_rows(h));

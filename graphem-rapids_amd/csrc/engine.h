@@ -126,6 +126,8 @@ struct gh_engine {
     double *d_stats_comb = nullptr;   // form C (gh_rank_layout): the ranks' statistics added in rank order, (2, LD)
     float *d_rows_packed = nullptr;   // form C, D < LD: (world, chunk, D) the finished blocks WITHOUT the pad columns -- what travels
                                       // (12 instead of 16 bytes per row at 3 components); gh_step_unpack_rows expands it into d_pos
+    bool packed_exchange = false;     // ... in use (gh_set_packed_rows; default: from 2 M vertices on, where the saved quarter of
+                                      // the all-gather outweighs the expansion kernel -- 30 us at 4 M vertices, 14 at 1 M)
     int32_t *d_qexact = nullptr;  // [0] = count, [1..] = queries outside the f16 range (scanned exactly)
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
     int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line

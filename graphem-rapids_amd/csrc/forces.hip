@@ -1040,7 +1040,7 @@ gh_status gh_launch_normalise_own(gh_engine *h, const double *stats_all, int wor
     normalise_kernel<0><<<dim3(grid), dim3(256), smem, h->stream>>>(
         h->d_new, h->rows, h->part.row_lo, h->D, h->LD, h->n, stats_all, h->d_pos, h->d_acc, h->d_tflag, h->d_touched,
         h->d_tcount, nfix, (int)grid, 0, sa, h->d_qexact, nullptr, sworld,
-        h->d_rows_packed ? h->d_rows_packed + (size_t)h->g_rank * h->g_chunk * h->D : nullptr);
+        h->packed_exchange ? h->d_rows_packed + (size_t)h->g_rank * h->g_chunk * h->D : nullptr);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
@@ -1057,7 +1057,7 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const float *__restric
     pos[t] = d < D ? packed[row * D + d] : 0.0f;
 }
 gh_status gh_launch_unpack_rows(gh_engine *h) {
-    if (!h->d_rows_packed) return GH_OK;
+    if (!h->packed_exchange) return GH_OK;
     gh_scope t(h, "unpack_rows");
     unpack_rows_kernel<<<dim3(grid_for(h->n * h->LD, 256)), dim3(256), 0, h->stream>>>(h->d_rows_packed, h->n, h->D, h->LD, h->part.row_lo,
                                                                                        h->part.row_hi, h->d_pos);

@@ -125,10 +125,13 @@ class HipShardEngine:
         self.gbuf = device_view(e.gather_buffer_device_ptr(), (world, e.gather_slot_bytes()), torch.uint8, self.device, e)
         self.stats = device_view(e.stats_partial_device_ptr(), (e.stats_rows(), e.ld), torch.float64, self.device, e)
 
-    def rank_layout(self, world, rank, chunk):
-        """finish="own": per-rank statistics gathered into stats_all, position blocks gathered in place in pos."""
+    def rank_layout(self, world, rank, chunk, packed=None):
+        """finish="own": per-rank statistics gathered into stats_all, position blocks gathered in place in pos.
+        packed: force the unpadded block exchange on / off (None: the library's default, on from 2 M vertices)."""
         e = self.eng
         e.rank_layout(world, rank, chunk)
+        if packed is not None and ((world > 1 and e.D < e.ld) or not packed):
+            e.set_packed_rows(packed)
         self.world, self.rank, self.chunk = world, rank, chunk
         self.stats_all = torch.zeros((world, e.stats_rows(), e.ld), dtype=torch.float64, device=self.device)
         self.pos_blocks = self.pos[: world * chunk].view(world, chunk * e.ld)

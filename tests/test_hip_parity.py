@@ -304,7 +304,7 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D, finish):
         parts.append((lo, hi))
         shards.append(HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, part, 0))
         if finish == "own":
-            shards[-1].rank_layout(world, r, chunk)
+            shards[-1].rank_layout(world, r, chunk, packed=True)   # (the unpadded block exchange, on by default from 2 M vertices)
         else:
             shards[-1].gather_layout(world, r, chunk)
         shards[-1].set_positions(pos)
@@ -434,6 +434,8 @@ def test_native_partitioned_loop_on_the_loopback_backend(world, n, D, finish):
         e = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=4, partition=(lo, hi, 0, 0, _native.EDGES_HASHED))
         if finish == "own":
             e.rank_layout(world, r, chunk)
+            if D < e.ld:   # the unpadded block exchange (default from 2 M vertices on): forced on for the even world sizes
+                e.set_packed_rows(world % 2 == 0)
         else:
             e.gather_layout(world, r, chunk)
         e.comm_init_loopback(group, r)

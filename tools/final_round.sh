@@ -7,13 +7,15 @@ python bench.py --steps 50 --warmup 5 > $out/bench_default_rr1m.json 2> $out/ben
 for wl in rr100k er1m rr4m rr16m snap16 rr1m_d6 rr1m_d12 pp1m; do
   python bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_$wl.json 2>/dev/null || echo "$wl failed"
 done
-python bench.py --knn-distance cdist --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_cdist_rr1m.json 2>/dev/null || echo "cdist failed"
-python bench.py --knn-distance cdist --workload rr100k --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_cdist_rr100k.json 2>/dev/null || echo "cdist 100k failed"
+python bench.py --knn-distance cdist --sampler host --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_cdist_rr1m.json 2>/dev/null || echo "cdist failed"
+python bench.py --knn-distance cdist --sampler host --workload rr100k --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_cdist_rr100k.json 2>/dev/null || echo "cdist 100k failed"
 python bench.py --dist --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_dist_world1_python_rr1m.json 2>/dev/null || echo "dist python failed"
 python bench.py --dist --loop native --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_dist_world1_native_rr1m.json 2>/dev/null || echo "dist native failed"
 python bench.py --dist --loop native --workload rr4m --steps 50 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_dist_world1_native_rr4m.json 2>/dev/null || echo "dist native rr4m failed"
 (python tools/bench_init.py 100000; python tools/bench_init.py 1000000) > $out/bench_init.log 2>&1
 python tools/cdist_probe.py rr1m 30 > $out/cdist_probe_rr1m.log 2>&1
+python tools/bench_f64.py rr100k rr1m > $out/bench_f64.log 2>&1
+python bench.py --dist --loop native --knn-distance cdist --steps 30 --warmup 5 --no-cpu-baseline --no-parity-mode > $out/bench_dist_world1_native_cdist_rr1m.json 2>/dev/null || echo "dist native cdist failed"
 python -m pytest tests/test_hip_reference_fullsize.py tests/test_hip_f64.py tests/test_spectral_init.py -q -m gpu -s > $out/gpu_tests_fullsize_f64_spectral.log 2>&1
 python - <<PY
 import json, glob
