@@ -49,6 +49,7 @@
 #include "engine.h"
 #include "scan_core.h"
 #include "select_core.h"
+#include "cdist_heap_asm.h"
 
 #include <algorithm>
 #include <math.h>
@@ -537,55 +538,32 @@ struct cdist_heap_par {
 };
 
 #define GH_CD_KS 16
-// (value and id apart, 32 bits each: a comparison of the high halves of two packed 64-bit keys is widened by the compiler to
-// a 64-bit comparison, which the scalar unit does not have)
+// (cdist_heap_asm.h, generated by tools/gen_heap_asm.py: element i pinned to the scalar register pair s[40 + 2 i : 41 + 2 i],
+// id in the low half and value key in the high one, so that a move is one s_mov_b64 and a comparison one s_cmp_lt_u32 of
+// the high halves.  The same tree written as C++ templates over two 16-element arrays compiled to a block that copied the
+// heap between register sets at every merge: 526 cycles per entering element against ~25 instructions of real work.)
 struct cdist_heap_scalar {
-    uint32_t v[GH_CD_KS], id[GH_CD_KS];
-    // __push_heap: the hole at J climbs while it is below `top` in the tree and its parent is smaller than the new element
-    template <int J>
-    __device__ __forceinline__ void climb(int top, uint32_t xv, uint32_t xid) {
-        if constexpr (J == 0) {
-            v[0] = xv; id[0] = xid;
-        } else {
-            constexpr int PJ = (J - 1) / 2;
-            if (J > top && v[PJ] < xv) { v[J] = v[PJ]; id[J] = id[PJ]; climb<PJ>(top, xv, xid); }
-            else { v[J] = xv; id[J] = xid; }
-        }
-    }
-    // __adjust_heap with the hole at I (a compile-time index), heap length len <= GH_CD_KS
-    template <int I>
-    __device__ __forceinline__ void sink(int top, int len, uint32_t xv, uint32_t xid) {
-        if constexpr (2 * I + 2 < GH_CD_KS) {
-            if (2 * I + 2 < len) {   // two children: the right one unless it is smaller than the left
-                if (v[2 * I + 2] < v[2 * I + 1]) { v[I] = v[2 * I + 1]; id[I] = id[2 * I + 1]; sink<2 * I + 1>(top, len, xv, xid); }
-                else { v[I] = v[2 * I + 2]; id[I] = id[2 * I + 2]; sink<2 * I + 2>(top, len, xv, xid); }
-                return;
-            }
-        }
-        if constexpr (2 * I + 1 < GH_CD_KS) {
-            if (2 * I + 1 < len) {   // a single child (len even): it moves up, the hole ends there
-                v[I] = v[2 * I + 1]; id[I] = id[2 * I + 1];
-                climb<2 * I + 1>(top, xv, xid);
-                return;
-            }
-        }
-        climb<I>(top, xv, xid);
-    }
+    uint64_t h[GH_CD_KS];
     __device__ __forceinline__ void load(const cdist_heap_par &hp) {
 #pragma unroll
-        for (int i = 0; i < GH_CD_KS; ++i) {
-            v[i] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(hp.key >> 32), i);
-            id[i] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)hp.key, i);
-        }
+        for (int i = 0; i < GH_CD_KS; ++i) h[i] = readlane_u64(hp.key, i);
     }
-    __device__ __forceinline__ void store(cdist_heap_par &hp) const {
-        uint32_t hv = v[0], hi = id[0];
+    // (through LDS: a chain of selects on the lane id is turned into an indexed read of h[], which would put the heap in
+    // scratch memory)
+    __device__ __forceinline__ void store(cdist_heap_par &hp, uint64_t *lds /* GH_CD_KS */) const {
+        if (hp.lane == 0) {
 #pragma unroll
-        for (int i = 1; i < GH_CD_KS; ++i) { hv = hp.lane == i ? v[i] : hv; hi = hp.lane == i ? id[i] : hi; }
-        hp.key = ((uint64_t)hv << 32) | hi;
+            for (int i = 0; i < GH_CD_KS; ++i) lds[i] = h[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its LDS operations complete in order)
+        hp.key = lds[hp.lane & (GH_CD_KS - 1)];
     }
-    __device__ __forceinline__ void replace_max(int K, uint32_t xv, uint32_t xid) { sink<0>(0, K, xv, xid); }
-    __device__ __forceinline__ uint32_t top() const { return v[0]; }
+    // std::__pop_heap's __adjust_heap(first, 0, K, x): the maximum leaves, x = (xv << 32 | id) sinks in from the root
+    __device__ __forceinline__ void replace_max(int K, uint32_t xv, uint32_t xid) {
+        const uint64_t x = ((uint64_t)xv << 32) | xid;
+        asm(GH_CD_HEAP_REPLACE_ASM : GH_CD_HEAP_OPERANDS(h) : [x] "s"(x), [xv] "s"(xv), [len] "s"(K) : "scc");
+    }
+    __device__ __forceinline__ uint32_t top() const { return (uint32_t)(h[0] >> 32); }
 };
 struct cdist_heap_lds {
     uint64_t *hk;
@@ -810,8 +788,9 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
     }
     GH_CD_STAMP(3);
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
+    static_assert(GH_EXTRACT_MAX_K >= GH_CD_KS, "best[] carries the scalar heap back to the lanes");
     if (wave0) {
-        if constexpr (HEAP == 0) hs.store(hw);
+        if constexpr (HEAP == 0) hs.store(hw, best);
         hw.sort_heap(K);   // std::sort_heap: ascending
         if (nth_form) {
             bool tie = eq_out == hw.val(K - 1);
