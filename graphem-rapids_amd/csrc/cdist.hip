@@ -478,6 +478,8 @@ __global__ __launch_bounds__(256) void cdist_prefix_kernel(cdist_args a, cdist_r
 // order like the numbers; NaN gets one pattern above +inf.  That is exactly the comparator of ATen's topk on values ("x before
 // y" iff x < y or only y is NaN) at one instruction per comparison, and it makes a heap element one 64-bit key
 // (value bits << 32 | id) -- the layout of gh_key.
+// (the predicate straight into a lane mask: HIP's __ballot goes through an integer compare of the widened predicate)
+__device__ __forceinline__ unsigned long long gh_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t cdist_vkey(float v) { return v != v ? 0x7FC00000u : __float_as_uint(v); }
 __device__ __forceinline__ uint32_t cdist_kv(uint64_t key) { return (uint32_t)(key >> 32); }
 
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
                                                           const float *__restrict__ vbuf, int64_t vstride,
                                                           const float *__restrict__ cmin, int nchunks,
                                                           const uint64_t *__restrict__ cand, uint64_t *__restrict__ out_keys,
-                                                          int nth_form, inter_args ia,
+                                                          int nth_arg, inter_args ia,
                                                           unsigned long long *__restrict__ stamps /* diagnostic (GRAPHEM_HIP_STAMPS), or null */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];   // the LDS heap (HEAP == 2)
     __shared__ float cml[GH_CD_TILE];
@@ -629,6 +631,9 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
     __shared__ int live_ids[GH_CD_BATCH];
     __shared__ int s_nlive;
     __shared__ uint64_t tail_lds[GH_CD_TAIL_LDS];
+    // (the tiny-graph bookkeeping stays out of the scalar-register form, whose loop is counted in instructions: the host
+    // sends such rows to the lane form)
+    const bool nth_form = HEAP != 0 && nth_arg != 0;
     const int t = r0 + (int)blockIdx.x;
     // (slot records are read before the count is known: they exist for every t < S)
     const int nrare = all_rows ? all_rows : rr.hdr[0];
@@ -674,8 +679,8 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
     auto live = [&](float mv) { const uint32_t mk = cdist_vkey(mv); return nth_form ? !(hmax < mk) : mk < hmax; };
     // 64 pairs (lane l: value key x, id xid, `in` = to be considered): in lane (= index) order, whatever still beats the maximum enters
     auto process = [&](uint32_t x, int32_t xid, bool in) __attribute__((always_inline)) {
-        if (nth_form && __ballot(in && x == hmax)) eq_out = hmax;
-        unsigned long long mask = __ballot(in && x < hmax);
+        if (nth_form && gh_ballot(in && x == hmax)) eq_out = hmax;
+        unsigned long long mask = gh_ballot(in && x < hmax);
         while (mask) {   // every lane of the mask holds a value below the maximum of this moment
             const int l = __builtin_ctzll(mask);
             const uint32_t ev = (uint32_t)__builtin_amdgcn_readlane((int)x, l), eid = (uint32_t)__builtin_amdgcn_readlane(xid, l);
@@ -686,8 +691,8 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
             ++n_entered;
             if (nth_form && old == hmax) eq_out = hmax;   // one of several equal maxima was popped: it now waits outside
             const unsigned long long later = l == 63 ? 0ull : ~((2ull << l) - 1ull);
-            mask = __ballot(in && x < hmax) & later;
-            if (nth_form && (__ballot(in && x == hmax) & later)) eq_out = hmax;
+            mask = gh_ballot(in && x < hmax) & later;
+            if (nth_form && (gh_ballot(in && x == hmax) & later)) eq_out = hmax;
         }
     };
     // ---- the valued prefix: chunk minima through LDS, GH_CD_TILE at a time; the chunks that are live under the maximum of the
@@ -712,14 +717,14 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
                 int nl = 0;
                 while (p < nt && nl < GH_CD_BATCH) {
                     const int b = p & ~63;
-                    const unsigned long long m = __ballot(b + lane < nt && live(cml[b + lane])) & (~0ull << (p - b));
+                    const unsigned long long m = gh_ballot(b + lane < nt && live(cml[b + lane])) & (~0ull << (p - b));
                     const int room = GH_CD_BATCH - nl;
                     const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
                     const bool take = ((m >> lane) & 1ull) && rank < room;
                     if (take) live_ids[nl + rank] = b + lane;
                     const int have = __builtin_popcountll(m);
                     if (have > room) {   // the batch is full: go on behind the last chunk taken
-                        const unsigned long long tk = __ballot(take);
+                        const unsigned long long tk = gh_ballot(take);
                         p = b + 64 - __builtin_clzll(tk);
                         nl = GH_CD_BATCH;
                     } else {
@@ -753,7 +758,7 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
                 for (int rb = 0; rb < nl; rb += 64) {
                     const int my_c = rb + lane < nl ? live_ids[rb + lane] : 0;
                     const float mv = rb + lane < nl ? cml[my_c] : INFINITY;
-                    unsigned long long m = __ballot(rb + lane < nl && live(mv));
+                    unsigned long long m = gh_ballot(rb + lane < nl && live(mv));
                     int r = m ? __builtin_ctzll(m) : 0;
                     float xn = stage[(rb + r) * 64 + lane];
                     while (m) {
@@ -764,7 +769,7 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
                         const int r2 = (m & later) ? __builtin_ctzll(m & later) : r;   // the next one as things stand
                         xn = stage[(rb + r2) * 64 + lane];
                         process(cdist_vkey(x), (int32_t)(base + lane), base + lane >= K && base + lane < P);
-                        m = __ballot(rb + lane < nl && live(mv)) & later;
+                        m = gh_ballot(rb + lane < nl && live(mv)) & later;
                         if (!m) break;
                         r = __builtin_ctzll(m);
                         if (r != r2) xn = stage[(rb + r) * 64 + lane];   // the maximum fell below that chunk's minimum meanwhile
@@ -1036,16 +1041,17 @@ static gh_status cdist_replay_rounds(gh_engine *h, const cdist_args &a, const cd
         gh_scope t(h, fuse ? "cdist_replay_intersect" : "cdist_replay");
         const size_t smem = h->K <= 64 ? 0 : sizeof(uint64_t) * (size_t)h->K;
         const inter_args ia = make_inter_args(h, fuse);
+        const bool scalar_heap = h->K <= GH_CD_KS && !nth_form;
 #define GH_CREP(DD, HEAPv, INTv) cdist_replay_kernel<DD, HEAPv, INTv><<<dim3((unsigned)h->cd_R), dim3(256), smem, h->stream>>>( \
         rr, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride, h->d_cd_cmin, h->cd_nchunks, h->d_cand, out_keys, nth_form, ia, h->d_stamps)
-#define GH_CREP_D(DD) case DD: if (h->K <= GH_CD_KS) GH_CREP(DD, 0, true); else GH_CREP(DD, 1, true); break;
+#define GH_CREP_D(DD) case DD: if (scalar_heap) GH_CREP(DD, 0, true); else GH_CREP(DD, 1, true); break;
         if (fuse) {
             switch (h->D) {
                 GH_CREP_D(2) GH_CREP_D(3) GH_CREP_D(4) GH_CREP_D(5) GH_CREP_D(6) GH_CREP_D(7) GH_CREP_D(8) GH_CREP_D(9)
                 GH_CREP_D(10) GH_CREP_D(11) GH_CREP_D(12) GH_CREP_D(13) GH_CREP_D(14) GH_CREP_D(15)
-                default: if (h->K <= GH_CD_KS) GH_CREP(16, 0, true); else GH_CREP(16, 1, true); break;
+                default: if (scalar_heap) GH_CREP(16, 0, true); else GH_CREP(16, 1, true); break;
             }
-        } else if (h->K <= GH_CD_KS) {
+        } else if (scalar_heap) {
             GH_CREP(0, 0, false);
         } else if (h->K <= 64) {
             GH_CREP(0, 1, false);

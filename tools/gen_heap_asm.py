@@ -3,8 +3,8 @@
 replay (csrc/cdist.hip, cdist_heap_scalar) as ONE block of gfx950 scalar instructions over 16 pinned SGPR pairs.
 
 libstdc++'s __adjust_heap(first, 0, len, x) + __push_heap, written as a decision tree: every heap index is a register
-name, so an element that enters costs 3 instructions per level on the way down (compare the children's values, branch,
-s_mov_b64 of value and id together), 3 per level on the way up and one to place it -- the compiler's rendering of the same
+name, so an element that enters costs 5 instructions per level on the way down (is there a child, compare the children's
+values, s_mov_b64 of value and id together), 3 per level on the way up and one to place it -- the compiler's rendering of the same
 tree copies the whole heap between register sets at every merge (profiles/r04/cdist: 526 cycles per element).
 
 usage: python tools/gen_heap_asm.py        (rewrites the header in place; the header is committed)
@@ -38,10 +38,31 @@ def emit(s):
     out.append(s)
 
 
-for i in range(KMAX):
-    if not internal(i):
-        continue
+# Layout: a taken branch costs an instruction-buffer refill (tens of cycles; an instruction ~4), so the tree is laid out
+# depth first -- the right child's block follows its parent's move directly, the left one follows the landing pad of the
+# one conditional branch -- and every climb is a straight line from its starting index to the root, left by one branch.
+emitted = set()
+
+
+def climb(j):   # the hole at j moves up while its parent's value is below the new one (top = 0)
+    emitted.add(j)
+    emit(".Lgh_c%d_%%=:" % j)
+    q = j
+    while q > 0:
+        p = (q - 1) // 2
+        emit("s_cmp_lt_u32 %s, %%[xv]" % hi(p))
+        emit("s_cbranch_scc0 .Lgh_p%d_%%=" % q)
+        emit("s_mov_b64 %s, %s" % (reg(q), reg(p)))
+        q = p
+    emit("s_mov_b64 %s, %%[x]" % reg(0))
+    emit("s_branch .Lgh_done_%=")
+
+
+def node(i):
     l, r = 2 * i + 1, 2 * i + 2
+    if not internal(i):
+        climb(i)
+        return
     emit(".Lgh_n%d_%%=:" % i)
     if r <= KMAX - 1:
         emit("s_cmp_gt_u32 %%[len], %d" % r)              # two children?
@@ -49,29 +70,114 @@ for i in range(KMAX):
         emit("s_cmp_lt_u32 %s, %s" % (hi(r), hi(l)))      # the right one unless it is smaller than the left
         emit("s_cbranch_scc1 .Lgh_l%d_%%=" % i)
         emit("s_mov_b64 %s, %s" % (reg(i), reg(r)))
-        emit("s_branch %s" % after_move(r))
+        node(r)
         emit(".Lgh_l%d_%%=:" % i)
         emit("s_mov_b64 %s, %s" % (reg(i), reg(l)))
-        emit("s_branch %s" % after_move(l))
+        node(l)
         emit(".Lgh_s%d_%%=:" % i)
     emit("s_cmp_gt_u32 %%[len], %d" % l)                  # a single child (len even): it moves up, the hole ends there
     emit("s_cbranch_scc0 .Lgh_c%d_%%=" % i)
     emit("s_mov_b64 %s, %s" % (reg(i), reg(l)))
     emit("s_branch .Lgh_c%d_%%=" % l)
-# the climb: the hole at j moves up while its parent's value is below the new one (top = 0)
+
+
+node(0)
 for j in range(KMAX - 1, 0, -1):
-    p = (j - 1) // 2
-    emit(".Lgh_c%d_%%=:" % j)
-    emit("s_cmp_lt_u32 %s, %%[xv]" % hi(p))
-    emit("s_cbranch_scc0 .Lgh_p%d_%%=" % j)
-    emit("s_mov_b64 %s, %s" % (reg(j), reg(p)))
-    emit("s_branch .Lgh_c%d_%%=" % p)
+    if j not in emitted:
+        climb(j)
+for j in range(KMAX - 1, 0, -1):
     emit(".Lgh_p%d_%%=:" % j)
     emit("s_mov_b64 %s, %%[x]" % reg(j))
     emit("s_branch .Lgh_done_%=")
 emit(".Lgh_c0_%=:")
 emit("s_mov_b64 %s, %%[x]" % reg(0))
 emit(".Lgh_done_%=:")
+
+
+def run_block(h, length, x):
+    """Interprets the generated block (the five instructions it uses) on heap h (list of (value, id)); -> taken branches."""
+    labels = {s[:-1]: k for k, s in enumerate(out) if s.endswith(":")}
+    regs = {reg(i): h[i] for i in range(KMAX)}
+    his = {hi(i): i for i in range(KMAX)}
+
+    def val(tok):
+        if tok == "%[xv]":
+            return x[0]
+        if tok == "%[len]":
+            return length
+        if tok in his:
+            return regs[reg(his[tok])][0]
+        return int(tok)
+    pc, scc, taken, steps = 0, 0, 0, 0
+    while pc < len(out):
+        ins = out[pc]
+        pc += 1
+        if ins.endswith(":"):
+            continue
+        steps += 1
+        op, rest = ins.split(" ", 1)
+        a = [t.strip() for t in rest.split(", ")]
+        if op == "s_cmp_gt_u32":
+            scc = int(val(a[0]) > val(a[1]))
+        elif op == "s_cmp_lt_u32":
+            scc = int(val(a[0]) < val(a[1]))
+        elif op == "s_mov_b64":
+            regs[a[0]] = x if a[1] == "%[x]" else regs[a[1]]
+        elif op in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1"):
+            if op == "s_branch" or (op == "s_cbranch_scc0") == (scc == 0):
+                pc = labels[a[0]]
+                taken += 1
+        else:
+            raise ValueError(ins)
+    for i in range(KMAX):
+        h[i] = regs[reg(i)]
+    return taken, steps
+
+
+def adjust_heap(first, length, x):
+    """libstdc++ bits/stl_heap.h __adjust_heap(first, 0, length, x, less-on-values) followed by __push_heap."""
+    hole = child = 0
+    while child < (length - 1) // 2:
+        child = 2 * (child + 1)
+        if first[child][0] < first[child - 1][0]:
+            child -= 1
+        first[hole] = first[child]
+        hole = child
+    if length % 2 == 0 and child == (length - 2) // 2:
+        child = 2 * (child + 1)
+        first[hole] = first[child - 1]
+        hole = child - 1
+    parent = (hole - 1) // 2
+    while hole > 0 and first[parent][0] < x[0]:
+        first[hole] = first[parent]
+        hole = parent
+        parent = (hole - 1) // 2
+    first[hole] = x
+
+
+def self_check():
+    import random
+    rng = random.Random(7)
+    tk = st = n = 0
+    for length in range(1, KMAX + 1):
+        for trial in range(400):
+            span = rng.choice([2, 3, 5, 1000])   # few distinct values: ties everywhere
+            vals = sorted((rng.randrange(span) for _ in range(length)), reverse=True)
+            h = [(v, 100 + k) for k, v in enumerate(vals)]   # a sorted array is a heap; then churn it
+            h += [(0xFFFFFFFF, 0)] * (KMAX - length)
+            g = list(h)
+            for step in range(12):
+                x = (rng.randrange(span + 1), 1000 + step)
+                a, b = run_block(h, length, x)
+                adjust_heap(g, length, x)
+                assert h == g, (length, trial, step)
+                tk += a
+                st += b
+                n += 1
+    print("self-check: %d replacements identical to __adjust_heap; %.1f instructions, %.1f taken branches each" % (n, st / n, tk / n))
+
+
+self_check()
 
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "graphem-rapids_amd", "csrc", "cdist_heap_asm.h")
 with open(path, "w") as f:
