@@ -627,9 +627,10 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
                                                           unsigned long long *__restrict__ stamps /* diagnostic (GRAPHEM_HIP_STAMPS), or null */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];   // the LDS heap (HEAP == 2)
     __shared__ float cml[GH_CD_TILE];
-    __shared__ float stage[GH_CD_BATCH * 64];
+    __shared__ uint32_t stage[GH_CD_BATCH * 64];   // value KEYS of the fetched chunks; 0xFFFFFFFF where the id is out of [K, P)
     __shared__ int live_ids[GH_CD_BATCH];
-    __shared__ int s_nlive;
+    __shared__ int s_nlive, s_pnext, s_cnt[4];
+    __shared__ uint32_t s_hmax;
     __shared__ uint64_t tail_lds[GH_CD_TAIL_LDS];
     // (the tiny-graph bookkeeping stays out of the scalar-register form, whose loop is counted in instructions: the host
     // sends such rows to the lane form)
@@ -653,57 +654,94 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
     int n_batches = 0, n_entered = 0, n_chunks = 0;
 #define GH_CD_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
     GH_CD_STAMP(0);
-    if (!wave0)   // the tail comes in while wave 0 builds the heap (read behind the barriers of the prefix loop)
-        for (int i = (int)threadIdx.x - 64; i < min(ct, GH_CD_TAIL_LDS); i += 192) tail_lds[i] = tl[i];
-    // the heap: built in the lane form (or in LDS); the scalar form takes it over for the replay
+    // ---- everything the first stretch needs is requested at once, ahead of the heap build: the K values of the heap, the
+    // chunk minima of the first tile, the tail of the candidate list, and the FIRST BATCH of the valued prefix -- the chunks
+    // right behind the heap's own values, which are live under the first maximum whatever it is, so they are fetched
+    // without being listed (listing + fetching them behind the heap build was 3.5 us of every row)
+    const int nch = (int)((P + 63) >> 6);
+    const int P32 = (int)P;
+    const int c_first = K >> 6;
+    const int tile_first = c_first / GH_CD_TILE * GH_CD_TILE;
+    int pre = max(0, min(min(nch, tile_first + GH_CD_TILE) - c_first, GH_CD_BATCH));
+    constexpr int PT = GH_CD_BATCH * 64 / 256;   // values per thread of a full batch
     using wide_t = typename std::conditional<HEAP == 2, cdist_heap_lds, cdist_heap_par>::type;
     wide_t hw;
     cdist_heap_scalar hs;
     hw.lane = lane;
     uint32_t hmax = 0xFFFFFFFFu;
     uint32_t eq_out = 0xFFFFFFFFu;   // nth_form: a value left outside the heap while equal to its maximum (boundary tie if it stays so)
-    if (wave0) {
-        if constexpr (HEAP == 2) {
-            hw.hk = reinterpret_cast<uint64_t *>(smem_raw);
-            for (int i = lane; i < K; i += 64) hw.hk[i] = ((uint64_t)cdist_vkey(v[i]) << 32) | (uint32_t)i;
-            hw.sync();
-        } else {
-            hw.key = ((uint64_t)(lane < K ? cdist_vkey(v[lane]) : 0xFFFFFFFFu) << 32) | (uint32_t)lane;
+    {
+        float h0 = 0.0f;
+        if constexpr (HEAP != 2) h0 = wave0 && lane < K ? v[lane] : 0.0f;
+        float tmc[GH_CD_TILE / 256], tps[PT];
+        const int nt0 = min(GH_CD_TILE, nch - tile_first);
+#pragma unroll
+        for (int u = 0; u < GH_CD_TILE / 256; ++u) tmc[u] = u * 256 + (int)threadIdx.x < nt0 ? cm[tile_first + u * 256 + threadIdx.x] : INFINITY;
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int i = u * 256 + (int)threadIdx.x;
+            tps[u] = i < pre * 64 ? v[((int64_t)(c_first + (i >> 6)) << 6) + (i & 63)] : 0.0f;
         }
-        if (K >= 2) hw.make_heap(K);
-        if constexpr (HEAP == 0) hs.load(hw);
-        hmax = hw.val(0);
+        if (!wave0)
+            for (int i = (int)threadIdx.x - 64; i < min(ct, GH_CD_TAIL_LDS); i += 192) tail_lds[i] = tl[i];
+        // the heap: built in the lane form (or in LDS); the scalar form takes it over for the replay
+        if (wave0) {
+            if constexpr (HEAP == 2) {
+                hw.hk = reinterpret_cast<uint64_t *>(smem_raw);
+                for (int i = lane; i < K; i += 64) hw.hk[i] = ((uint64_t)cdist_vkey(v[i]) << 32) | (uint32_t)i;
+                hw.sync();
+            } else {
+                hw.key = ((uint64_t)(lane < K ? cdist_vkey(h0) : 0xFFFFFFFFu) << 32) | (uint32_t)lane;
+            }
+            if (K >= 2) hw.make_heap(K);
+            if constexpr (HEAP == 0) hs.load(hw);
+            hmax = hw.val(0);
+            if (lane == 0) s_hmax = hmax;
+        }
+#pragma unroll
+        for (int u = 0; u < GH_CD_TILE / 256; ++u) cml[u * 256 + threadIdx.x] = tmc[u];
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int id = ((c_first + u * 4 + (int)(threadIdx.x >> 6)) << 6) + lane;   // (i >> 6 = u * 4 + wave, i & 63 = lane)
+            stage[u * 256 + threadIdx.x] = id >= K && id < P32 ? cdist_vkey(tps[u]) : 0xFFFFFFFFu;
+        }
+        if ((int)threadIdx.x < pre) live_ids[threadIdx.x] = c_first - tile_first + (int)threadIdx.x;
     }
     GH_CD_STAMP(1);
     // "may hold an element that enters": minimum below the maximum (nth_form: or equal to it, for the boundary-tie count)
-    auto live = [&](float mv) { const uint32_t mk = cdist_vkey(mv); return nth_form ? !(hmax < mk) : mk < hmax; };
-    // 64 pairs (lane l: value key x, id xid, `in` = to be considered): in lane (= index) order, whatever still beats the maximum enters
+    auto live_key = [&](uint32_t mk) { return nth_form ? !(hmax < mk) : mk < hmax; };
+    // 64 pairs (lane l: value key x, id xid, `in` = to be considered): in lane (= index) order, whatever still beats the maximum
+    // enters.  The loop is counted in instructions (one wave issues one every ~4 cycles, a taken branch costs ~28): lanes
+    // out of consideration get the key 0xFFFFFFFF, above every value's, so that the lanes still in the running are ONE
+    // v_cmp against the maximum and one s_and with the lanes not yet through (the maximum only falls: a lane that failed
+    // once fails for good, so only the lanes that entered have to be struck out).
     auto process = [&](uint32_t x, int32_t xid, bool in) __attribute__((always_inline)) {
         if (nth_form && gh_ballot(in && x == hmax)) eq_out = hmax;
-        unsigned long long mask = gh_ballot(in && x < hmax);
+        const uint32_t xk = in ? x : 0xFFFFFFFFu;
+        unsigned long long todo = ~0ull;
+        unsigned long long mask = gh_ballot(xk < hmax);
         while (mask) {   // every lane of the mask holds a value below the maximum of this moment
             const int l = __builtin_ctzll(mask);
-            const uint32_t ev = (uint32_t)__builtin_amdgcn_readlane((int)x, l), eid = (uint32_t)__builtin_amdgcn_readlane(xid, l);
+            const uint32_t ev = (uint32_t)__builtin_amdgcn_readlane((int)xk, l), eid = (uint32_t)__builtin_amdgcn_readlane(xid, l);
             // std::__pop_heap(first, middle, i): the maximum leaves, the new element sinks in from the root
             const uint32_t old = hmax;
             if constexpr (HEAP == 0) { hs.replace_max(K, ev, eid); hmax = hs.top(); }
             else { hw.adjust(0, K, ((uint64_t)ev << 32) | eid); hmax = hw.val(0); }
             ++n_entered;
             if (nth_form && old == hmax) eq_out = hmax;   // one of several equal maxima was popped: it now waits outside
-            const unsigned long long later = l == 63 ? 0ull : ~((2ull << l) - 1ull);
-            mask = gh_ballot(in && x < hmax) & later;
-            if (nth_form && (gh_ballot(in && x == hmax) & later)) eq_out = hmax;
+            todo &= ~(1ull << l);
+            mask = gh_ballot(xk < hmax) & todo;
+            if (nth_form && (gh_ballot(in && x == hmax) & (l == 63 ? 0ull : ~((2ull << l) - 1ull)))) eq_out = hmax;
         }
     };
     // ---- the valued prefix: chunk minima through LDS, GH_CD_TILE at a time; the chunks that are live under the maximum of the
     // moment are listed (up to GH_CD_BATCH), fetched by all four waves into LDS -- every thread's loads issued together: a
     // load per loop trip was a memory round trip per trip, most of this kernel's first version -- and processed in order,
     // each re-tested (64 minima per ballot) against the maximum of its moment
-    const int nch = (int)((P + 63) >> 6);
-    for (int tile0 = (K >> 6) / GH_CD_TILE * GH_CD_TILE; tile0 < nch; tile0 += GH_CD_TILE) {
+    for (int tile0 = tile_first; tile0 < nch; tile0 += GH_CD_TILE) {
         const int nt = min(GH_CD_TILE, nch - tile0);
-        __syncthreads();
-        {
+        if (tile0 != tile_first) {
+            __syncthreads();
             float tmp[GH_CD_TILE / 256];
 #pragma unroll
             for (int u = 0; u < GH_CD_TILE / 256; ++u) tmp[u] = u * 256 + (int)threadIdx.x < nt ? cm[tile0 + u * 256 + threadIdx.x] : INFINITY;
@@ -711,71 +749,96 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
             for (int u = 0; u < GH_CD_TILE / 256; ++u) cml[u * 256 + threadIdx.x] = tmp[u];
         }
         __syncthreads();
-        int p = max(0, (K >> 6) - tile0);   // next chunk of the tile to look at (wave 0)
+        int p = max(0, c_first - tile0);   // next chunk of the tile to look at (wave 0)
         for (;;) {
-            if (wave0) {
-                int nl = 0;
-                while (p < nt && nl < GH_CD_BATCH) {
-                    const int b = p & ~63;
-                    const unsigned long long m = gh_ballot(b + lane < nt && live(cml[b + lane])) & (~0ull << (p - b));
-                    const int room = GH_CD_BATCH - nl;
-                    const int rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
-                    const bool take = ((m >> lane) & 1ull) && rank < room;
-                    if (take) live_ids[nl + rank] = b + lane;
-                    const int have = __builtin_popcountll(m);
-                    if (have > room) {   // the batch is full: go on behind the last chunk taken
-                        const unsigned long long tk = gh_ballot(take);
-                        p = b + 64 - __builtin_clzll(tk);
-                        nl = GH_CD_BATCH;
-                    } else {
-                        nl += have;
-                        p = b + 64;
+            int nl;
+            if (pre) {   // the batch fetched ahead (first tile only)
+                nl = pre;
+                p += pre;
+                pre = 0;
+                if (stamps && threadIdx.x == 0 && n_batches < 4) stamps[16 + 4 * n_batches] = wall_clock64();
+                ++n_batches;
+            } else {
+                // the chunks that are live under the maximum of the moment (published by wave 0), listed in order by all four
+                // waves: each counts the live chunks of its quarter of [p, nt), then writes them behind the quarters before
+                // it; the GH_CD_BATCH-th one listed says where the next batch starts
+                {
+                    const uint32_t hm = s_hmax;
+                    const int wv = (int)(threadIdx.x >> 6);
+                    const int g0 = p >> 6, per = (((nt + 63) >> 6) - g0 + 3) >> 2;
+                    const int ga = g0 + wv * per, gb = min((nt + 63) >> 6, ga + per);
+                    auto group = [&](int g) {
+                        const int c = (g << 6) + lane;
+                        const uint32_t mk = c >= p && c < nt ? cdist_vkey(cml[c]) : 0xFFFFFFFFu;
+                        return gh_ballot(nth_form ? !(hm < mk) : mk < hm);
+                    };
+                    int cnt = 0;
+                    for (int g = ga; g < gb; ++g) cnt += __builtin_popcountll(group(g));
+                    if (lane == 0) s_cnt[wv] = cnt;
+                    __syncthreads();
+                    int off = 0, tot = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) { const int cw = s_cnt[w]; off += w < wv ? cw : 0; tot += cw; }
+                    for (int g = ga; g < gb && off < GH_CD_BATCH; ++g) {
+                        const unsigned long long m = group(g);
+                        const int rank = off + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                        if (((m >> lane) & 1ull) && rank < GH_CD_BATCH) {
+                            live_ids[rank] = (g << 6) + lane;
+                            if (rank == GH_CD_BATCH - 1) s_pnext = (g << 6) + lane + 1;
+                        }
+                        off += __builtin_popcountll(m);
+                    }
+                    if (threadIdx.x == 0) {
+                        s_nlive = min(tot, GH_CD_BATCH);
+                        if (tot < GH_CD_BATCH) s_pnext = nt;
                     }
                 }
-                if (lane == 0) s_nlive = nl;
-            }
-            __syncthreads();
-            const int nl = s_nlive;
-            if (nl == 0) break;
-            if (stamps && threadIdx.x == 0 && n_batches < 4) stamps[16 + 4 * n_batches] = wall_clock64();
-            ++n_batches;
-            {
-                constexpr int PT = GH_CD_BATCH * 64 / 256;   // values per thread of a full batch
-                float tmp[PT];
+                __syncthreads();
+                nl = s_nlive;
+                p = s_pnext;
+                if (nl == 0) break;
+                if (stamps && threadIdx.x == 0 && n_batches < 4) stamps[16 + 4 * n_batches] = wall_clock64();
+                ++n_batches;
+                {
+                    float tmp[PT];
+                    int tid0[PT];
 #pragma unroll
-                for (int u = 0; u < PT; ++u) {
-                    const int i = u * 256 + (int)threadIdx.x;
-                    tmp[u] = i < nl * 64 ? v[((int64_t)(tile0 + live_ids[i >> 6]) << 6) + (i & 63)] : 0.0f;
+                    for (int u = 0; u < PT; ++u) {
+                        const int i = u * 256 + (int)threadIdx.x;
+                        tid0[u] = i < nl * 64 ? ((tile0 + live_ids[i >> 6]) << 6) + (i & 63) : -1;
+                        tmp[u] = tid0[u] >= 0 ? v[tid0[u]] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < PT; ++u) stage[u * 256 + threadIdx.x] = tid0[u] >= K && tid0[u] < P32 ? cdist_vkey(tmp[u]) : 0xFFFFFFFFu;
                 }
-#pragma unroll
-                for (int u = 0; u < PT; ++u) stage[u * 256 + threadIdx.x] = tmp[u];
+                __syncthreads();
             }
-            __syncthreads();
             if (stamps && threadIdx.x == 0 && n_batches <= 4) stamps[16 + 4 * (n_batches - 1) + 1] = wall_clock64();
             if (wave0) {
                 // (the ids and minima of 64 listed chunks in registers; the values of the next live chunk are requested from
                 // LDS before the current one is processed: two dependent LDS round trips per chunk were a third of its cost)
                 for (int rb = 0; rb < nl; rb += 64) {
                     const int my_c = rb + lane < nl ? live_ids[rb + lane] : 0;
-                    const float mv = rb + lane < nl ? cml[my_c] : INFINITY;
-                    unsigned long long m = gh_ballot(rb + lane < nl && live(mv));
+                    const uint32_t mk = rb + lane < nl ? cdist_vkey(cml[my_c]) : 0xFFFFFFFFu;   // (never live)
+                    unsigned long long m = gh_ballot(live_key(mk));
                     int r = m ? __builtin_ctzll(m) : 0;
-                    float xn = stage[(rb + r) * 64 + lane];
+                    uint32_t xn = stage[(rb + r) * 64 + lane];
                     while (m) {
                         ++n_chunks;
-                        const float x = xn;
-                        const int64_t base = (int64_t)(tile0 + __builtin_amdgcn_readlane(my_c, r)) << 6;
+                        const uint32_t x = xn;
+                        const int base = (tile0 + __builtin_amdgcn_readlane(my_c, r)) << 6;   // (edge ids are 32-bit)
                         const unsigned long long later = r == 63 ? 0ull : ~((2ull << r) - 1ull);
                         const int r2 = (m & later) ? __builtin_ctzll(m & later) : r;   // the next one as things stand
                         xn = stage[(rb + r2) * 64 + lane];
-                        process(cdist_vkey(x), (int32_t)(base + lane), base + lane >= K && base + lane < P);
-                        m = gh_ballot(rb + lane < nl && live(mv)) & later;
+                        process(x, base + lane, true);
+                        m = gh_ballot(live_key(mk)) & later;
                         if (!m) break;
                         r = __builtin_ctzll(m);
                         if (r != r2) xn = stage[(rb + r) * 64 + lane];   // the maximum fell below that chunk's minimum meanwhile
                     }
                 }
             }
+            if (wave0 && lane == 0) s_hmax = hmax;
             if (stamps && threadIdx.x == 0 && n_batches <= 4) { stamps[16 + 4 * (n_batches - 1) + 2] = wall_clock64(); stamps[16 + 4 * (n_batches - 1) + 3] = nl; }
             __syncthreads();
         }

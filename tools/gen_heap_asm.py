@@ -41,61 +41,54 @@ def emit(s):
 # Layout: a taken branch costs an instruction-buffer refill (tens of cycles; an instruction ~4), so the tree is laid out
 # depth first -- the right child's block follows its parent's move directly, the left one follows the landing pad of the
 # one conditional branch -- and every climb is a straight line from its starting index to the root, left by one branch.
-emitted = set()
-
-
-def climb(j):   # the hole at j moves up while its parent's value is below the new one (top = 0)
-    emitted.add(j)
-    emit(".Lgh_c%d_%%=:" % j)
-    q = j
-    while q > 0:
-        p = (q - 1) // 2
-        emit("s_cmp_lt_u32 %s, %%[xv]" % hi(p))
-        emit("s_cbranch_scc0 .Lgh_p%d_%%=" % q)
-        emit("s_mov_b64 %s, %s" % (reg(q), reg(p)))
-        q = p
-    emit("s_mov_b64 %s, %%[x]" % reg(0))
-    emit("s_branch .Lgh_done_%=")
-
-
+# The block walks DOWN only.  libstdc++ sinks the hole to the bottom along the larger children w_1 >= w_2 >= ... (heap
+# order) and lets x climb back while its parent is smaller; the result is w_1 .. w_j one level up and x below them, j = the
+# number of path elements that are not below x -- so the walk can stop at the first larger child that IS below x (the ones
+# under it are no larger), which is what one s_cselect_b64 per level does: the child moves up, or x lands and the block ends.
+# Layout: a taken branch costs an instruction-buffer refill (~28 cycles measured; an instruction ~4), so the tree is laid
+# out depth first: the right child's block follows its parent's directly, the left one follows the landing pad of the one
+# conditional branch of the level.
 def node(i):
     l, r = 2 * i + 1, 2 * i + 2
     if not internal(i):
-        climb(i)
+        emit("s_mov_b64 %s, %%[x]" % reg(i))
+        emit("s_branch .Lgh_done_%=")
         return
-    emit(".Lgh_n%d_%%=:" % i)
     if r <= KMAX - 1:
         emit("s_cmp_gt_u32 %%[len], %d" % r)              # two children?
         emit("s_cbranch_scc0 .Lgh_s%d_%%=" % i)
         emit("s_cmp_lt_u32 %s, %s" % (hi(r), hi(l)))      # the right one unless it is smaller than the left
         emit("s_cbranch_scc1 .Lgh_l%d_%%=" % i)
-        emit("s_mov_b64 %s, %s" % (reg(i), reg(r)))
+        emit("s_cmp_lt_u32 %s, %%[xv]" % hi(r))           # below x: x lands here
+        emit("s_cselect_b64 %s, %%[x], %s" % (reg(i), reg(r)))
+        emit("s_cbranch_scc1 .Lgh_done_%=")
         node(r)
         emit(".Lgh_l%d_%%=:" % i)
-        emit("s_mov_b64 %s, %s" % (reg(i), reg(l)))
+        emit("s_cmp_lt_u32 %s, %%[xv]" % hi(l))
+        emit("s_cselect_b64 %s, %%[x], %s" % (reg(i), reg(l)))
+        emit("s_cbranch_scc1 .Lgh_done_%=")
         node(l)
         emit(".Lgh_s%d_%%=:" % i)
-    emit("s_cmp_gt_u32 %%[len], %d" % l)                  # a single child (len even): it moves up, the hole ends there
-    emit("s_cbranch_scc0 .Lgh_c%d_%%=" % i)
-    emit("s_mov_b64 %s, %s" % (reg(i), reg(l)))
-    emit("s_branch .Lgh_c%d_%%=" % l)
+    emit("s_cmp_gt_u32 %%[len], %d" % l)                  # a single child (len even), or none
+    emit("s_cbranch_scc0 .Lgh_p%d_%%=" % i)
+    emit("s_cmp_lt_u32 %s, %%[xv]" % hi(l))
+    emit("s_cselect_b64 %s, %%[x], %s" % (reg(i), reg(l)))
+    emit("s_cbranch_scc1 .Lgh_done_%=")
+    emit("s_mov_b64 %s, %%[x]" % reg(l))
+    emit("s_branch .Lgh_done_%=")
+    emit(".Lgh_p%d_%%=:" % i)
+    emit("s_mov_b64 %s, %%[x]" % reg(i))
+    emit("s_branch .Lgh_done_%=")
 
 
 node(0)
-for j in range(KMAX - 1, 0, -1):
-    if j not in emitted:
-        climb(j)
-for j in range(KMAX - 1, 0, -1):
-    emit(".Lgh_p%d_%%=:" % j)
-    emit("s_mov_b64 %s, %%[x]" % reg(j))
-    emit("s_branch .Lgh_done_%=")
-emit(".Lgh_c0_%=:")
-emit("s_mov_b64 %s, %%[x]" % reg(0))
+while out[-1].startswith("s_branch .Lgh_done"):
+    out.pop()
 emit(".Lgh_done_%=:")
 
 
 def run_block(h, length, x):
-    """Interprets the generated block (the five instructions it uses) on heap h (list of (value, id)); -> taken branches."""
+    """Interprets the generated block (the six instructions it uses) on heap h (list of (value, id)); -> taken branches."""
     labels = {s[:-1]: k for k, s in enumerate(out) if s.endswith(":")}
     regs = {reg(i): h[i] for i in range(KMAX)}
     his = {hi(i): i for i in range(KMAX)}
@@ -123,6 +116,9 @@ def run_block(h, length, x):
             scc = int(val(a[0]) < val(a[1]))
         elif op == "s_mov_b64":
             regs[a[0]] = x if a[1] == "%[x]" else regs[a[1]]
+        elif op == "s_cselect_b64":
+            src = a[1] if scc else a[2]
+            regs[a[0]] = x if src == "%[x]" else regs[src]
         elif op in ("s_branch", "s_cbranch_scc0", "s_cbranch_scc1"):
             if op == "s_branch" or (op == "s_cbranch_scc0") == (scc == 0):
                 pc = labels[a[0]]
