@@ -360,6 +360,15 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
             if (d == 0) tflag[x] = 0;
         }
     }
+    // set-up workgroups: the rows they will need are requested before anything else -- two levels of dependent cold loads
+    // (edge -> rows), which the statistics' own round trip and arithmetic below then run under instead of in front of
+    // (16-wide rows: 64 registers held across the prologue would cost the launch its occupancy; they fetch afterwards)
+    constexpr int LDS_ = LDT > 0 ? LDT : 4;
+    constexpr bool early_fetch = LDT > 0 && LDT <= 8;
+    gh_setup_rows<LDS_> srows;
+    auto raw_row = [=](int64_t v, float (&row)[LDS_]) { gh_load_row<LDS_>(nw, v, row); };
+    if constexpr (early_fetch)
+        if (setup_block && sa.tiles > 0) gh_setup_fetch<LDS_>(sa, (int)blockIdx.x, raw_row, srows);
     extern __shared__ float ms[];  // mean[LD], std[LD], then the (2 + 2 nfix, LD) statistics rows as doubles
     // all statistics rows with one load per thread and round, then summed from LDS in the fixed order: a thread adding
     // its column's 2 nfix corrections straight from memory waited for them one after the other (LD = 16: 64 loads, 7.6 us
@@ -402,8 +411,13 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
         // position of vertex v, component d < D, exactly as the normalising threads below compute it
         auto getp = [=](int64_t v, int d) { return (nw[v * LD + d] - ms[d]) / ms[LD + d]; };
         if constexpr (LDT > 0) {
-            if (sa.tiles > 0) gh_setup_block<LDT>(sa, (int)blockIdx.x, getp, setup_lds, stamps);
-            else gh_setup_item(sa, t, getp);
+            if (sa.tiles > 0) {
+                auto norm = [=](float x, int d) { return (x - ms[d]) / ms[LD + d]; };
+                if constexpr (!early_fetch) gh_setup_fetch<LDS_>(sa, (int)blockIdx.x, raw_row, srows);
+                gh_setup_finish<LDS_>(sa, (int)blockIdx.x, raw_row, norm, srows, setup_lds, stamps);
+            } else {
+                gh_setup_item(sa, t, getp);
+            }
         } else {
             gh_setup_item(sa, t, getp);
         }

@@ -90,39 +90,76 @@ __device__ __forceinline__ uint32_t gh_row_min_u32(uint32_t v) {
 // (The first version put references on lanes and reduced over them on the DPP datapath: 256 dependent
 // LDS-read / DPP chains per wave, 40 us.)  Workgroup 0 also does the per-query set-up items.
 #define GH_SETUP_LDS_BYTES (GH_THR_TILE * 16 * 4)
-template <int LD, class P>
-__device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, P getp, unsigned char *lds,
-                                               unsigned long long *stamps = nullptr /* diagnostic */) {
+// The work is split at the point where the positions have to be KNOWN: gh_setup_fetch requests the rows -- RAW(vertex, row):
+// this lane's first query (sample id -> edge -> two rows) and, for the first GH_THR_TILE lanes, a subset edge of the tile
+// (endpoints -> two rows) -- and gh_setup_finish turns them into positions, NORM(raw value, d), and goes on.  Inside a
+// normalise launch the rows are the un-normalised new positions and NORM needs mean and std: the fetch is issued BEFORE the
+// statistics are read, so that the two chains of dependent cold loads and the statistics' own round trip run together.
+template <int LD>
+struct gh_setup_rows {
+    float qa[LD], qb[LD], ma[LD], mb[LD];   // endpoint rows of the lane's query / of its subset edge
+    int32_t e32;
+};
+template <int LD, class RAW /* void(int64_t vertex, float (&row)[LD]) */>
+__device__ __forceinline__ void gh_setup_fetch(const gh_setup_args &a, int blk, RAW raw, gh_setup_rows<LD> &st) {
+    const int t = threadIdx.x;
+    __builtin_amdgcn_s_setprio(3);  // inside a normalise launch these waves sit among streaming ones: their chains go first
+    if (blk == 0 && t == 0 && a.tau_flag) *a.tau_flag = 0;
+    st.e32 = 0;
+#pragma unroll
+    for (int d = 0; d < LD; ++d) { st.qa[d] = 0.0f; st.qb[d] = 0.0f; st.ma[d] = 0.0f; st.mb[d] = 0.0f; }
+    // this lane's first query (every workgroup needs all of them; issued before the tile so that both chains of
+    // dependent loads -- id -> edge -> rows here, endpoints -> rows below -- are in flight together)
+    if (t < a.S) {
+        if (a.mode == 1) st.e32 = gh_sample_id(a.E, a.seed, gh_setup_iter(a), t);
+        else if (a.mode == 2) st.e32 = (int32_t)t;
+        else st.e32 = a.sampled[t];
+        const int2 uv = reinterpret_cast<const int2 *>(a.edges)[st.e32];
+        raw(uv.x, st.qa);
+        raw(uv.y, st.qb);
+    }
+    if (t < GH_THR_TILE) {
+        const int64_t j = (int64_t)blk * GH_THR_TILE + t;
+        if (j < a.M1) {
+            const int2 uv = a.sub_uv[j];
+            raw(uv.x, st.ma);
+            raw(uv.y, st.mb);
+        }
+    }
+}
+
+template <int LD, class RAW, class NORM /* float(float raw value, int d) */>
+__device__ __forceinline__ void gh_setup_finish(const gh_setup_args &a, int blk, RAW raw, NORM norm, const gh_setup_rows<LD> &st,
+                                                unsigned char *lds, unsigned long long *stamps = nullptr /* diagnostic */) {
     // the tile in LDS as PAIRS of subset edges, component-interleaved: pair p, coordinate d -> (m_2p[d], m_2p+1[d]),
     // so that the distance chain of two references runs on packed fp32 instructions (v_pk_add_f32 / v_pk_fma_f32)
     gh_f2 *rsh = reinterpret_cast<gh_f2 *>(lds);     // [GH_THR_TILE / 2][LD]
     const int t = threadIdx.x;
-    __builtin_amdgcn_s_setprio(3);  // inside a normalise launch these waves sit among streaming ones: their chains go first
-    // this lane's first query (every workgroup needs all of them; issued before the tile so that both chains of
-    // dependent loads -- id -> edge -> rows here, endpoints -> rows below -- are in flight together)
-    if (blk == 0 && t == 0 && a.tau_flag) *a.tau_flag = 0;
     const uint64_t iter = gh_setup_iter(a);
-    auto query = [&](int64_t s, int32_t &e32, float (&q)[LD]) {
+    auto query = [&](int64_t s, int32_t &e32, float (&q)[LD]) {   // (queries past the first 256)
         if (a.mode == 1) e32 = gh_sample_id(a.E, a.seed, iter, s);
         else if (a.mode == 2) e32 = (int32_t)s;
         else e32 = a.sampled[s];
         const int2 uv = reinterpret_cast<const int2 *>(a.edges)[e32];
+        float ra[LD], rb[LD];
+        raw(uv.x, ra);
+        raw(uv.y, rb);
 #pragma unroll
-        for (int d = 0; d < LD; ++d) q[d] = d < a.D ? (getp(uv.x, d) + getp(uv.y, d)) / 2.0f : 0.0f;
+        for (int d = 0; d < LD; ++d) q[d] = d < a.D ? (norm(ra[d], d) + norm(rb[d], d)) / 2.0f : 0.0f;
     };
     float q[LD];
-    int32_t e32 = 0;
-    if (t < a.S) query(t, e32, q);
+    int32_t e32 = st.e32;
+#pragma unroll
+    for (int d = 0; d < LD; ++d) q[d] = d < a.D ? (norm(st.qa[d], d) + norm(st.qb[d], d)) / 2.0f : 0.0f;
     if (t < GH_THR_TILE) {
         const int64_t j = (int64_t)blk * GH_THR_TILE + t;
         float m[LD];
 #pragma unroll
         for (int d = 0; d < LD; ++d) m[d] = 0.0f;
         if (j < a.M1) {
-            const int2 uv = a.sub_uv[j];
 #pragma unroll
             for (int d = 0; d < LD; ++d)
-                if (d < a.D) m[d] = (getp(uv.x, d) + getp(uv.y, d)) / 2.0f;
+                if (d < a.D) m[d] = (norm(st.ma[d], d) + norm(st.mb[d], d)) / 2.0f;
         } else {
             m[0] = INFINITY;  // padding slot: (q - inf)^2 = inf for every finite query
         }
@@ -181,6 +218,20 @@ __device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, 
                 *reinterpret_cast<uint4 *>(dst + g4) = make_uint4(mn[g4], mn[g4 + 1], mn[g4 + 2], mn[g4 + 3]);
         }
     }
+}
+
+// Both halves at once, positions read through getp(vertex, d) (knn_setup_kernel, the gathered normalise).
+template <int LD, class P>
+__device__ __forceinline__ void gh_setup_block(const gh_setup_args &a, int blk, P getp, unsigned char *lds,
+                                               unsigned long long *stamps = nullptr /* diagnostic */) {
+    auto raw = [&](int64_t v, float (&row)[LD]) {
+#pragma unroll
+        for (int d = 0; d < LD; ++d) row[d] = d < a.D ? getp(v, d) : 0.0f;
+    };
+    auto norm = [](float x, int) { return x; };
+    gh_setup_rows<LD> st;
+    gh_setup_fetch<LD>(a, blk, raw, st);
+    gh_setup_finish<LD>(a, blk, raw, norm, st, lds, stamps);
 }
 
 // Runtime row stride -> the instantiation (the scan path has LD in {4, 8, 16}).
