@@ -3,13 +3,16 @@
 replay (csrc/cdist.hip, cdist_heap_scalar) as ONE block of gfx950 scalar instructions over 16 pinned SGPR pairs.
 
 libstdc++'s __adjust_heap(first, 0, len, x) + __push_heap, written as a decision tree: every heap index is a register
-name, so an element that enters costs 5 instructions per level on the way down (is there a child, compare the children's
-values, s_mov_b64 of value and id together), 3 per level on the way up and one to place it -- the compiler's rendering of the same
-tree copies the whole heap between register sets at every merge (profiles/r04/cdist: 526 cycles per element).
+name, so an element that enters costs 7 instructions per level it passes (is there a child, which child, is it below x:
+s_cselect_b64 moves the child up or lands x) -- the compiler's rendering of the same tree over two register arrays copied
+the whole heap between register sets at every merge (NOTES.md round 4: 526 cycles per element).
 
-usage: python tools/gen_heap_asm.py        (rewrites the header in place; the header is committed)
+usage: python tools/gen_heap_asm.py          rewrites the header in place (the header is committed)
+       python tools/gen_heap_asm.py --check  checks the block against a port of __adjust_heap and the committed header
+                                             against what would be written (tests/test_heap_asm_generator.py)
 """
 import os
+import sys
 
 BASE = 40      # heap element i lives in s[BASE + 2 i : BASE + 2 i + 1]: id in the low half, value key in the high half
 KMAX = 16
@@ -170,23 +173,35 @@ def self_check():
                 tk += a
                 st += b
                 n += 1
-    print("self-check: %d replacements identical to __adjust_heap; %.1f instructions, %.1f taken branches each" % (n, st / n, tk / n))
+    return "self-check: %d replacements identical to __adjust_heap; %.1f instructions, %.1f taken branches each" % (n, st / n, tk / n)
 
 
-self_check()
+HEADER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "graphem-rapids_amd", "csrc", "cdist_heap_asm.h")
 
-path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "graphem-rapids_amd", "csrc", "cdist_heap_asm.h")
-with open(path, "w") as f:
-    f.write("// GENERATED by tools/gen_heap_asm.py -- do not edit.  The K <= %d heap of csrc/cdist.hip in pinned scalar registers:\n" % KMAX)
-    f.write("// element i = %s ... (id low, value key high); one block replaces the maximum by [x] ([xv] = its value key) in a\n" % reg(0))
-    f.write("// heap of [len] elements exactly as libstdc++'s __adjust_heap(first, 0, len, x) + __push_heap do.\n")
-    f.write("#pragma once\n")
-    f.write("#define GH_CD_HEAP_BASE %d\n" % BASE)
-    f.write("#define GH_CD_HEAP_REPLACE_ASM \\\n")
-    for s in out:
-        f.write('    "%s\\n" \\\n' % s)
-    f.write('    ""\n')
-    f.write("#define GH_CD_HEAP_OPERANDS(h) \\\n    ")
-    f.write(", ".join('"+{%s}"((h)[%d])' % (reg(i), i) for i in range(KMAX)))
-    f.write("\n")
-print("wrote", os.path.normpath(path), len(out), "lines")
+
+def header_text():
+    t = []
+    t.append("// GENERATED by tools/gen_heap_asm.py -- do not edit.  The K <= %d heap of csrc/cdist.hip in pinned scalar registers:\n" % KMAX)
+    t.append("// element i = %s ... (id low, value key high); one block replaces the maximum by [x] ([xv] = its value key) in a\n" % reg(0))
+    t.append("// heap of [len] elements exactly as libstdc++'s __adjust_heap(first, 0, len, x) + __push_heap do.\n")
+    t.append("#pragma once\n")
+    t.append("#define GH_CD_HEAP_BASE %d\n" % BASE)
+    t.append("#define GH_CD_HEAP_REPLACE_ASM \\\n")
+    for line in out:
+        t.append('    "%s\\n" \\\n' % line)
+    t.append('    ""\n')
+    t.append("#define GH_CD_HEAP_OPERANDS(h) \\\n    ")
+    t.append(", ".join('"+{%s}"((h)[%d])' % (reg(i), i) for i in range(KMAX)))
+    t.append("\n")
+    return "".join(t)
+
+
+if __name__ == "__main__":
+    print(self_check())
+    if "--check" in sys.argv[1:]:
+        same = open(HEADER).read() == header_text()
+        print("committed header", "matches" if same else "DIFFERS from", "the generator's output")
+        sys.exit(0 if same else 1)
+    with open(HEADER, "w") as f:
+        f.write(header_text())
+    print("wrote", os.path.normpath(HEADER), len(out), "lines")
