@@ -102,6 +102,30 @@ def test_cdist_rows_equal_atens_on_random_graphs(n, deg, D, k, S, kind):
     eng.close()
 
 
+@pytest.mark.parametrize("k", list(range(1, 16)))
+def test_scalar_register_heap_at_every_length(k):
+    """K = k + 1 = 2 .. 16 keys: the replay's heap lives in pinned scalar registers and its step is the generated block of
+    csrc/cdist_heap_asm.h (tools/gen_heap_asm.py), whose shape depends on the heap length (which nodes have two children,
+    one, none).  Lattice positions put ties in every row; E = 6000 sends every row through the full pass (256 replays per
+    search), a second graph goes through the filtered scan + prefix / tail replay."""
+    import graphem_rapids_amd as gra
+    for n, deg, D, kind, S in ((3000, 4, 3, "lattice", 256), (30000, 8, 2, "lattice_fine", 256)):
+        rng = np.random.default_rng(1000 * k + D)
+        edges = np.ascontiguousarray(gra.random_regular_edges(n, deg, seed=k), dtype=np.int32)
+        E = len(edges)
+        pos = _positions(kind, n, D, rng)
+        eng = _engine(n, D, edges, k, S)
+        eng.set_positions(pos)
+        sampled = rng.permutation(E)[:S].astype(np.int32)
+        knn = eng.knn_midpoints(sampled)
+        full, unresolved = eng.knn_cdist_stats()
+        want = oracle.knn_midpoints_aten(pos, edges, sampled, k)
+        bad = np.nonzero(~(knn == want).all(axis=1))[0]
+        assert len(bad) == 0, f"K = {k + 1}, {kind}: {len(bad)} rows differ; first: row {bad[0]}\n  hip  {knn[bad[0]]}\n  aten {want[bad[0]]}"
+        assert unresolved == 0 and full > 0
+        eng.close()
+
+
 @pytest.mark.parametrize("n,deg,D,k,kind", [
     (120, 4, 3, 10, "gauss"),          # E = 240 < 64 * 11
     (120, 4, 3, 10, "lattice"),        # ties in every row: introselect's and introsort's order of equal values
