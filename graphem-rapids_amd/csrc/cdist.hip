@@ -33,11 +33,14 @@
 //           IS in the list.  The select workgroup of a listed row finds P from a histogram of the list's ids and puts the
 //           list's tail (ids >= P) in id order (range start + rank inside the range), in registers / LDS;
 //        b. cdist_prefix_kernel values only the ids below P (chip-wide; minima per 64 ids on the side);
-//        c. cdist_replay_kernel (one workgroup per listed row; wave 0 replays, all four waves fetch) walks the prefix --
-//           skipping 64-id chunks whose minimum cannot enter, the live ones staged through LDS 128 at a time -- then
-//           the sorted tail, pops the heap into ascending order and runs the row's intersection phase.  K <= 64: the heap
-//           lives one element per lane and an element enters in ONE data-parallel step (children through ds_bpermute,
-//           the sift path through v_readlane, every lane on the path deciding for itself): ~0.1 us instead of ~0.3.
+//        c. cdist_replay_kernel (one workgroup per listed row; wave 0 replays, all four waves list and fetch) walks the
+//           prefix -- skipping 64-id chunks whose minimum cannot enter, the live ones staged through LDS 128 at a time as
+//           value keys, the first 128 chunks fetched ahead of the heap build -- then the sorted tail, pops the heap into
+//           ascending order and runs the row's intersection phase.  The replay is ONE wave's instruction stream, ~150
+//           entering elements per row at a million vertices, so the step is written for its instruction count: K <= 16
+//           keys live in pinned scalar register pairs and an element enters through a generated block of ~13 scalar
+//           instructions (cdist_heap_asm.h); K <= 64 one element per lane, an element enters in one data-parallel step
+//           (children through ds_bpermute, the sift path through v_readlane); beyond, in LDS.
 //      A row whose list overflowed or could not be proven complete takes P = E (no tail): the round-3 full pass.
 //   EVERY row of a graph too small for the scan takes (b) + (c) with P = E.
 //   Rows of graphs with K * 64 > E (tiny ones) are ranked by std::nth_element + std::sort in ATen: cdist_nth_kernel replays
@@ -486,10 +489,13 @@ __device__ __forceinline__ uint32_t cdist_kv(uint64_t key) { return (uint32_t)(k
 // Max-heap with the tie behaviour of libstdc++'s __adjust_heap, which std::partial_sort is built on: the hole at `top`
 // sinks to the bottom along the larger child (the RIGHT one unless it is smaller than the left), then the new element climbs
 // while its parent is smaller.  Three homes for the heap:
-//   cdist_heap_scalar  K <= 16 (n_neighbors <= 15): the keys in SCALAR registers, every index a compile-time constant: the sink
-//                   is a decision tree of s_cmp / s_mov_b64, ~25 scalar instructions per element that enters.  One wave
-//                   issues an instruction every ~4 cycles whatever its kind, so the instruction count IS the time: the
-//                   lane-parallel form below takes ~75 (0.24 us per element measured, 140 elements per row).
+//   cdist_heap_scalar  K <= 16 (n_neighbors <= 15): the keys in SCALAR registers, every index a register name: a generated
+//                   decision tree (cdist_heap_asm.h) that walks DOWN only -- the path of larger children is
+//                   non-increasing, so the new element lands at the first child below it, which is where the climb
+//                   would have brought it back to --, 12.6 scalar instructions and 2.2 taken branches per element
+//                   on average.  One wave issues an instruction every ~4 cycles and pays ~28 for a taken branch, so
+//                   instructions and branches ARE the time: ~0.07 us per element; the lane-parallel form below takes
+//                   ~75 instructions (0.24 us).
 //   cdist_heap_par  K <= 64: element i in lane i's registers; the whole adjustment is ONE data-parallel step.  Every
 //                   lane looks at its two children (ds_bpermute) and knows which one the hole would move to; the path is
 //                   followed through v_readlane (a few scalar steps); along the path the old values w_1 >= w_2 >= ... (heap
