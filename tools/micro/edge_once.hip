@@ -49,6 +49,45 @@ __device__ __forceinline__ void term(const float *px, const float *py, float L_m
     t[3] = 0.0f;
 }
 
+// (round 4, second half) two more shapes of the same pull: the neighbour rows through non-temporal loads (global_load ... nt:
+// does a gather that is not going to hit again cost the fabric a whole 128-byte line?), and rows without their pad column
+// (12-byte stride: a 12 MB table, 10.7 rows per line instead of 8)
+typedef float gh_v4f __attribute__((ext_vector_type(4)));
+template <int MODE>
+__global__ __launch_bounds__(256) void pull_variant_kernel(const float *__restrict__ pos, const float *__restrict__ pos12,
+                                                           const int *__restrict__ adj8, int64_t n, float *__restrict__ Fs,
+                                                           float *__restrict__ new0) {
+    const int64_t x = blockIdx.x * (int64_t)256 + threadIdx.x;
+    if (x >= n) return;
+    float px[4], F[4] = {0.f, 0.f, 0.f, 0.f};
+    gh_load_row<4>(pos, x, px);
+    const int4 a = reinterpret_cast<const int4 *>(adj8)[2 * x], b = reinterpret_cast<const int4 *>(adj8)[2 * x + 1];
+    const int ys[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float py[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (MODE == 1) {
+            const gh_v4f r = __builtin_nontemporal_load(reinterpret_cast<const gh_v4f *>(pos) + ys[j]);
+            py[j][0] = r.x; py[j][1] = r.y; py[j][2] = r.z; py[j][3] = r.w;
+        } else {
+            const float *r = pos12 + (int64_t)ys[j] * 3;
+            py[j][0] = r[0]; py[j][1] = r[1]; py[j][2] = r[2]; py[j][3] = 0.0f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t[4];
+        term<true>(px, py[j], 1.0f, -0.2f, t);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) F[d] = F[d] + t[d];
+    }
+    float nw[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) nw[d] = px[d] + F[d];
+    gh_store_row<4>(Fs, x, F);
+    gh_store_row<4>(new0, x, nw);
+}
+
 template <bool ARITH>
 __global__ __launch_bounds__(256) void pull_kernel(const float *__restrict__ pos, const int *__restrict__ adj8, int64_t n,
                                                    float *__restrict__ Fs, float *__restrict__ new0) {
@@ -158,6 +197,23 @@ int main(int argc, char **argv) {
     printf("n = %lld vertices, E = %lld edges, position table %.0f MB, slot array %.0f MB\n", (long long)n, (long long)(4 * n), n * 16 / 1e6, n * 128 / 1e6);
     const float t_pull = timeit("pull", [&] { pull_kernel<true><<<grid, blk>>>(pos, d8, n, Fs, new0); });
     const float t_pull_mem = timeit("pull_mem", [&] { pull_kernel<false><<<grid, blk>>>(pos, d8, n, Fs, new0); });
+    {
+        std::vector<float> h12((size_t)n * 3);
+        for (int64_t i = 0; i < n; ++i) for (int d = 0; d < 3; ++d) h12[(size_t)i * 3 + d] = hp[(size_t)i * 4 + d];
+        float *pos12;
+        CK(hipMalloc(&pos12, n * 12));
+        CK(hipMemcpy(pos12, h12.data(), n * 12, hipMemcpyHostToDevice));
+        timeit("pull_nt", [&] { pull_variant_kernel<1><<<grid, blk>>>(pos, pos12, d8, n, Fs2, new02); });
+        timeit("pull_12B", [&] { pull_variant_kernel<2><<<grid, blk>>>(pos, pos12, d8, n, Fs2, new02); });
+        std::vector<float> a((size_t)n * 4), b((size_t)n * 4);
+        pull_kernel<true><<<grid, blk>>>(pos, d8, n, Fs, new0);
+        CK(hipMemcpy(a.data(), Fs, n * 16, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(b.data(), Fs2, n * 16, hipMemcpyDeviceToHost));
+        int64_t bad = 0;
+        for (size_t i = 0; i < a.size(); ++i) bad += a[i] != b[i] ? 1 : 0;
+        printf("12-byte rows: forces identical: %s\n", bad ? "NO" : "yes");
+        CK(hipFree(pos12));
+    }
     pull_kernel<true><<<grid, blk>>>(pos, d8, n, Fs, new0);
     const float t_once = timeit("once", [&] { once_kernel<true><<<grid, blk>>>(pos, d4, n, slots); });
     const float t_once_mem = timeit("once_mem", [&] { once_kernel<false><<<grid, blk>>>(pos, d4, n, slots); });
