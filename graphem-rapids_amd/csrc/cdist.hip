@@ -47,7 +47,9 @@
 //   libstdc++'s introselect and introsort on their values (E <= 8000; beyond, equal values are ordered by id and a row with a
 //   tie is counted in gh_knn_cdist_stats).
 //   Row partitions: a rank stops at (2) with its K + 1 best keys and a proof flag; after the all-gather
-//   knn_merge_cdist_kernel decides the rows without a tie and lists the others, which every rank replays with P = E.
+//   knn_merge_cdist_kernel decides the rows without a tie and lists the others, which every rank replays -- over the ids
+//   below a bound P taken from the gathered keys alone (about E / world) plus the gathered keys behind it; P = E where a
+//   rank could not prove its keys.
 #include "common.h"
 #include "engine.h"
 #include "scan_core.h"
@@ -331,20 +333,23 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
 // Row partitions: the ranks' K + 1 best cdist keys (and whether each rank could prove them its K + 1 best) -> the global
 // rows.  A query whose merged K + 1 smallest values are pairwise different, every rank's list proven, is decided: ascending
 // values (its k candidate pairs go through the intersection phase here).  Any other query is LISTED and partial_sort's heap
-// is replayed over ALL edges (P = E, no tail: the candidate lists are spread over the ranks) -- on every rank alike, every
-// rank holding all positions and the whole edge list, so no further collective is needed and all ranks get the same rows.
+// is replayed -- on every rank alike, every rank holding all positions and the whole edge list, so no further collective
+// is needed and all ranks get the same rows; over which ids, see the listed branch below.
 template <int DT>
 __global__ __launch_bounds__(256) void knn_merge_cdist_kernel(const uint64_t *__restrict__ gathered /* (world, S, K + 2) */, int world,
                                                               int64_t S, int K, int64_t E, uint64_t *__restrict__ merged, cdist_rows rr,
-                                                              inter_args ia) {
+                                                              inter_args ia, uint64_t *__restrict__ cand /* listed rows: their tails */,
+                                                              int bound /* a second n2 keys of LDS are there for the id order */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t *buf = reinterpret_cast<uint64_t *>(smem_raw);
     __shared__ gh_pair_list pairs;
+    __shared__ uint32_t s_tstar;
     const int Ks = K + 1;
     const int64_t qi = blockIdx.x;
     const int total = world * Ks;
     const int n2 = next_pow2(total < 2 ? 2 : total);
-    int bad = 0;
+    int bad = 0, unproven = 0;
+    if (threadIdx.x == 0) s_tstar = 0xFFFFFFFFu;
     for (int i = threadIdx.x; i < n2; i += 256) {
         uint64_t key = GH_KEY_INF;
         if (i < total) {
@@ -353,17 +358,47 @@ __global__ __launch_bounds__(256) void knn_merge_cdist_kernel(const uint64_t *__
         }
         buf[i] = key;
     }
-    for (int w = threadIdx.x; w < world; w += 256) bad |= gathered[((int64_t)w * S + qi) * (Ks + 1) + Ks] == 1ull ? 0 : 1;
+    for (int w = threadIdx.x; w < world; w += 256) unproven |= gathered[((int64_t)w * S + qi) * (Ks + 1) + Ks] == 1ull ? 0 : 1;
     __syncthreads();
+    // t* = the smallest of the ranks' (K + 1)-th best values: an edge outside the gathered keys is no better than its own
+    // rank's (K + 1)-th best, hence not below t* (a rank with fewer keys holds all its edges: its slot is the padding key)
+    for (int w = threadIdx.x; w < world; w += 256) atomicMin(&s_tstar, (uint32_t)(buf[w * Ks + Ks - 1] >> 32));
+    unproven = __syncthreads_or(unproven);
+    const uint32_t tstar = s_tstar;
     block_sort(buf, n2);
     for (int i = threadIdx.x; i + 1 < Ks; i += 256) bad |= (uint32_t)(buf[i] >> 32) == (uint32_t)(buf[i + 1] >> 32) ? 1 : 0;
-    if (__syncthreads_or(bad)) {
+    if (__syncthreads_or(bad) || unproven) {
+        // LISTED.  With every rank's keys proven, partial_sort's heap need not see all E values (the bound of the single-rank
+        // replay, from the gathered keys alone): let C = the gathered keys with value <= t* (at least K + 1 of them) and P =
+        // one past the K-th smallest ID in C.  Once the ids below P are through, the heap holds K values <= t*, so whatever
+        // enters later has a value < t* -- below every rank's (K + 1)-th best, hence among the gathered keys.  The replay
+        // therefore takes the ids below P in full and, behind them, the keys of C with id >= P in id order (the tail).  With
+        // the ranks' best keys alike in value C holds about world * K keys and P is about E / world.
+        int32_t P = (int32_t)E, ct = 0;
+        if (!unproven && bound) {
+            uint64_t *byid = buf + n2;
+            int c = 0;   // (buf is sorted by (value, id): C is its first c keys)
+            for (int i0 = 0; i0 < n2; i0 += 256) {
+                const int i = i0 + (int)threadIdx.x;
+                const uint64_t key = i < n2 ? buf[i] : GH_KEY_INF;
+                const bool in = i < total && (uint32_t)(key >> 32) <= tstar;
+                if (i < n2) byid[i] = in ? (key << 32) | (key >> 32) : GH_KEY_INF;   // (id << 32 | value bits): the tail's format
+                c += __syncthreads_count(in ? 1 : 0);
+            }
+            block_sort(byid, n2);
+            if (c >= K) {
+                P = (int32_t)min((int64_t)(byid[K - 1] >> 32) + 1, E);
+                ct = c - K;
+                uint64_t *tl = cand + qi * GH_CAND_CAP + GH_CD_ALT;
+                for (int i = threadIdx.x; i < ct; i += 256) tl[i] = byid[K + i];
+            }
+        }
         if (threadIdx.x == 0) {
             const int slot = atomicAdd(&rr.hdr[0], 1);
             rr.rare[1 + slot] = (int32_t)qi;
-            rr.P[slot] = (int32_t)E;
-            rr.ct[slot] = 0;
-            atomicMax(&rr.hdr[2], (int32_t)E);
+            rr.P[slot] = P;
+            rr.ct[slot] = ct;
+            atomicMax(&rr.hdr[2], P);
         }
         return;
     }
@@ -1195,11 +1230,13 @@ gh_status gh_knn_merge_cdist(gh_engine *h, const uint64_t *gathered, int world) 
         h->err = "world * (n_neighbors + 2) too large for the merge kernel";
         return GH_ERR_INVALID;
     }
+    // the listed rows' prefix bound needs the keys a second time, in id order (else: P = E); ids are 32-bit
+    const int bound = (size_t)2 * n2 * sizeof(uint64_t) <= 40 * 1024 && h->E < ((int64_t)1 << 31) ? 1 : 0;
     {
         gh_scope t(h, fuse ? "knn_merge_cdist_intersect" : "knn_merge_cdist");
         const inter_args ia = make_inter_args(h, fuse);
-#define GH_CMRG(DD) knn_merge_cdist_kernel<DD><<<dim3((unsigned)h->S), dim3(256), sizeof(uint64_t) * (size_t)n2, h->stream>>>( \
-        gathered, world, h->S, h->K, h->E, h->d_merged, rr, ia)
+#define GH_CMRG(DD) knn_merge_cdist_kernel<DD><<<dim3((unsigned)h->S), dim3(256), sizeof(uint64_t) * (size_t)n2 * (bound ? 2 : 1), h->stream>>>( \
+        gathered, world, h->S, h->K, h->E, h->d_merged, rr, ia, h->d_cand, bound)
         if (fuse) { GH_DISPATCH_DIM(h->D, GH_CMRG) } else { GH_CMRG(0); }
 #undef GH_CMRG
         GH_LAUNCH_CHECK();

@@ -73,10 +73,10 @@ typedef struct {
  *                  (GH_ERR_INVALID).  On a row partition (gh_partition given) a rank sends, instead of its K best keys, a
  *                  record of K + 2 words per query (gh_knn_partial_cols): its K + 1 best cdist keys and 1 where it could
  *                  prove them its K + 1 best; gh_step_merge decides the queries whose merged K + 1 smallest values are
- *                  pairwise different and replays partial_sort's heap over ALL edges for the others -- every rank holds
- *                  all positions and the whole edge list, so every rank gets the same rows and no further collective is
- *                  needed (the single engine's prefix / tail shortcut needs one candidate list; there it is spread over
- *                  the ranks). */
+ *                  pairwise different and replays partial_sort's heap for the others -- every rank holds all positions
+ *                  and the whole edge list, so every rank gets the same rows and no further collective is needed; the
+ *                  replay covers the ids below a bound taken from the gathered keys (about E / world) and the gathered
+ *                  keys behind it, or all edges where a rank could not prove its keys. */
 #define GH_DIST_EXACT 0
 #define GH_DIST_CDIST 1
 
