@@ -183,8 +183,8 @@ SPINUP_MS = 150.0
 
 def spin_up(run, sync, steps, reset):
     """The device's power state, not the workload: an MI355X that sat idle while the host built the graph runs its first
-    ~15 ms of kernels at lower clocks (rr1m: 20-step passes of 176, 172, 168, 166, 165 us per iteration after 3 s of idle
-    against 164 back to back on a busy device, the SAME layout either way -- tools/warm_probe.py).  So the same iterations
+    ~15 ms of kernels at lower clocks (rr1m: 20-step passes of 177, 175, 169, 167, 166 us per iteration after 3 s of idle
+    against 164 back to back on a busy device, the SAME layout either way -- tools/warm_probe.py, profiles/r04/final/warm_probe.log).  So the same iterations
     run untimed for SPINUP_MS first, then `reset` puts the starting positions back: the W warm-up steps and the K timed
     steps that follow are the iterations they would have been without this, on a device in its steady state."""
     t0 = time.perf_counter()
