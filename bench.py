@@ -181,20 +181,26 @@ def parity_mode(args, n, D, k, S, edges, pos, device_id):
 SPINUP_MS = 150.0
 
 
-def spin_up(run, sync, steps, reset):
+def spin_up(run, sync, steps, reset, agree=None):
     """The device's power state, not the workload: an MI355X that sat idle while the host built the graph runs its first
     ~15 ms of kernels at lower clocks (rr1m: 20-step passes of 177, 175, 169, 167, 166 us per iteration after 3 s of idle
     against 164 back to back on a busy device, the SAME layout either way -- tools/warm_probe.py, profiles/r04/final/warm_probe.log).  So the same iterations
     run untimed for SPINUP_MS first, then `reset` puts the starting positions back: the W warm-up steps and the K timed
     steps that follow are the iterations they would have been without this, on a device in its steady state."""
+    # (every rank must run the SAME number of iterations -- they contain collectives: one timed round, the slowest rank's
+    # time agreed on, the number of further rounds derived from that)
+    run(steps)   # (the first round carries one-off launches: not the one to measure)
+    sync()
     t0 = time.perf_counter()
-    n = 0
-    while (time.perf_counter() - t0) * 1e3 < SPINUP_MS:
+    run(steps)
+    sync()
+    dt = agree(time.perf_counter() - t0) if agree else time.perf_counter() - t0
+    rounds = int(min(2000, max(0, np.ceil(SPINUP_MS * 1e-3 / max(dt, 1e-6)) - 1)))
+    for _ in range(rounds):
         run(steps)
-        sync()
-        n += steps
+    sync()
     reset()
-    return n
+    return (2 + rounds) * steps
 
 
 def self_launch(args):
@@ -316,7 +322,13 @@ def main():
         def barrier():
             return None
 
-    spinup_steps = spin_up(run, sync, max(1, args.steps), (lambda: lay.set_positions(pos)) if use_dist else (lambda: eng.set_positions(pos)))
+    def agree(dt_local):   # the slowest rank's time, the same number on every rank
+        if not use_dist:
+            return dt_local
+        t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    spinup_steps = spin_up(run, sync, max(1, args.steps), (lambda: lay.set_positions(pos)) if use_dist else (lambda: eng.set_positions(pos)), agree)
     run(args.warmup)
     passes = []
     for _ in range(max(1, args.repeats)):   # median of 3 repeats; every pass is exactly --steps iterations
