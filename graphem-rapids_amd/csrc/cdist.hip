@@ -1116,7 +1116,10 @@ static gh_status cdist_replay_rounds(gh_engine *h, const cdist_args &a, const cd
     const int64_t vstride = cdist_vstride(h);
     const int nth_form = (int64_t)h->K * 64 > h->E ? 1 : 0;
     const int all = all_rows ? (int)h->S : 0;
-    const int npt = h->E >= (1 << 16) ? 4 : 1;   // ids per thread of cdist_prefix_kernel
+    // ids per thread of cdist_prefix_kernel: four where the prefix is all edges or E / world of them (more gathers in flight per
+    // thread); one where it is the sliver a single engine's candidate list leaves (~E / stride ids: spread over as many
+    // workgroups as there are, each thread's chain one id long)
+    const int npt = h->E >= (1 << 16) && (all_rows || h->cd_part) ? 4 : 1;
     const unsigned nwg = (unsigned)((h->E + 256 * npt - 1) / (256 * npt));
     const unsigned gx = std::min(nwg, 1024u);
     // rows of a round are spread over gridDim.y so that the chip is filled, and so that a workgroup takes at most 256 of them
