@@ -67,8 +67,8 @@ typedef struct {
  *                  reference's row by row at every size.  The candidates of the filtered scan are re-valued with that
  *                  formula; for the rows whose K + 1 smallest values hold a tie (about 1 in 100 at a million vertices)
  *                  partial_sort's heap is replayed over the ids below a prefix bound (about E / stride of them) and the
- *                  id-sorted rest of the candidate list (csrc/cdist.hip): two more launches per iteration, 231 against
- *                  167 us at a million vertices.  Works on the candidates of GH_KNN_SCAN only: knn_method = GH_KNN_AUTO
+ *                  id-sorted rest of the candidate list (csrc/cdist.hip): two more launches per iteration, 220 against
+ *                  165 us at a million vertices.  Works on the candidates of GH_KNN_SCAN only: knn_method = GH_KNN_AUTO
  *                  takes the scan whatever the sample size, an explicit GH_KNN_GRID / GH_KNN_IVF is refused
  *                  (GH_ERR_INVALID).  On a row partition (gh_partition given) a rank sends, instead of its K best keys, a
  *                  record of K + 2 words per query (gh_knn_partial_cols): its K + 1 best cdist keys and 1 where it could
