@@ -15,7 +15,7 @@
 //   intersection    f64_intersect_kernel: pt.py:638-774 per candidate pair, double atomics into a dense (n, D) array
 //   update          f64_sum_kernel / f64_centre_kernel / f64_scale_kernel: new = pos + (Fs + Fi); column means, then
 //                   centred sums of squares (two passes, fixed-order reductions), unbiased std + 1e-6, divide.
-// Per-iteration cost is dominated by the search: S * E double distances twice (15 ms at a million vertices).
+// Per-iteration cost is dominated by the search: S * E double distances twice.
 #include "common.h"
 #include "engine.h"
 
@@ -92,26 +92,62 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
     if ((int)threadIdx.x < D) q[threadIdx.x] = mid[qe * D + threadIdx.x];
     if (threadIdx.x == 0) pool_n = 0;
     __syncthreads();
-    auto dist2 = [&](int64_t e) {
-        double s = 0.0;
-        for (int d = 0; d < D; ++d) { const double t = q[d] - mid[e * D + d]; s = fma(t, t, s); }
-        return s;
+    // A scan of the thread's stripe (e = threadIdx.x, + 256, ...): the squared distances of F64_UNR edges at a time, every
+    // load of the round requested before the first is used.  (One edge per trip left a single load in flight per thread:
+    // 15.6 K dependent memory round trips per scan at a million vertices, 99 of the engine's 100 ms per iteration.)  The
+    // chain of one edge is the same fma chain in coordinate order as before.
+    constexpr int F64_UNR = 8;
+    auto scan = [&](auto visit) __attribute__((always_inline)) {
+        for (int64_t e0 = threadIdx.x; e0 < E; e0 += 256 * F64_UNR) {
+            double s[F64_UNR];
+#pragma unroll
+            for (int u = 0; u < F64_UNR; ++u) s[u] = 0.0;
+            for (int d = 0; d < D; ++d) {
+                double t[F64_UNR];
+#pragma unroll
+                for (int u = 0; u < F64_UNR; ++u) {
+                    const int64_t e = e0 + (int64_t)u * 256;
+                    t[u] = e < E ? mid[e * D + d] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < F64_UNR; ++u) { const double df = q[d] - t[u]; s[u] = fma(df, df, s[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < F64_UNR; ++u) {
+                const int64_t e = e0 + (int64_t)u * 256;
+                if (e < E) visit(e, s[u]);
+            }
+        }
     };
-    // pass 1: the K-th smallest (rounded-down distance, id) key, by K rounds of a block-wide minimum over per-thread
-    // sorted candidates would be O(K E); instead every thread keeps its own smallest key not yet taken and the block
-    // extracts K times from those 256 -- a thread refills by rescanning its stripe above the last key it gave away.
-    // Simple and O(E + K * E / 256): fine for the sizes float64 runs are for.
-    uint64_t mine = GH_KEY_INF, taken = 0;   // taken: the largest key this thread has handed over (exclusive lower bound)
-    bool have_taken = false;
+    // pass 1: the K-th smallest (rounded-down distance, id) key.  One scan leaves every thread the F64_BEST smallest keys
+    // of its stripe, sorted; the block then extracts K times from the threads' current smallest.  A thread whose F64_BEST
+    // keys have all been taken (more than F64_BEST of the K best in one stripe of 1/256 of the ids: rare) rescans its
+    // stripe for the smallest key above the last one it gave away -- the first version's refill, kept as the fallback.
+    constexpr int F64_BEST = 4;
+    uint64_t best[F64_BEST];
+#pragma unroll
+    for (int i = 0; i < F64_BEST; ++i) best[i] = GH_KEY_INF;
+    scan([&](int64_t e, double d2) {
+        uint64_t key = gh_key(f64_round_down(d2), (uint32_t)e);
+        if (key < best[F64_BEST - 1]) {
+#pragma unroll
+            for (int i = 0; i < F64_BEST; ++i) {   // sorted insertion: the new key bubbles down to its place
+                const uint64_t lo = key < best[i] ? key : best[i];
+                key = key < best[i] ? best[i] : key;
+                best[i] = lo;
+            }
+        }
+    });
+    uint64_t mine = best[0], taken = 0;   // taken: the largest key this thread has handed over (exclusive lower bound)
+    int given = 0;
     auto refill = [&]() {
         uint64_t m = GH_KEY_INF;
-        for (int64_t e = threadIdx.x; e < E; e += 256) {
-            const uint64_t key = gh_key(f64_round_down(dist2(e)), (uint32_t)e);
-            if ((!have_taken || key > taken) && key < m) m = key;
-        }
+        scan([&](int64_t e, double d2) {
+            const uint64_t key = gh_key(f64_round_down(d2), (uint32_t)e);
+            if (key > taken && key < m) m = key;
+        });
         mine = m;
     };
-    refill();
     uint64_t kth = GH_KEY_INF;
     for (int r = 0; r < K; ++r) {
         uint64_t m = mine;
@@ -126,19 +162,29 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
         const uint64_t g = f64_min_u64(f64_min_u64(wmin[0], wmin[1]), f64_min_u64(wmin[2], wmin[3]));
         kth = g;
         if (g == GH_KEY_INF) break;
-        if (mine == g) { taken = g; have_taken = true; refill(); }   // keys are unique (the id is part of them)
+        if (mine == g) {   // keys are unique (the id is part of them)
+            taken = g;
+            ++given;
+            if (given < F64_BEST) {
+                uint64_t nx = best[1];
+#pragma unroll
+                for (int i = 2; i < F64_BEST; ++i) nx = given == i ? best[i] : nx;
+                mine = nx;
+            } else {
+                refill();
+            }
+        }
     }
     if (threadIdx.x == 0) thr = kth;
     __syncthreads();
     // pass 2: every edge whose rounded distance is <= that of the K-th key, with its double distance
     const uint32_t vmax = (uint32_t)(thr >> 32);
-    for (int64_t e = threadIdx.x; e < E; e += 256) {
-        const double d2 = dist2(e);
+    scan([&](int64_t e, double d2) {
         if (__float_as_uint(f64_round_down(d2)) <= vmax) {
             const int p = atomicAdd(&pool_n, 1);
             if (p < F64_POOL) { pool_d[p] = d2; pool_i[p] = (int32_t)e; }
         }
-    }
+    });
     __syncthreads();
     const int m = min(pool_n, F64_POOL);
     if (pool_n > F64_POOL && threadIdx.x == 0) *fail = 1;
