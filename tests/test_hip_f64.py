@@ -82,3 +82,33 @@ def test_float64_trajectory_and_public_api():
         eng.lib  # noqa: B018
         _native.Engine(n, D, g["edges"], 1.0, 0.2, 0.5, k, S, dtype="float64", partition=(0, n // 2, 0, 0, 1))
     eng.close()
+
+
+@pytest.mark.gpu
+def test_float64_search_against_numpy_with_one_stripe_holding_the_best():
+    """The float64 search keeps the four smallest keys of a thread's stripe (ids = threadIdx.x mod 256) from one scan and
+    rescans the stripe when more of the K best sit in it (csrc/f64.hip f64_knn_kernel).  A perfect matching makes every
+    midpoint free to place: here the 16 midpoints nearest the query all have ids = 7 mod 256 -- one thread hands over every
+    neighbour -- and a second query sees random midpoints; both rows against a float64 brute force in numpy (ties on the
+    smaller id; column 0 dropped, pt.py:421)."""
+    from graphem_rapids_amd import _native
+    rng = np.random.default_rng(5)
+    E, D, k = 4096, 3, 12
+    n = 2 * E
+    edges = np.stack([np.arange(0, n, 2), np.arange(1, n, 2)], axis=1).astype(np.int32)
+    mid = rng.standard_normal((E, D)) * 3.0 + 10.0
+    mid[0] = 0.0                                            # query A at the origin
+    for j in range(16):
+        mid[7 + 256 * j] = np.array([0.01 * (j + 1), 0.0, 0.0])
+    mid[100] = mid[200]                                     # a tie for query B's list to order by id
+    pos = np.repeat(mid, 2, axis=0)                         # both endpoints on the midpoint
+    eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, 2, dtype="float64")
+    eng.set_positions(pos)
+    sampled = np.array([0, 150], dtype=np.int32)
+    knn = eng.knn_midpoints(sampled)
+    for row, q in zip(knn, sampled):
+        d2 = ((mid - mid[q]) ** 2).sum(axis=1)              # (fma chain vs numpy's sum: equal here up to the last bit; the
+        order = np.lexsort((np.arange(E), d2))              #  rows below are separated by far more)
+        assert np.array_equal(row, order[1:k + 1]), (q, row, order[1:k + 1])
+    assert list(knn[0]) == [7 + 256 * j for j in range(12)]
+    eng.close()
