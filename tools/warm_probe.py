@@ -1,5 +1,8 @@
+"""The device's power state against the layout's: 20-step passes of rr1m from a fresh process, back to back, after 3 s of
+idle on the same layout, and on the early layout with a busy device (what bench.py's spin-up phase is for).
+python tools/warm_probe.py"""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench
 from graphem_rapids_amd import _native
 n, D, k, S, edges, pos = bench.make_workload("rr1m")
