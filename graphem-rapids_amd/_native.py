@@ -28,6 +28,7 @@ SYMBOLS = [
     "gh_knn_cdist_stats", "gh_rank_layout", "gh_step_finish_own", "gh_comm_available", "gh_selftest_arith",
     "gh_create_f64", "gh_set_positions_f64", "gh_get_positions_f64", "gh_positions_device_f64", "gh_spring_forces_f64",
     "gh_intersection_forces_f64", "gh_trlan_sweep", "gh_knn_ivf_config", "gh_knn_ivf_list_sizes",
+    "gh_torch_randperm_prefix", "gh_torch_randperm_isa", "gh_run_torch_sampled",
 ]
 
 
@@ -84,6 +85,12 @@ def load():
     L.gh_row_stride.restype = i32
     L.gh_run.argtypes = [vp, i32, vp]
     L.gh_run.restype = ctypes.c_int
+    L.gh_torch_randperm_prefix.argtypes = [vp, i64, i64, i64, i32, vp]
+    L.gh_torch_randperm_prefix.restype = ctypes.c_int
+    L.gh_torch_randperm_isa.argtypes = []
+    L.gh_torch_randperm_isa.restype = ctypes.c_char_p
+    L.gh_run_torch_sampled.argtypes = [vp, i32, vp, i64]
+    L.gh_run_torch_sampled.restype = ctypes.c_int
     L.gh_radial_topk.argtypes = [vp, i32, vp]
     L.gh_radial_topk.restype = ctypes.c_int
     L.gh_vertex_order.argtypes = [vp, vp]
@@ -295,6 +302,12 @@ class Engine:
                 raise ValueError(f"sample_stream must have shape {(iters, self.S)}, got {ss.shape}")
         self._chk(self.lib.gh_run(self.handle, int(iters), ptr(ss)))
 
+    def run_torch_sampled(self, iters, rng_state):
+        """gh_run_torch_sampled: rng_state = uint8 array of torch.get_rng_state() (5056 bytes), updated in place."""
+        if rng_state.dtype != np.uint8 or not rng_state.flags.c_contiguous or not rng_state.flags.writeable:
+            raise ValueError("rng_state must be a writable contiguous uint8 array")
+        self._chk(self.lib.gh_run_torch_sampled(self.handle, int(iters), ptr(rng_state), rng_state.size))
+
     def sync(self):
         self._chk(self.lib.gh_sync(self.handle))
 
@@ -486,6 +499,22 @@ def knn_points(query, reference, k, device_id=0):
                               query.shape[1], int(k), ptr(out))
     raise_for(st, None)
     return out
+
+
+def torch_randperm_prefix(rng_state, n, S, iters=1):
+    """(iters, S) int32 = `iters` successive torch.randperm(n)[:S] of the CPU generator state in `rng_state` (uint8 array
+    of torch.get_rng_state(), 5056 bytes), which is moved on in place exactly as those calls would (pure host code)."""
+    if rng_state.dtype != np.uint8 or not rng_state.flags.c_contiguous or not rng_state.flags.writeable:
+        raise ValueError("rng_state must be a writable contiguous uint8 array")
+    out = np.empty((int(iters), int(S)), dtype=np.int32)
+    st = load().gh_torch_randperm_prefix(ptr(rng_state), rng_state.size, int(n), int(S), int(iters), ptr(out))
+    if st != GH_OK:
+        raise ValueError("gh_torch_randperm_prefix: not a torch CPU generator state, or sizes out of range")
+    return out
+
+
+def torch_randperm_isa():
+    return load().gh_torch_randperm_isa().decode()
 
 
 def comm_unique_id():

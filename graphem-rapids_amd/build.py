@@ -12,7 +12,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp"))]
     srcs.append(os.path.join(HERE, "..", "include", "graphem_hip.h"))
     return any(os.path.getmtime(s) > t for s in srcs)
 

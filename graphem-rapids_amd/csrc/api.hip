@@ -3,8 +3,13 @@
 #include "common.h"
 #include "engine.h"
 
+#include "torch_randperm.h"
+
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 
@@ -91,6 +96,9 @@ static void free_all(gh_engine *h) {
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
+    if (h->h_ring) (void)hipHostFree(h->h_ring);
+    for (hipEvent_t e : h->ring_ev)
+        if (e) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
 }
 
@@ -815,6 +823,133 @@ extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_st
         else GH_TRY(step_finish(h, use_stream ? -1 : 1));  // after the last id row: nothing to prepare
     }
     h->d_sampled_cur = h->d_sampled;
+    return GH_OK;
+}
+
+// ---- the reference's own sampler, drawn beside the loop (pt.py:403-413) ---------------------------------------------
+extern "C" gh_status gh_torch_randperm_prefix(uint8_t *rng_state, int64_t state_bytes, int64_t n, int64_t S, int32_t iters,
+                                              int32_t *ids) {
+    if (!rng_state || state_bytes != GH_TORCH_RNG_STATE_BYTES || n < 0 || n >= ((int64_t)1 << 31) || S < 0 || S > n || iters < 0 ||
+        (!ids && iters > 0 && S > 0))
+        return GH_ERR_INVALID;
+    gh_mt19937 mt;
+    if (!gh_mt_load(&mt, rng_state)) return GH_ERR_INVALID;
+    std::vector<int64_t> scratch((size_t)gh_rp_scratch_words(S));
+    for (int32_t t = 0; t < iters; ++t) gh_torch_randperm_prefix_one(&mt, n, S, ids + (size_t)t * (size_t)S, scratch.data());
+    gh_mt_store(&mt, rng_state);
+    return GH_OK;
+}
+extern "C" const char *gh_torch_randperm_isa(void) { return gh_mt_isa(); }
+
+// iters iterations whose sample ids are torch.randperm(E)[:S] of the generator state handed in -- what run_layout of the
+// reference's CPU backend consumes (one randperm per iteration, pt.py:409) -- drawn by a host thread GH_RING_CHUNK
+// iterations at a time while this thread enqueues the iterations of the chunk before; a chunk's ids go up in one copy on the
+// engine's stream, ahead of the last iteration of the chunk before (whose normalise launch sets the first query records
+// up).  No host synchronisation with the stream except where the producer needs a pinned slot back (four chunks later).
+extern "C" gh_status gh_run_torch_sampled(gh_handle h, int32_t iters, uint8_t *rng_state, int64_t state_bytes) {
+    GH_TRY(check_handle(h));
+    if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
+    if (!rng_state || state_bytes != GH_TORCH_RNG_STATE_BYTES) { h->err = "rng_state must be the 5056 bytes of torch.get_rng_state()"; return GH_ERR_INVALID; }
+    if (iters == 0) return GH_OK;
+    if (h->S >= h->E) return gh_run(h, iters, nullptr);   // arange(E): no randomness consumed (pt.py:412)
+    gh_mt19937 mt;
+    if (!gh_mt_load(&mt, rng_state)) { h->err = "rng_state is not a torch CPU generator state (mt19937, legacy layout)"; return GH_ERR_INVALID; }
+    const size_t S = (size_t)h->S;
+    if (h->f64) {   // (the float64 engine takes host ids step by step: drawn up front)
+        std::vector<int32_t> ids((size_t)iters * S);
+        std::vector<int64_t> scratch((size_t)gh_rp_scratch_words(h->S));
+        for (int32_t t = 0; t < iters; ++t) gh_torch_randperm_prefix_one(&mt, h->E, h->S, ids.data() + (size_t)t * S, scratch.data());
+        GH_TRY(gh_f64_run(h, iters, ids.data()));
+        gh_mt_store(&mt, rng_state);
+        return GH_OK;
+    }
+    GH_TRY(check_whole(h, "gh_run_torch_sampled"));
+    GH_TRY(check_k(h));
+    const size_t ring_words = (size_t)GH_RING_SLOTS * GH_RING_CHUNK * S;
+    if (h->ring_cap < ring_words) {
+        GH_HIP(hipStreamSynchronize(h->stream));
+        if (h->h_ring) { (void)hipHostFree(h->h_ring); h->h_ring = nullptr; h->ring_cap = 0; }
+        GH_HIP(hipHostMalloc(reinterpret_cast<void **>(&h->h_ring), ring_words * sizeof(int32_t), hipHostMallocDefault));
+        h->ring_cap = ring_words;
+        for (hipEvent_t &e : h->ring_ev)
+            if (!e) GH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (ring_words > h->stream_ids_cap) {
+        if (h->d_stream_ids) { GH_HIP(hipStreamSynchronize(h->stream)); GH_HIP(hipFree(h->d_stream_ids)); h->d_stream_ids = nullptr; h->stream_ids_cap = 0; }
+        GH_TRY(dev_alloc(h, &h->d_stream_ids, ring_words, false));
+        h->stream_ids_cap = ring_words;
+    }
+    const int32_t nchunks = (iters + GH_RING_CHUNK - 1) / GH_RING_CHUNK;
+    auto chunk_len = [&](int32_t c) { return std::min<int32_t>(GH_RING_CHUNK, iters - c * GH_RING_CHUNK); };
+
+    std::mutex mu;
+    std::condition_variable cv;
+    int32_t drawn = 0;      // chunks whose ids are in the ring (producer -> this thread)
+    int32_t uploaded = 0;   // chunks whose upload has been enqueued and its event recorded (this thread -> producer)
+    bool stop = false;
+    const int dev = h->device;
+    std::thread producer([&]() {
+        (void)hipSetDevice(dev);
+        std::vector<int64_t> scratch((size_t)gh_rp_scratch_words(h->S));
+        for (int32_t c = 0; c < nchunks; ++c) {
+            const int slot = c % GH_RING_SLOTS;
+            if (c >= GH_RING_SLOTS) {   // the slot's previous occupant (chunk c - GH_RING_SLOTS) must have gone up
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || uploaded > c - GH_RING_SLOTS; });
+                if (stop) return;
+                lk.unlock();
+                (void)hipEventSynchronize(h->ring_ev[slot]);
+            }
+            int32_t *dst = h->h_ring + (size_t)slot * GH_RING_CHUNK * S;
+            for (int32_t t = 0; t < chunk_len(c); ++t) gh_torch_randperm_prefix_one(&mt, h->E, h->S, dst + (size_t)t * S, scratch.data());
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                drawn = c + 1;
+                if (stop) return;
+            }
+            cv.notify_all();
+        }
+    });
+    auto upload = [&](int32_t c) -> gh_status {   // waits for the producer, then one copy on the engine's stream
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return drawn > c; });
+        }
+        const int slot = c % GH_RING_SLOTS;
+        const size_t off = (size_t)slot * GH_RING_CHUNK * S;
+        GH_HIP(hipMemcpyAsync(h->d_stream_ids + off, h->h_ring + off, sizeof(int32_t) * (size_t)chunk_len(c) * S, hipMemcpyHostToDevice, h->stream));
+        GH_HIP(hipEventRecord(h->ring_ev[slot], h->stream));
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            uploaded = c + 1;
+        }
+        cv.notify_all();
+        return GH_OK;
+    };
+    auto row = [&](int32_t t) { return h->d_stream_ids + ((size_t)((t / GH_RING_CHUNK) % GH_RING_SLOTS) * GH_RING_CHUNK + (size_t)(t % GH_RING_CHUNK)) * S; };
+    auto loop = [&]() -> gh_status {
+        GH_TRY(upload(0));
+        for (int32_t t = 0; t < iters; ++t) {
+            const int32_t c = t / GH_RING_CHUNK;
+            if (t + 1 < iters && (t + 1) / GH_RING_CHUNK != c) GH_TRY(upload(c + 1));   // before this iteration's normalise launch reads the next ids
+            GH_TRY(set_sample(h, nullptr, row(t)));
+            GH_TRY(step_begin(h, true));
+            GH_TRY(step_merge(h, h->d_partial, 1));
+            if (t + 1 < iters) GH_TRY(step_finish(h, 0, row(t + 1)));
+            else GH_TRY(step_finish(h, -1));
+        }
+        return GH_OK;
+    };
+    const gh_status st = loop();
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = st != GH_OK;
+    }
+    cv.notify_all();
+    producer.join();
+    h->d_sampled_cur = h->d_sampled;
+    if (st != GH_OK) return st;
+    gh_mt_store(&mt, rng_state);
     return GH_OK;
 }
 

@@ -100,6 +100,13 @@ struct gh_engine {
     int32_t *d_sampled_cur = nullptr; // ids of the current iteration (d_sampled or a row of d_stream_ids)
     int32_t *d_stream_ids = nullptr;  // (iters, S) uploaded sample stream of gh_run
     size_t stream_ids_cap = 0;
+    // gh_run_torch_sampled (api.hip): pinned host ring the producer thread draws torch.randperm's prefixes into, one event
+    // per slot (recorded behind the slot's upload: the producer may overwrite the slot once it has fired)
+#define GH_RING_SLOTS 4
+#define GH_RING_CHUNK 32   /* iterations per slot */
+    int32_t *h_ring = nullptr;
+    size_t ring_cap = 0;              // int32 words allocated in h_ring (GH_RING_SLOTS * GH_RING_CHUNK * S)
+    hipEvent_t ring_ev[GH_RING_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
     bool new0_ready = false;      // the fused kernel of this step wrote d_new = pos + Fs and its block sums
     bool intersect_done = false;  // the KNN kernels of this step already ran the intersection phase
     bool stats_reduced = false;   // ... and reduced the fused kernel's workgroup sums into d_stats (knn_select_kernel)

@@ -272,13 +272,33 @@ class GraphEmbedderHIP:
         return self.positions
 
     # ---- the loop (pt.py:776-833) -------------------------------------------------------
+    def _torch_rng_state(self):
+        """The global CPU generator's state as a writable uint8 array when it is the 5056-byte mt19937 blob
+        gh_torch_randperm_prefix understands, else None (the caller then asks torch.randperm itself)."""
+        st = torch.get_rng_state()
+        if st.dtype != torch.uint8 or st.numel() != 5056:
+            return None
+        return st.numpy().copy()
+
     def _draw_samples(self, iterations):
         """Sample ids for `iterations` iterations, consuming the global torch CPU generator
-        exactly as pt.py:409 does (one randperm(E) per iteration; none when S >= E)."""
+        exactly as pt.py:409 does (one randperm(E) per iteration; none when S >= E).  The ids are
+        torch.randperm(E)[:S]; only the S entries asked for are materialised (ATen's CPU randperm is a forward
+        Fisher-Yates: gh_torch_randperm_prefix, include/graphem_hip.h), and the generator is left in the state
+        `iterations` calls of torch.randperm(E) leave it in."""
         E, S = self.n_edges, self.sample_size
         if S >= E or self.sampler == "device":
             return None
-        out = np.empty((iterations, S), dtype=np.int32)
+        state = self._torch_rng_state()
+        if state is not None:
+            try:
+                out = _native.torch_randperm_prefix(state, E, S, iterations)
+            except ValueError:
+                state = None
+            else:
+                torch.set_rng_state(torch.from_numpy(state))
+                return out
+        out = np.empty((iterations, S), dtype=np.int32)   # a generator this build does not know: ask torch (ms per draw)
         for t in range(iterations):
             out[t] = torch.randperm(E)[:S].numpy()
         return out
@@ -289,11 +309,24 @@ class GraphEmbedderHIP:
         self._engine.step(None if ids is None else ids[0])
 
     def run_layout(self, num_iterations=100):
-        """num_iterations iterations without host synchronisation; returns (n, D) numpy (pt.py:808-833)."""
+        """num_iterations iterations without host synchronisation; returns (n, D) numpy (pt.py:808-833).
+        sampler='torch': the ids are drawn by a host thread of the library while the GPU runs the iterations before
+        (gh_run_torch_sampled); the global CPU generator ends where the reference's loop would leave it."""
         if self.verbose:
             self.logger.info("Running layout for %d iterations", num_iterations)
         if num_iterations > 0:
-            self._engine.run(num_iterations, self._draw_samples(num_iterations))
+            state = self._torch_rng_state() if (self.sampler == "torch" and self.sample_size < self.n_edges) else None
+            if state is not None:
+                try:
+                    self._engine.run_torch_sampled(num_iterations, state)
+                except ValueError as exc:
+                    if "rng_state" not in str(exc):
+                        raise
+                    state = None
+                else:
+                    torch.set_rng_state(torch.from_numpy(state))
+            if state is None:
+                self._engine.run(num_iterations, self._draw_samples(num_iterations))
         return self.positions
 
     # ---- per-phase access (used by the parity tests; same names as pt.py) ------------------

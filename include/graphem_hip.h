@@ -192,6 +192,21 @@ gh_status gh_step(gh_handle h, const int32_t *sampled);
 /* iters iterations without host synchronisation.  sample_stream: (iters, S) host ids
  * or NULL for the device sampler. */
 gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_stream);
+/* The reference's own sampler beside the loop (pt.py:403-413: `torch.randperm(n_edges)[:sample_size]` on the global CPU
+ * generator, once per iteration).  ATen's CPU randperm is a forward Fisher-Yates over an mt19937 (z = random() % (n - i);
+ * swap(r[i], r[i + z])): entries [:S] are final after S draws, the other n - 1 - S draws only move the generator on.
+ *   gh_torch_randperm_prefix  pure host code, no GPU: rng_state = the 5056 bytes of torch.get_rng_state() (in / out);
+ *                             writes `iters` rows of S ids = what `iters` calls of torch.randperm(n)[:S] return, and
+ *                             leaves in rng_state the state those calls leave (hand it to torch.set_rng_state).
+ *                             O(S) swaps per row in a small table + an AVX2 / AVX-512 twist over the skipped words
+ *                             (gh_torch_randperm_isa names the one chosen on this host).
+ *   gh_run_torch_sampled      gh_run with those ids: a host thread draws them 32 iterations ahead into a pinned ring
+ *                             while the calling thread enqueues; rng_state in / out as above (written on success only).
+ *                             S >= E consumes nothing, like pt.py:412.  Whole-graph engines (float32 or float64). */
+gh_status gh_torch_randperm_prefix(uint8_t *rng_state, int64_t state_bytes, int64_t n, int64_t sample_size, int32_t iters,
+                                   int32_t *ids /* (iters, sample_size) host */);
+const char *gh_torch_randperm_isa(void);
+gh_status gh_run_torch_sampled(gh_handle h, int32_t iters, uint8_t *rng_state, int64_t state_bytes);
 /* Blocks until everything enqueued on h has finished. */
 gh_status gh_sync(gh_handle h);
 

@@ -344,3 +344,96 @@ def test_lean_sqrt_and_division_are_ieee():
     for seed in (1, 2):
         bad_sqrt, bad_div = _native.selftest_arith(1 << 31, seed=seed)
         assert (bad_sqrt, bad_div) == (0, 0)
+
+
+@pytest.mark.parametrize("iters", [1, 31, 32, 33, 64, 65, 130, 300])
+def test_run_torch_sampled_equals_run_over_torch_randperm(iters):
+    """gh_run_torch_sampled (ids drawn by the library's host thread from torch's mt19937 state, 32 iterations per ring
+    slot, 4 slots) == gh_run over torch.randperm(E)[:S] drawn by torch itself: positions bit for bit, generator state
+    identical afterwards -- across every ring-slot boundary and after the ring has wrapped (pt.py:409, 808-833)."""
+    import torch
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    n, D, k, S = 30000, 3, 10, 256
+    edges = gra.random_regular_edges(n, 8, seed=2).astype(np.int32)
+    E = len(edges)
+    pos = (np.random.default_rng(1).standard_normal((n, D)) * 0.1).astype(np.float32)
+    a = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_distance="cdist")
+    b = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, knn_distance="cdist")
+    a.set_positions(pos)
+    b.set_positions(pos)
+    torch.manual_seed(77)
+    torch.rand(11)
+    state = torch.get_rng_state().numpy().copy()
+    ids = np.stack([torch.randperm(E)[:S].numpy() for _ in range(iters)]).astype(np.int32)
+    a.run(iters, ids)
+    b.run_torch_sampled(iters, state)
+    assert np.array_equal(state, torch.get_rng_state().numpy())
+    assert np.array_equal(a.get_positions(), b.get_positions())
+    # a second call continues from the state it left (and reuses the ring)
+    ids2 = np.stack([torch.randperm(E)[:S].numpy() for _ in range(5)]).astype(np.int32)
+    a.run(5, ids2)
+    b.run_torch_sampled(5, state)
+    assert np.array_equal(state, torch.get_rng_state().numpy())
+    assert np.array_equal(a.get_positions(), b.get_positions())
+    a.close()
+    b.close()
+
+
+def test_run_torch_sampled_small_graph_f64_and_no_draw_cases():
+    import torch
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    # (1) a graph below the fused path's size (the per-phase kernels), float32 and float64 engines
+    n, D, k, S = 300, 2, 5, 64
+    edges = gra.random_regular_edges(n, 4, seed=3).astype(np.int32)
+    E = len(edges)
+    pos = (np.random.default_rng(2).standard_normal((n, D)) * 0.1)
+    for dtype in ("float32", "float64"):
+        a = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, dtype=dtype)
+        b = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, dtype=dtype)
+        a.set_positions(pos)
+        b.set_positions(pos)
+        torch.manual_seed(3)
+        state = torch.get_rng_state().numpy().copy()
+        ids = np.stack([torch.randperm(E)[:S].numpy() for _ in range(40)]).astype(np.int32)
+        a.run(40, ids)
+        b.run_torch_sampled(40, state)
+        assert np.array_equal(state, torch.get_rng_state().numpy())
+        assert np.array_equal(a.get_positions(), b.get_positions())
+        a.close()
+        b.close()
+    # (2) S >= E: the reference uses arange(E) and draws nothing (pt.py:412): the state stays as it was
+    c = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, E + 5)
+    c.set_positions(pos)
+    state = torch.get_rng_state().numpy().copy()
+    before = state.copy()
+    c.run_torch_sampled(3, state)
+    assert np.array_equal(state, before)
+    # (3) not a generator state: ValueError, nothing ran
+    d = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S)
+    d.set_positions(pos)
+    with pytest.raises(ValueError):
+        d.run_torch_sampled(3, np.zeros(5056, dtype=np.uint8))
+    assert np.array_equal(d.get_positions(), pos.astype(np.float32))
+    c.close()
+    d.close()
+
+
+def test_public_run_layout_draws_like_the_reference_loop():
+    """run_layout(sampler='torch') leaves torch's global generator where `iters` torch.randperm(E) calls leave it and
+    gives the positions of the same run with the ids drawn by torch.randperm (pt.py:409)."""
+    import torch
+    import graphem_rapids_amd as gra
+    adj = gra.generate_random_regular(20000, 8, seed=4)
+    a = gra.create_graphem(adj, n_components=3, verbose=False, seed=11, init="random", sampler="torch")
+    b = gra.create_graphem(adj, n_components=3, verbose=False, seed=11, init="random", sampler="torch")
+    E, S = a.n_edges, a.sample_size
+    torch.manual_seed(9)
+    out = a.run_layout(70)
+    after = torch.get_rng_state().clone()
+    torch.manual_seed(9)
+    ids = np.stack([torch.randperm(E)[:S].numpy() for _ in range(70)]).astype(np.int32)
+    assert torch.equal(after, torch.get_rng_state())
+    b._engine.run(70, ids)
+    assert np.array_equal(out, b.get_positions())
