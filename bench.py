@@ -82,11 +82,12 @@ def pmc_traffic(workload, kernel):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "final", f"traffic_{workload}.json")))
     if not files:
-        return None, None
+        return None
     rec = json.load(open(files[-1]))
     if rec.get("kernel") != kernel:
-        return None, None
-    return rec["traffic_bytes"], os.path.relpath(files[-1], ROOT)
+        return None
+    rec["file"] = os.path.relpath(files[-1], ROOT)
+    return rec
 
 
 def cpu_baseline(n, D, k, S, edges, pos, budget_s=24.0):
@@ -139,6 +140,59 @@ def cpu_baseline(n, D, k, S, edges, pos, budget_s=24.0):
             "torch_cpu": legs["torch_cpu"]}
 
 
+def fused_roofline(kern, E_rank, n_rank, D, workload, world):
+    """(roofline, roofline_knn_fp32_equivalent) of the dominant kernel from its HIP-event duration.  SURVEY 8d, the parts
+    of B_iter the fused spring+scan kernel performs: spring (edge list, read pos, zero F, write F), KNN midpoints (edge
+    list, read pos) and the un-normalised update (read pos, read F, write new) = 16 E + 7 * (n D 4) bytes per launch."""
+    dom = "spring_scan" if "spring_scan" in kern else "spring_mid" if "spring_mid" in kern else "knn_scan"
+    scan_us = kern.get(dom, {}).get("avg_us")
+    if not scan_us:
+        return None, None
+    b_alg = 16.0 * E_rank + 28.0 * n_rank * D if dom == "spring_scan" else 8.0 * E_rank + 4.0 * n_rank * D
+    ach = b_alg / (scan_us * 1e-6)
+    roofline = {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": ach / HBM_PEAK, "traffic": None, "avg_launch_us": scan_us,
+                "algorithmic_bytes_per_launch": b_alg,
+                "random_row_fetches_per_launch": 2.0 * E_rank,
+                "row_fetch_rate_G_per_s": 2.0 * E_rank / (scan_us * 1e-6) / 1e9,
+                "row_fetch_ceiling_G_per_s": 73.9,  # tools/micro/gather_bench.hip: 8M random 16-B rows of a 16 MB table in 108 us
+                }
+    if world == 1 and workload:
+        rec = pmc_traffic(workload, dom)
+        if rec:
+            tb = rec["traffic_bytes"]
+            roofline["traffic"] = tb
+            roofline["traffic_source"] = rec["file"]
+            roofline["traffic_measured_at_commit"] = rec.get("commit")
+            roofline["traffic_note"] = ("PMC counters (FETCH_SIZE, WRITE_SIZE; separate rocprofv3 --pmc passes, read side doubled per "
+                                        "the guide's gfx950 note) of this kernel in the committed profile named in traffic_source -- "
+                                        "bench.py cannot profile itself, so NOT measured in this run")
+            if tb:
+                roofline["traffic_rate_GBps"] = tb / (scan_us * 1e-6) / 1e9
+                roofline["traffic_frac_of_peak"] = tb / (scan_us * 1e-6) / HBM_PEAK
+    # the same kernel's arithmetic side (SURVEY 8d: F_knn = 3 D S E per launch) as an fp32-EQUIVALENT rate: the
+    # algorithm's fp32 flops over the kernel's duration against the fp32 vector peak.  NOT a pipe utilisation: the
+    # pre-filter runs on the f16 matrix pipe (split-f16 operands) and spends far fewer instructions per pair.
+    return roofline, scan_us
+
+
+def iter_roofline(ms, E, n, D):
+    b_iter = 16.0 * E + 36.0 * n * D                       # SURVEY 8d: B_iter = 16E + 36nD
+    return {"bound": "hbm", "achieved": b_iter / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": b_iter / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_iter": b_iter, "traffic": None}
+
+
+def cold_pass(run, sync, args):
+    """ms per step of the FIRST W + K steps this process runs on the engine, before spin_up: what a caller sees on a device
+    that idled while the host built the graph (clock ramp; one-off launches of the first iteration are in the W steps)."""
+    run(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    run(args.steps)
+    sync()
+    return 1e3 * (time.perf_counter() - t0) / args.steps
+
+
 def parity_mode(args, n, D, k, S, edges, pos, device_id):
     """The same K steps on an engine in the mode whose neighbour rows ARE the reference's (knn_distance='cdist': torch.cdist's
     values, torch.topk's tie order, pt.py:580-583; ids drawn on the host like torch.randperm's, before the timed region):
@@ -150,6 +204,8 @@ def parity_mode(args, n, D, k, S, edges, pos, device_id):
     rng = np.random.default_rng(3)
     stream = np.stack([rng.permutation(E)[:S] for _ in range(max(args.steps, args.warmup))]).astype(np.int32) if S < E else None
     run = lambda iters: eng.run(iters, None if stream is None else stream[:iters])
+    cold_ms = cold_pass(run, eng.sync, args)
+    eng.set_positions(pos)
     spin_up(run, eng.sync, max(1, args.steps), lambda: eng.set_positions(pos))
     run(args.warmup)
     passes = []
@@ -171,11 +227,74 @@ def parity_mode(args, n, D, k, S, edges, pos, device_id):
         eng.step(None if stream is None else stream[0])
         listed.append(int(eng.knn_cdist_stats()[0]))
     eng.close()
-    return {"knn_distance": "cdist", "sampler": "host", "value": args.steps / dt, "unit": "iterations/s",
-            "ms_per_step": 1e3 * dt / args.steps, "ms_per_step_passes": [1e3 * p / args.steps for p in passes],
+    kern = {name: {"avg_us": 1e3 * tot / cnt, "launches_per_step": cnt / args.steps}
+            for name, (tot, cnt) in sorted(timings.items(), key=lambda kv: -kv[1][0])}
+    ms = 1e3 * dt / args.steps
+    return {"knn_distance": "cdist", "sampler": "host", "reference_identical": True,
+            "what": "neighbour rows = the reference's torch.cdist + torch.topk rows id for id (pt.py:580-583); ids handed in like torch.randperm's",
+            "value": args.steps / dt, "unit": "iterations/s",
+            "ms_per_step": ms, "ms_per_step_passes": [1e3 * p / args.steps for p in passes],
+            "ms_per_step_cold": cold_ms,
             "replayed_rows_per_step_sample": listed,
-            "kernels": {name: {"avg_us": 1e3 * tot / cnt, "launches_per_step": cnt / args.steps}
-                        for name, (tot, cnt) in sorted(timings.items(), key=lambda kv: -kv[1][0])}}
+            "roofline": fused_roofline(kern, E, n, D, None, None)[0],
+            "roofline_iter_hbm": iter_roofline(ms, E, n, D),
+            "kernels": kern}
+
+
+def public_api(args, device_id):
+    """The seam the north star names, timed the way the reference times itself (graphem_rapids/benchmark.py:131-133: wall
+    clock around run_layout): create_graphem(adjacency, D, backend='hip', init='random', ...).run_layout(K), INCLUDING the
+    final download of the positions, after one untimed run_layout(W) -- on BASELINE configs[1] (rr100k) and on the bench
+    workload, with sampler='torch' (the parity default up to 2**20 edges: ids = torch.randperm(E)[:S] of the global CPU
+    generator, knn_distance='cdist') and sampler='device' (the speed mode).  `torch_randperm_ms` = what ONE
+    torch.randperm(E) call costs on this host: the per-iteration host work of this path until round 4."""
+    import torch
+    import graphem_rapids_amd as gra
+    from graphem_rapids_amd import _native
+    K = max(args.steps, 100)   # run_layout's own default length (pt.py:808) unless more steps were asked for
+    out = {"protocol": f"wall clock around run_layout({K}) incl. the download of the positions; run_layout({args.warmup}) before, untimed; "
+                       "median of 3", "steps": K, "host_twist": _native.torch_randperm_isa(), "cases": {}}
+    for wl in dict.fromkeys(["rr100k", args.workload]):
+        n, D, k, S, edges, pos = make_workload(wl)
+        adj = gra.edges_to_adjacency(n, edges)
+        E = len(edges)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            torch.randperm(E)
+        rp_ms = 1e3 * (time.perf_counter() - t0) / 3
+        st = torch.get_rng_state().numpy().copy()
+        t0 = time.perf_counter()
+        _native.torch_randperm_prefix(st, E, S, 20)
+        draw_us = 1e6 * (time.perf_counter() - t0) / 20
+        rec = {"n_vertices": n, "n_edges": E, "torch_randperm_ms": rp_ms, "host_draw_us_per_iteration": draw_us}
+        for sampler in ("torch", "device"):
+            t0 = time.perf_counter()
+            emb = gra.create_graphem(adj, n_components=D, backend="hip", init="random", n_neighbors=k, sample_size=S,
+                                     sampler=sampler, verbose=False, seed=0, device=f"cuda:{device_id}")
+            t_create = time.perf_counter() - t0
+            emb.positions = pos
+            emb.run_layout(max(1, args.warmup))
+            spin_up(emb.run_layout, emb._engine.sync, 20, lambda: setattr(emb, "positions", pos))
+            walls = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                res = emb.run_layout(K)
+                walls.append(time.perf_counter() - t0)
+            assert res.shape == (n, D) and np.isfinite(res).all()
+            t0 = time.perf_counter()
+            emb.get_positions()
+            t_dl = time.perf_counter() - t0
+            w = sorted(walls)[1]
+            host = None
+            if sampler == "torch":
+                st = emb._engine.sampler_stats()
+                host = {k: float(v) for k, v in st.items()}
+            rec[sampler] = {"host_sampler_ms_last_run": host, "knn_distance": emb.knn_distance, "reference_identical": emb.knn_distance == "cdist" and sampler == "torch",
+                            "wall_ms": 1e3 * w, "ms_per_iteration": 1e3 * w / K, "iterations_per_s": K / w,
+                            "wall_ms_passes": [1e3 * x for x in walls], "download_ms": 1e3 * t_dl, "create_s": t_create}
+            del emb
+        out["cases"][wl] = rec
+    return out
 
 
 SPINUP_MS = 150.0
@@ -186,7 +305,9 @@ def spin_up(run, sync, steps, reset, agree=None):
     ~15 ms of kernels at lower clocks (rr1m: 20-step passes of 177, 175, 169, 167, 166 us per iteration after 3 s of idle
     against 164 back to back on a busy device, the SAME layout either way -- tools/warm_probe.py, profiles/r04/final/warm_probe.log).  So the same iterations
     run untimed for SPINUP_MS first, then `reset` puts the starting positions back: the W warm-up steps and the K timed
-    steps that follow are the iterations they would have been without this, on a device in its steady state."""
+    steps that follow start from the layout they would have started from without this, on a device in its steady state
+    (the engine's iteration counter, which keys the device sampler, is not put back: same layout, other sample draws).
+    The pass BEFORE this is reported as `ms_per_step_cold`."""
     # (every rank must run the SAME number of iterations -- they contain collectives: one timed round, the slowest rank's
     # time agreed on, the number of further rounds derived from that)
     run(steps)   # (the first round carries one-off launches: not the one to measure)
@@ -252,6 +373,7 @@ def main():
     ap.add_argument("--sampler", default="device", choices=["device", "host"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the parity_mode sub-record (the same steps with knn_distance='cdist')")
+    ap.add_argument("--no-public-api", action="store_true", help="skip the public_api sub-record (wall clock around create_graphem(...).run_layout(K))")
     ap.add_argument("--sample-size", type=int, default=None, help="override the workload's number of sampled midpoints")
     ap.add_argument("--knn", default="auto", choices=["auto", "scan", "grid", "ivf"],
                     help="KNN search (gh_params.knn_method); ivf is approximate (recall: tools/ivf_probe.py)")
@@ -328,7 +450,10 @@ def main():
         t = torch.tensor([dt_local], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
-    spinup_steps = spin_up(run, sync, max(1, args.steps), (lambda: lay.set_positions(pos)) if use_dist else (lambda: eng.set_positions(pos)), agree)
+    reset = (lambda: lay.set_positions(pos)) if use_dist else (lambda: eng.set_positions(pos))
+    cold_ms = agree(cold_pass(run, sync, args))
+    reset()
+    spinup_steps = spin_up(run, sync, max(1, args.steps), reset, agree)
     run(args.warmup)
     passes = []
     for _ in range(max(1, args.repeats)):   # median of 3 repeats; every pass is exactly --steps iterations
@@ -366,49 +491,31 @@ def main():
         # Dominant kernel: the fused spring+scan kernel (the stand-alone scan when unfused).  It is bound by the
         # memory system: the spring phase gathers one position row per pull-list entry (2E random 16-byte rows),
         # and with no locality in the graph most of them miss the L2 (PMC traffic below).
-        dom = "spring_scan" if "spring_scan" in kern else "spring_mid" if "spring_mid" in kern else "knn_scan"
-        scan_us = kern.get(dom, {}).get("avg_us")
-        roofline = None
+        roofline, scan_us = fused_roofline(kern, E_rank, n_rank, D, args.workload, world)
         knn_fp32 = None
         if scan_us:
-            # SURVEY 8d, the parts of B_iter this kernel performs: spring (edge list, read pos, zero F, write F),
-            # KNN midpoints (edge list, read pos) and the un-normalised update (read pos, read F, write new):
-            # 16 E + 7 * (n D 4) bytes, per rank
-            b_alg = 16.0 * E_rank + 28.0 * n_rank * D if dom == "spring_scan" else 8.0 * E_rank + 4.0 * n_rank * D
-            ach = b_alg / (scan_us * 1e-6)
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK, "traffic": None, "avg_launch_us": scan_us,
-                        "algorithmic_bytes_per_launch": b_alg,
-                        "random_row_fetches_per_launch": 2.0 * E_rank,
-                        "row_fetch_rate_G_per_s": 2.0 * E_rank / (scan_us * 1e-6) / 1e9,
-                        "row_fetch_ceiling_G_per_s": 73.9,  # tools/micro/gather_bench.hip: 8M random 16-B rows of a 16 MB table in 108 us
-                        }
-            if world == 1:
-                tb, src = pmc_traffic(args.workload, dom)
-                roofline["traffic"] = tb
-                roofline["traffic_source"] = src
-                if tb:
-                    roofline["traffic_rate_GBps"] = tb / (scan_us * 1e-6) / 1e9
-                    roofline["traffic_frac_of_peak"] = tb / (scan_us * 1e-6) / HBM_PEAK
-            # the same kernel's arithmetic side (F_knn = 3 D S E per launch) against the fp32 vector
-            # peak (= dense fp32 MFMA peak): the precision the result is exact in; the pre-filter itself runs on the
-            # f16 matrix pipe and spends far fewer instructions per pair than this count
             flops_scan = 3.0 * D * S * E_rank
-            knn_fp32 = {"kernel": dom, "bound": "mfma", "pipe": "pre-filter on v_mfma_f32_32x32x16_f16 with split-f16 operands (D <= 3), packed fp32 VALU otherwise; exact fp32 re-check",
-                        "achieved": flops_scan / (scan_us * 1e-6) / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
+            knn_fp32 = {"kernel": roofline["kernel"], "bound": "mfma", "kind": "fp32-equivalent rate, not pipe utilisation",
+                        "what": "the search's algorithmic fp32 flops (3 D S E per launch) over the kernel's duration against the fp32 vector "
+                                "peak; the work itself is done by a split-f16 pre-filter on v_mfma_f32_32x32x16_f16 (D <= 3; packed fp32 VALU "
+                                "otherwise) plus an exact fp32 re-check of the few pairs that pass, in far fewer instructions per pair",
+                        "achieved": flops_scan / (scan_us * 1e-6) / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s (fp32-equivalent)",
                         "frac": flops_scan / (scan_us * 1e-6) / FP32_PEAK, "algorithmic_flops_per_launch": flops_scan}
-        b_iter = 16.0 * E + 36.0 * n * D                       # B_iter = 16E + 36nD
-        hbm = {"bound": "hbm", "achieved": b_iter / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-               "frac": b_iter / (ms * 1e-3) / HBM_PEAK, "algorithmic_bytes_per_iter": b_iter, "traffic": None}
+        hbm = iter_roofline(ms, E, n, D)
         out = {
             "metric": "layout iterations/s", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup_steps, "ms_per_step": ms,
+            "ms_per_step_cold": cold_ms,
             "repeats": len(passes), "ms_per_step_passes": [1e3 * p / args.steps for p in passes],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "graph": WORKLOADS[args.workload][0], "n_vertices": n,
                        "n_edges": E, "n_components": D, "n_neighbors": k, "sample_size": S,
-                       "sampler": args.sampler, "knn": args.knn, "knn_distance": args.knn_distance, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else "")},
+                       "sampler": args.sampler, "knn": args.knn, "knn_distance": args.knn_distance, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else ""),
+                       # speed mode (knn_distance='exact', device sampler): exact-difference distances, ties on the smaller id --
+                       # 252-256 of 256 neighbour rows equal the reference's at 1 M vertices; the mode whose rows ARE the
+                       # reference's on every vertex is the `parity_mode` record of this line (reference_identical: true)
+                       "reference_identical": args.knn_distance == "cdist" and args.sampler == "host"},
             "roofline": roofline, "roofline_knn_fp32": knn_fp32, "roofline_iter_hbm": hbm, "kernels": kern,
         }
         if use_dist:  # rank 0's split of an iteration (HIP events on the engine's stream, second pass): where a scaling run loses its time
@@ -419,6 +526,8 @@ def main():
                                         if getattr(lay, "native", False) else "python-driven (torch.distributed)"}
         if world == 1 and not use_dist and args.knn_distance == "exact" and not args.no_parity_mode:
             out["parity_mode"] = parity_mode(args, n, D, k, S, edges, pos, local_rank)
+        if world == 1 and not use_dist and not args.no_public_api:
+            out["public_api"] = public_api(args, local_rank)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, D, k, S, edges, pos)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

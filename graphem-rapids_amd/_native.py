@@ -28,7 +28,7 @@ SYMBOLS = [
     "gh_knn_cdist_stats", "gh_rank_layout", "gh_step_finish_own", "gh_comm_available", "gh_selftest_arith",
     "gh_create_f64", "gh_set_positions_f64", "gh_get_positions_f64", "gh_positions_device_f64", "gh_spring_forces_f64",
     "gh_intersection_forces_f64", "gh_trlan_sweep", "gh_knn_ivf_config", "gh_knn_ivf_list_sizes",
-    "gh_torch_randperm_prefix", "gh_torch_randperm_isa", "gh_run_torch_sampled",
+    "gh_torch_randperm_prefix", "gh_torch_randperm_isa", "gh_run_torch_sampled", "gh_set_cdist_replay", "gh_sampler_stats",
 ]
 
 
@@ -171,6 +171,10 @@ def load():
     L.gh_knn_last_counts.restype = ctypes.c_int
     L.gh_knn_cdist_stats.argtypes = [vp, vp, vp]
     L.gh_knn_cdist_stats.restype = ctypes.c_int
+    L.gh_sampler_stats.argtypes = [vp, vp]
+    L.gh_sampler_stats.restype = ctypes.c_int
+    L.gh_set_cdist_replay.argtypes = [vp, i32]
+    L.gh_set_cdist_replay.restype = ctypes.c_int
     L.gh_knn_ivf_config.argtypes = [vp, vp, vp]
     L.gh_knn_ivf_config.restype = ctypes.c_int
     L.gh_knn_ivf_list_sizes.argtypes = [vp, vp, ctypes.c_int32]
@@ -307,6 +311,12 @@ class Engine:
         if rng_state.dtype != np.uint8 or not rng_state.flags.c_contiguous or not rng_state.flags.writeable:
             raise ValueError("rng_state must be a writable contiguous uint8 array")
         self._chk(self.lib.gh_run_torch_sampled(self.handle, int(iters), ptr(rng_state), rng_state.size))
+
+    def sampler_stats(self):
+        """Host ms of the last run_torch_sampled: producer drawing, caller waiting for an upload slot, caller waiting for ids, the call."""
+        out = np.zeros(4, dtype=np.float64)
+        self._chk(self.lib.gh_sampler_stats(self.handle, ptr(out)))
+        return {"draw_ms": out[0], "slot_wait_ms": out[1], "caller_wait_ms": out[2], "call_ms": out[3]}
 
     def sync(self):
         self._chk(self.lib.gh_sync(self.handle))
@@ -458,6 +468,10 @@ class Engine:
         a, b = ctypes.c_int32(0), ctypes.c_int32(0)
         self._chk(self.lib.gh_knn_cdist_stats(self.handle, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def set_cdist_replay(self, all_ties):
+        """The loop of a knn_distance='cdist' engine replays every tie (True) or only those that can change a force (False, default)."""
+        self._chk(self.lib.gh_set_cdist_replay(self.handle, 1 if all_ties else 0))
 
     def knn_ivf_config(self):
         """(lists, probes per query) of a knn_method='ivf' engine; (0, 0) otherwise."""

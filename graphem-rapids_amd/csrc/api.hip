@@ -6,6 +6,7 @@
 #include "torch_randperm.h"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -826,6 +827,14 @@ extern "C" gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_st
     return GH_OK;
 }
 
+extern "C" gh_status gh_set_cdist_replay(gh_handle h, int32_t all_ties) {
+    GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_set_cdist_replay"));
+    if (!h->cdist) { h->err = "gh_set_cdist_replay: not a GH_DIST_CDIST engine"; return GH_ERR_INVALID; }
+    h->cd_all_ties = all_ties != 0;
+    return GH_OK;
+}
+
 // ---- the reference's own sampler, drawn beside the loop (pt.py:403-413) ---------------------------------------------
 extern "C" gh_status gh_torch_randperm_prefix(uint8_t *rng_state, int64_t state_bytes, int64_t n, int64_t S, int32_t iters,
                                               int32_t *ids) {
@@ -842,10 +851,14 @@ extern "C" gh_status gh_torch_randperm_prefix(uint8_t *rng_state, int64_t state_
 extern "C" const char *gh_torch_randperm_isa(void) { return gh_mt_isa(); }
 
 // iters iterations whose sample ids are torch.randperm(E)[:S] of the generator state handed in -- what run_layout of the
-// reference's CPU backend consumes (one randperm per iteration, pt.py:409) -- drawn by a host thread GH_RING_CHUNK
-// iterations at a time while this thread enqueues the iterations of the chunk before; a chunk's ids go up in one copy on the
-// engine's stream, ahead of the last iteration of the chunk before (whose normalise launch sets the first query records
-// up).  No host synchronisation with the stream except where the producer needs a pinned slot back (four chunks later).
+// reference's CPU backend consumes (one randperm per iteration, pt.py:409) -- drawn by a host thread into a circular host
+// buffer while this thread enqueues: before iteration t goes out, the rows drawn so far (at least row t + 1, whose query
+// records the normalise launch of iteration t sets up; at most GH_RING_CHUNK at a time) are copied to a pinned slot and
+// from there, in one copy on the engine's stream, into a device ring of GH_DEV_RING rows.  The GPU starts after ONE draw;
+// when the producer is ahead the uploads are whole slots, when it is the bottleneck they are single rows.  The only host
+// synchronisation with the stream is for a pinned slot to come back (GH_RING_SLOTS uploads later).
+#define GH_DEV_RING 128    /* rows of the device ring: a row is overwritten GH_DEV_RING - GH_RING_CHUNK - 1 iterations after its own at the earliest */
+#define GH_HOST_RING 256   /* rows the producer may be ahead of the uploads */
 extern "C" gh_status gh_run_torch_sampled(gh_handle h, int32_t iters, uint8_t *rng_state, int64_t state_bytes) {
     GH_TRY(check_handle(h));
     if (iters < 0) { h->err = "negative iteration count"; return GH_ERR_INVALID; }
@@ -874,64 +887,80 @@ extern "C" gh_status gh_run_torch_sampled(gh_handle h, int32_t iters, uint8_t *r
         for (hipEvent_t &e : h->ring_ev)
             if (!e) GH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    if (ring_words > h->stream_ids_cap) {
+    if ((size_t)GH_DEV_RING * S > h->stream_ids_cap) {
         if (h->d_stream_ids) { GH_HIP(hipStreamSynchronize(h->stream)); GH_HIP(hipFree(h->d_stream_ids)); h->d_stream_ids = nullptr; h->stream_ids_cap = 0; }
-        GH_TRY(dev_alloc(h, &h->d_stream_ids, ring_words, false));
-        h->stream_ids_cap = ring_words;
+        GH_TRY(dev_alloc(h, &h->d_stream_ids, (size_t)GH_DEV_RING * S, false));
+        h->stream_ids_cap = (size_t)GH_DEV_RING * S;
     }
-    const int32_t nchunks = (iters + GH_RING_CHUNK - 1) / GH_RING_CHUNK;
-    auto chunk_len = [&](int32_t c) { return std::min<int32_t>(GH_RING_CHUNK, iters - c * GH_RING_CHUNK); };
 
+    std::vector<int32_t> hbuf((size_t)GH_HOST_RING * S);
     std::mutex mu;
     std::condition_variable cv;
-    int32_t drawn = 0;      // chunks whose ids are in the ring (producer -> this thread)
-    int32_t uploaded = 0;   // chunks whose upload has been enqueued and its event recorded (this thread -> producer)
+    int32_t drawn = 0;      // rows in hbuf (producer -> this thread)
+    int32_t taken = 0;      // rows copied out of hbuf (this thread -> producer)
     bool stop = false;
-    const int dev = h->device;
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); };
+    const clk::time_point t_begin = clk::now();
+    double draw_ms = 0.0, slot_wait_ms = 0.0, main_wait_ms = 0.0;
     std::thread producer([&]() {
-        (void)hipSetDevice(dev);
         std::vector<int64_t> scratch((size_t)gh_rp_scratch_words(h->S));
-        for (int32_t c = 0; c < nchunks; ++c) {
-            const int slot = c % GH_RING_SLOTS;
-            if (c >= GH_RING_SLOTS) {   // the slot's previous occupant (chunk c - GH_RING_SLOTS) must have gone up
+        for (int32_t t = 0; t < iters; ++t) {
+            if (t >= GH_HOST_RING) {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || uploaded > c - GH_RING_SLOTS; });
+                cv.wait(lk, [&] { return stop || taken > t - GH_HOST_RING; });
                 if (stop) return;
-                lk.unlock();
-                (void)hipEventSynchronize(h->ring_ev[slot]);
             }
-            int32_t *dst = h->h_ring + (size_t)slot * GH_RING_CHUNK * S;
-            for (int32_t t = 0; t < chunk_len(c); ++t) gh_torch_randperm_prefix_one(&mt, h->E, h->S, dst + (size_t)t * S, scratch.data());
+            const clk::time_point t0 = clk::now();
+            gh_torch_randperm_prefix_one(&mt, h->E, h->S, hbuf.data() + (size_t)(t % GH_HOST_RING) * S, scratch.data());
+            draw_ms += ms_since(t0);
             {
                 std::lock_guard<std::mutex> lk(mu);
-                drawn = c + 1;
+                drawn = t + 1;
                 if (stop) return;
             }
             cv.notify_all();
         }
     });
-    auto upload = [&](int32_t c) -> gh_status {   // waits for the producer, then one copy on the engine's stream
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return drawn > c; });
+    int32_t uploaded = 0, uploads = 0;
+    // rows [uploaded, uploaded + m) -> device ring; m >= 1 once row `need` is drawn
+    auto upload_through = [&](int32_t need) -> gh_status {
+        while (uploaded <= need) {
+            int32_t have;
+            {
+                const clk::time_point t0 = clk::now();
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return drawn > uploaded; });
+                have = drawn;
+                main_wait_ms += ms_since(t0);
+            }
+            int32_t m = std::min<int32_t>(have - uploaded, GH_RING_CHUNK);
+            m = std::min<int32_t>(m, GH_DEV_RING - uploaded % GH_DEV_RING);     // neither ring wraps inside one copy
+            m = std::min<int32_t>(m, GH_HOST_RING - uploaded % GH_HOST_RING);
+            const int slot = uploads % GH_RING_SLOTS;
+            if (uploads >= GH_RING_SLOTS) {
+                const clk::time_point t0 = clk::now();
+                GH_HIP(hipEventSynchronize(h->ring_ev[slot]));
+                slot_wait_ms += ms_since(t0);
+            }
+            int32_t *pin = h->h_ring + (size_t)slot * GH_RING_CHUNK * S;
+            memcpy(pin, hbuf.data() + (size_t)(uploaded % GH_HOST_RING) * S, sizeof(int32_t) * (size_t)m * S);
+            GH_HIP(hipMemcpyAsync(h->d_stream_ids + (size_t)(uploaded % GH_DEV_RING) * S, pin, sizeof(int32_t) * (size_t)m * S, hipMemcpyHostToDevice, h->stream));
+            GH_HIP(hipEventRecord(h->ring_ev[slot], h->stream));
+            uploaded += m;
+            ++uploads;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                taken = uploaded;
+            }
+            cv.notify_all();
         }
-        const int slot = c % GH_RING_SLOTS;
-        const size_t off = (size_t)slot * GH_RING_CHUNK * S;
-        GH_HIP(hipMemcpyAsync(h->d_stream_ids + off, h->h_ring + off, sizeof(int32_t) * (size_t)chunk_len(c) * S, hipMemcpyHostToDevice, h->stream));
-        GH_HIP(hipEventRecord(h->ring_ev[slot], h->stream));
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            uploaded = c + 1;
-        }
-        cv.notify_all();
         return GH_OK;
     };
-    auto row = [&](int32_t t) { return h->d_stream_ids + ((size_t)((t / GH_RING_CHUNK) % GH_RING_SLOTS) * GH_RING_CHUNK + (size_t)(t % GH_RING_CHUNK)) * S; };
+    auto row = [&](int32_t t) { return h->d_stream_ids + (size_t)(t % GH_DEV_RING) * S; };
     auto loop = [&]() -> gh_status {
-        GH_TRY(upload(0));
         for (int32_t t = 0; t < iters; ++t) {
-            const int32_t c = t / GH_RING_CHUNK;
-            if (t + 1 < iters && (t + 1) / GH_RING_CHUNK != c) GH_TRY(upload(c + 1));   // before this iteration's normalise launch reads the next ids
+            GH_TRY(upload_through(std::min(t + 1, iters - 1)));   // this iteration's ids, and the next one's for its normalise launch
             GH_TRY(set_sample(h, nullptr, row(t)));
             GH_TRY(step_begin(h, true));
             GH_TRY(step_merge(h, h->d_partial, 1));
@@ -948,8 +977,16 @@ extern "C" gh_status gh_run_torch_sampled(gh_handle h, int32_t iters, uint8_t *r
     cv.notify_all();
     producer.join();
     h->d_sampled_cur = h->d_sampled;
+    h->sampler_stats[0] = draw_ms; h->sampler_stats[1] = slot_wait_ms; h->sampler_stats[2] = main_wait_ms; h->sampler_stats[3] = ms_since(t_begin);
     if (st != GH_OK) return st;
     gh_mt_store(&mt, rng_state);
+    return GH_OK;
+}
+
+extern "C" gh_status gh_sampler_stats(gh_handle h, double *out4) {
+    GH_TRY(check_handle(h));
+    if (!out4) { h->err = "out4 is NULL"; return GH_ERR_INVALID; }
+    for (int i = 0; i < 4; ++i) out4[i] = h->sampler_stats[i];
     return GH_OK;
 }
 

