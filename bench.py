@@ -388,6 +388,11 @@ def main():
                     help="N > 1: 'python' drives each iteration's kernels and collectives through torch.distributed (RCCL); "
                          "'native' = gh_run_partitioned, the loop inside the C library over its own RCCL communicator "
                          "(opt-in until a world > 1 run has passed on hardware)")
+    ap.add_argument("--finish", default="overlap", choices=["overlap", "own", "gathered"],
+                    help="N > 1: how an iteration ends (graphem_rapids_amd/distributed.py).  overlap = form D: the all-gather of the "
+                         "un-normalised rows starts right after the fused kernel, on a second stream / communicator, and runs beside "
+                         "select -> keys -> merge -> statistics; every rank normalises all n rows.  own = form C (round 4): three "
+                         "collectives in a row, the rows last.  gathered = form B")
     ap.add_argument("--repeats", type=int, default=3, help="timed passes of --steps iterations; the median is reported")
     args = ap.parse_args()
 
@@ -422,7 +427,7 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, rank=rank, world=world,
-                                device_id=local_rank, native=args.loop == "native", knn_distance=args.knn_distance)
+                                device_id=local_rank, native=args.loop == "native", knn_distance=args.knn_distance, finish=args.finish)
         lay.set_positions(pos)
         run = lay.run
         sync = lay.sync
@@ -477,10 +482,19 @@ def main():
     # per-kernel durations with HIP events on the launching stream: a second pass of the same K steps
     eng.timing_enable(True)
     eng.timing_reset()
+    if use_dist:
+        lay.time_overlap = True
     run(args.steps)
     sync()
     timings = eng.timings()
     eng.timing_enable(False)
+    exposed_py = None
+    if use_dist:
+        lay.time_overlap = False
+        if lay.exposed_events:   # Python-driven form D: how long the engine's stream still waited for the early all-gather
+            torch.cuda.synchronize()
+            exposed_py = 1e3 * sum(a.elapsed_time(b) for a, b in lay.exposed_events) / len(lay.exposed_events)
+            lay.exposed_events.clear()
 
     if rank == 0:
         ms = 1e3 * dt / args.steps
@@ -519,11 +533,29 @@ def main():
             "roofline": roofline, "roofline_knn_fp32": knn_fp32, "roofline_iter_hbm": hbm, "kernels": kern,
         }
         if use_dist:  # rank 0's split of an iteration (HIP events on the engine's stream, second pass): where a scaling run loses its time
-            coll = sum(v["avg_us"] * v["launches_per_step"] for name, v in kern.items() if name.startswith("allgather"))
+            per = lambda name: kern[name]["avg_us"] * kern[name]["launches_per_step"] if name in kern else 0.0
             comp = sum(v["avg_us"] * v["launches_per_step"] for name, v in kern.items() if not name.startswith("allgather"))
-            out["rank0_us_per_step"] = {"kernels": comp, "collectives": coll,
-                                        "loop": "gh_run_partitioned (C library, RCCL all-gathers on the engine's stream)"
-                                        if getattr(lay, "native", False) else "python-driven (torch.distributed)"}
+            # collectives on the engine's stream are exposed in full; form D's early all-gather of the rows runs on a side
+            # stream ("allgather_rows": its whole duration there) and only what the engine's stream then still waits for is
+            # exposed ("allgather_rows_exposed", native loop; the Python-driven loop measures the same wait with CUDA events)
+            on_stream = sum(per(nm) for nm in kern if nm.startswith("allgather") and nm not in ("allgather_rows", "allgather_rows_exposed"))
+            rows_total = per("allgather_rows")
+            native = bool(getattr(lay, "native", False))
+            if args.finish == "overlap":
+                rows_exposed = per("allgather_rows_exposed") if native else exposed_py
+            else:
+                rows_exposed = rows_total
+            out["rank0_us_per_step"] = {
+                "kernels": comp, "collectives_exposed": on_stream + (rows_exposed or 0.0),
+                "small_collectives_on_stream": on_stream, "rows_allgather_total": rows_total if native or args.finish != "overlap" else None,
+                "rows_allgather_exposed": rows_exposed,
+                "rows_allgather_hidden": (rows_total - rows_exposed) if (rows_exposed is not None and rows_total) else None,
+                "finish": args.finish,
+                "note": "HIP events, second pass of the same K steps (events add launch gaps).  No N > 1 run of this code on hardware "
+                        "existed when it was written (development boxes have one GPU): this record is what a multi-GPU driver run fills in",
+                "loop": "gh_run_partitioned (C library; RCCL all-gathers, form D's rows on a second stream + ncclCommSplit communicator)"
+                        if native else "python-driven (torch.distributed; form D's rows on a side stream + a process group of their own)"}
+            out["config"]["finish"] = args.finish
         if world == 1 and not use_dist and args.knn_distance == "exact" and not args.no_parity_mode:
             out["parity_mode"] = parity_mode(args, n, D, k, S, edges, pos, local_rank)
         if world == 1 and not use_dist and not args.no_public_api:

@@ -29,6 +29,8 @@ SYMBOLS = [
     "gh_create_f64", "gh_set_positions_f64", "gh_get_positions_f64", "gh_positions_device_f64", "gh_spring_forces_f64",
     "gh_intersection_forces_f64", "gh_trlan_sweep", "gh_knn_ivf_config", "gh_knn_ivf_list_sizes",
     "gh_torch_randperm_prefix", "gh_torch_randperm_isa", "gh_run_torch_sampled", "gh_set_cdist_replay", "gh_sampler_stats",
+    "gh_overlap_layout", "gh_rows_all_device", "gh_rows_all_row_floats", "gh_stats_all_device", "gh_step_rows_early",
+    "gh_step_pack_rows", "gh_step_finish_overlap",
 ]
 
 
@@ -101,6 +103,20 @@ def load():
     L.gh_gather_layout.restype = ctypes.c_int
     L.gh_rank_layout.argtypes = [vp, i32, i32, i64]
     L.gh_rank_layout.restype = ctypes.c_int
+    L.gh_overlap_layout.argtypes = [vp, i32, i32, i64]
+    L.gh_overlap_layout.restype = ctypes.c_int
+    L.gh_rows_all_device.argtypes = [vp]
+    L.gh_rows_all_device.restype = vp
+    L.gh_rows_all_row_floats.argtypes = [vp]
+    L.gh_rows_all_row_floats.restype = i32
+    L.gh_stats_all_device.argtypes = [vp]
+    L.gh_stats_all_device.restype = vp
+    L.gh_step_rows_early.argtypes = [vp]
+    L.gh_step_rows_early.restype = i32
+    L.gh_step_pack_rows.argtypes = [vp, vp, i32]
+    L.gh_step_pack_rows.restype = ctypes.c_int
+    L.gh_step_finish_overlap.argtypes = [vp]
+    L.gh_step_finish_overlap.restype = ctypes.c_int
     L.gh_step_finish_own.argtypes = [vp, vp, i32]
     L.gh_step_finish_own.restype = ctypes.c_int
     L.gh_create_f64.argtypes = [ctypes.POINTER(vp), ctypes.c_int, i64, i32, i64, vp, ctypes.POINTER(GhParams),
@@ -394,6 +410,29 @@ class Engine:
 
     def rank_layout(self, world, rank, chunk):
         self._chk(self.lib.gh_rank_layout(self.handle, int(world), int(rank), int(chunk)))
+
+    # form D (include/graphem_hip.h gh_overlap_layout)
+    def overlap_layout(self, world, rank, chunk):
+        self._chk(self.lib.gh_overlap_layout(self.handle, int(world), int(rank), int(chunk)))
+
+    def rows_all_device_ptr(self):
+        return self.lib.gh_rows_all_device(self.handle)
+
+    def rows_all_row_floats(self):
+        return int(self.lib.gh_rows_all_row_floats(self.handle))
+
+    def stats_all_device_ptr(self):
+        return self.lib.gh_stats_all_device(self.handle)
+
+    def step_rows_early(self):
+        return bool(self.lib.gh_step_rows_early(self.handle))
+
+    def step_pack_rows(self, stream_ptr=None):
+        """Own block of new0 -> its packed slot, on the given raw HIP stream (None: the engine's stream)."""
+        self._chk(self.lib.gh_step_pack_rows(self.handle, ctypes.c_void_p(stream_ptr or 0), 1 if stream_ptr is None else 0))
+
+    def step_finish_overlap(self):
+        self._chk(self.lib.gh_step_finish_overlap(self.handle))
 
     def step_finish_own(self, stats_all_ptr, world):
         self._chk(self.lib.gh_step_finish_own(self.handle, ctypes.c_void_p(stats_all_ptr), int(world)))

@@ -18,7 +18,7 @@ static thread_local std::string g_create_error;
 void gh_set_create_error(const std::string &msg) { g_create_error = msg; }
 
 // ---- timing ------------------------------------------------------------------------
-gh_scope::gh_scope(gh_engine *h_, const char *name) : h(h_) {
+gh_scope::gh_scope(gh_engine *h_, const char *name, hipStream_t on) : h(h_), stream(on ? on : h_->stream) {
     if (!h->timing) return;
     for (size_t i = 0; i < h->timers.size(); ++i)
         if (h->timers[i].name == name) slot = (int)i;
@@ -29,11 +29,11 @@ gh_scope::gh_scope(gh_engine *h_, const char *name) : h(h_) {
     }
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
-    (void)hipEventRecord(a, h->stream);
+    (void)hipEventRecord(a, stream);
 }
 gh_scope::~gh_scope() {
     if (slot < 0) return;
-    (void)hipEventRecord(b, h->stream);
+    (void)hipEventRecord(b, stream);
     h->timers[slot].pending.emplace_back(a, b);
 }
 
@@ -90,9 +90,9 @@ static gh_status reject_f64(gh_engine *h, const char *what) {
 static void free_all(gh_engine *h) {
     gh_f64_free(h);
     gh_ivf_free(h);
-    void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, h->d_gbuf ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
+    void *ptrs[] = {h->d_edges, h->d_rowptr, h->d_adj, h->d_pos, (h->d_gbuf || h->d_rows_all) ? (void *)h->d_new_own : (void *)h->d_new, h->d_gbuf, h->d_rows_all, h->d_rows_pk, h->d_stats_all, h->d_tmpF, h->d_tmpF2, h->d_io, h->d_acc,
                     h->d_tflag, h->d_touched, h->d_tcount, h->d_sampled, h->d_q, h->d_qscan, h->d_qA, h->d_qexact, h->d_order, h->d_long_rows, h->d_long_ownptr, h->d_long_ownadj, h->d_long_eptr, h->d_long_erow, h->d_long_terms, h->d_own_long, h->d_cand, h->d_cnt,
-                    h->d_ovf, h->d_sel_redo, h->d_tq_count, h->d_tq_base, h->d_tq_touched, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rows_packed, h->d_rare, h->d_cd_rows, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, h->d_gbuf ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
+                    h->d_ovf, h->d_sel_redo, h->d_tq_count, h->d_tq_base, h->d_tq_touched, h->d_dbg_cnt, h->d_partial, h->d_merged, h->d_first_edge, h->d_own_eids, h->d_mid, h->d_Fs, h->d_gmin, h->d_sub_uv, h->d_stamps, h->d_tau_flag, h->d_wait_failed, h->d_grid_u32, h->d_grid_smid, h->d_grid_temp, h->d_iter, h->d_stats_comb, h->d_rows_packed, h->d_rare, h->d_cd_rows, h->d_cd_vbuf, h->d_cd_cmin, h->d_cd_stat, h->d_vblock, h->d_blockstats, (h->d_gbuf || h->d_rows_all) ? (void *)h->d_stats_own : (void *)h->d_stats, h->d_iscratch, h->d_stream_ids};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
@@ -644,7 +644,19 @@ static gh_status set_sample(gh_engine *h, const int32_t *host_ids, const int32_t
 
 // Spring forces of the own rows -> d_Fs and this rank's K best keys per query -> d_partial.
 // fuse_intersect: single-rank step, the KNN kernels also run the intersection phase.
+static gh_status step_begin_launches(gh_engine *h, bool fuse_intersect);
 static gh_status step_begin(gh_engine *h, bool fuse_intersect) {
+    h->rows_early = false;
+    GH_TRY(step_begin_launches(h, fuse_intersect));
+    // form D: new0 = pos + Fs of the own rows is in their block -- written by the fused kernel, or (a rank too small for it;
+    // every rank must send at the same point of the iteration) by a launch of its own -- and may travel now
+    if (h->overlap) {
+        if (!h->new0_ready) GH_TRY(gh_launch_new0(h));
+        h->rows_early = true;
+    }
+    return GH_OK;
+}
+static gh_status step_begin_launches(gh_engine *h, bool fuse_intersect) {
     h->intersect_done = false;
     h->stats_reduced = false;
     h->new0_ready = false;
@@ -1078,6 +1090,50 @@ extern "C" gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, in
     h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
     return GH_OK;
 }
+// Form D: form B's finish (every rank normalises all n rows from the gathered un-normalised rows) with the big collective
+// moved to the front of the KNN tail -- see include/graphem_hip.h.
+extern "C" gh_status gh_overlap_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk) {
+    GH_TRY(check_handle(h));
+    GH_TRY(reject_f64(h, "gh_overlap_layout"));
+    if (world < 1 || rank < 0 || rank >= world || chunk < 1 || chunk * world < h->n ||
+        h->part.row_lo != std::min<int64_t>(h->n, rank * chunk) || h->part.row_hi != std::min<int64_t>(h->n, (rank + 1) * chunk)) {
+        h->err = "overlap layout does not match the engine's row partition";
+        return GH_ERR_INVALID;
+    }
+    if (h->d_gbuf || h->g_world) { h->err = "rank / gather layout already set"; return GH_ERR_INVALID; }
+    const size_t R = (size_t)(2 + 2 * gh_fix_blocks(h->LD));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    GH_TRY(dev_alloc(h, &h->d_rows_all, (size_t)world * chunk * h->LD, true));
+    GH_TRY(dev_alloc(h, &h->d_stats_all, (size_t)world * R * h->LD, true));
+    if (h->D < h->LD && world > 1) GH_TRY(dev_alloc(h, &h->d_rows_pk, (size_t)world * chunk * h->D, true));
+    GH_HIP(hipStreamSynchronize(h->stream));
+    h->d_new_own = h->d_new;
+    h->d_stats_own = h->d_stats;
+    h->d_new = h->d_rows_all + (size_t)rank * chunk * h->LD;
+    h->d_stats = h->d_stats_all + (size_t)rank * R * h->LD;
+    h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
+    h->overlap = true;
+    return GH_OK;
+}
+extern "C" float *gh_rows_all_device(gh_handle h) { return !h || !h->overlap ? nullptr : h->d_rows_pk ? h->d_rows_pk : h->d_rows_all; }
+extern "C" int32_t gh_rows_all_row_floats(gh_handle h) { return !h || !h->overlap ? 0 : h->d_rows_pk ? h->D : h->LD; }
+extern "C" double *gh_stats_all_device(gh_handle h) { return h && h->overlap ? h->d_stats_all : nullptr; }
+extern "C" int32_t gh_step_rows_early(gh_handle h) { return h && h->overlap && h->rows_early ? 1 : 0; }
+extern "C" gh_status gh_step_pack_rows(gh_handle h, void *hip_stream, int32_t use_engine_stream) {
+    GH_TRY(check_handle(h));
+    if (!h->overlap) { h->err = "gh_overlap_layout has not been called"; return GH_ERR_INVALID; }
+    return gh_launch_pack_rows(h, use_engine_stream ? h->stream : reinterpret_cast<hipStream_t>(hip_stream));
+}
+extern "C" gh_status gh_step_finish_overlap(gh_handle h) {
+    GH_TRY(check_handle(h));
+    if (!h->overlap) { h->err = "gh_overlap_layout has not been called"; return GH_ERR_INVALID; }
+    if (h->rows_early) GH_TRY(gh_launch_patch_rows(h));   // (a late step's rows travelled with their intersection forces in them)
+    GH_TRY(gh_launch_normalise_gathered(h, h->last_step_own_ids ? (h->S >= h->E ? 2 : 1) : -1));
+    h->rows_early = false;
+    h->iter += 1;
+    return GH_OK;
+}
+
 extern "C" gh_status gh_set_packed_rows(gh_handle h, int32_t on) {
     GH_TRY(check_handle(h));
     if (on && !h->d_rows_packed) { h->err = "no packed block exchange for this engine (needs gh_rank_layout with world > 1 and fewer components than the row stride)"; return GH_ERR_INVALID; }

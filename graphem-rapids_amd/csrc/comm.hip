@@ -35,6 +35,7 @@ struct rccl_api {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *) = nullptr;   // optional (form D's second communicator)
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -55,6 +56,7 @@ rccl_api *rccl() {
         api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+        api.CommSplit = reinterpret_cast<decltype(api.CommSplit)>(dlsym(api.lib, "ncclCommSplit"));
     });
     return &api;
 }
@@ -101,13 +103,19 @@ struct gh_comm {
     gh_loop_group *loop = nullptr;      // loopback backend
     uint64_t *d_gathered = nullptr;     // (world, S, K) keys of all ranks
     double *d_stats_all = nullptr;      // (world, stats rows, LD) statistics of all ranks (form C)
+    // form D: the all-gather of the new0 blocks runs beside the KNN tail, on a stream and a communicator of its own
+    ncclComm_t nccl_b = nullptr;        // ncclCommSplit of `nccl` (same ranks); null: the loopback backend, or no overlap
+    hipStream_t stream_b = nullptr;
+    hipEvent_t ev_fused = nullptr, ev_rows = nullptr;
 };
 
-static gh_status comm_all_gather(gh_engine *h, const void *send, void *recv, size_t bytes, const char *what) {
+// side: the collective goes on the second stream / communicator (form D's early all-gather of the rows)
+static gh_status comm_all_gather(gh_engine *h, const void *send, void *recv, size_t bytes, const char *what, bool side = false) {
     gh_comm *c = h->comm;
-    gh_scope t(h, what);
+    const hipStream_t stream = side ? c->stream_b : h->stream;
+    gh_scope t(h, what, stream);
     if (c->nccl) {
-        const ncclResult_t r = rccl()->AllGather(send, recv, bytes, ncclUint8, c->nccl, h->stream);
+        const ncclResult_t r = rccl()->AllGather(send, recv, bytes, ncclUint8, side ? c->nccl_b : c->nccl, stream);
         if (r != ncclSuccess) { h->err = std::string("ncclAllGather: ") + rccl()->GetErrorString(r); return GH_ERR_RUNTIME; }
         return GH_OK;
     }
@@ -115,7 +123,7 @@ static gh_status comm_all_gather(gh_engine *h, const void *send, void *recv, siz
     // overwriting its send buffer (the next iteration) before everybody has copied
     gh_loop_group *g = c->loop;
     auto fail = [&](const char *msg) { g->poison(); h->err = msg; return GH_ERR_RUNTIME; };
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("loopback all-gather: stream synchronisation failed");
+    if (hipStreamSynchronize(stream) != hipSuccess) return fail("loopback all-gather: stream synchronisation failed");
     {
         std::lock_guard<std::mutex> lk(g->mu);
         g->send[(size_t)c->rank] = send;
@@ -124,9 +132,9 @@ static gh_status comm_all_gather(gh_engine *h, const void *send, void *recv, siz
     for (int r = 0; r < c->world; ++r) {
         void *dst = static_cast<unsigned char *>(recv) + (size_t)r * bytes;
         const void *src = g->send[(size_t)r];
-        if (dst != src && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream) != hipSuccess) return fail("loopback all-gather: copy failed");
+        if (dst != src && hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return fail("loopback all-gather: copy failed");
     }
-    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("loopback all-gather: stream synchronisation failed");
+    if (hipStreamSynchronize(stream) != hipSuccess) return fail("loopback all-gather: stream synchronisation failed");
     if (!g->barrier()) { h->err = "loopback all-gather: another rank of the group failed"; return GH_ERR_RUNTIME; }
     return GH_OK;
 }
@@ -164,6 +172,15 @@ static gh_status comm_common(gh_engine *h, int world, int rank) {
         h->err = "hipMalloc of the gather buffers failed";
         return GH_ERR_NOMEM;
     }
+    if (h->overlap) {   // form D: a second stream for the early all-gather of the rows, ordered against the engine's by two events
+        if (hipStreamCreateWithFlags(&h->comm->stream_b, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->comm->ev_fused, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->comm->ev_rows, hipEventDisableTiming) != hipSuccess) {
+            gh_comm_free(h);
+            h->err = "form D: creating the side stream failed";
+            return GH_ERR_HIP;
+        }
+    }
     return GH_OK;
 }
 
@@ -183,6 +200,12 @@ extern "C" gh_status gh_comm_init_rccl(gh_handle h, int32_t world, int32_t rank,
         (void)hipFree(h->comm->d_stats_all);
         delete h->comm; h->comm = nullptr;
         return GH_ERR_RUNTIME;
+    }
+    // form D: the early all-gather needs a communicator of its own to be in flight beside the keys' and the statistics'.
+    // Without ncclCommSplit (or if it fails -- on every rank alike: it is a collective call) the rows go out on the engine's
+    // stream after the merge, form B's order: correct, nothing hidden.
+    if (h->overlap && world > 1 && api->CommSplit) {
+        if (api->CommSplit(h->comm->nccl, 0, rank, &h->comm->nccl_b, nullptr) != ncclSuccess) h->comm->nccl_b = nullptr;
     }
     return GH_OK;
 }
@@ -208,7 +231,11 @@ extern "C" gh_status gh_comm_init_loopback(gh_handle h, gh_loop_group *group, in
 
 void gh_comm_free(gh_engine *h) {
     if (!h->comm) return;
+    if (h->comm->nccl_b) (void)rccl()->CommDestroy(h->comm->nccl_b);
     if (h->comm->nccl) (void)rccl()->CommDestroy(h->comm->nccl);
+    if (h->comm->stream_b) (void)hipStreamDestroy(h->comm->stream_b);
+    if (h->comm->ev_fused) (void)hipEventDestroy(h->comm->ev_fused);
+    if (h->comm->ev_rows) (void)hipEventDestroy(h->comm->ev_rows);
     if (h->comm->d_gathered) (void)hipFree(h->comm->d_gathered);
     if (h->comm->d_stats_all) (void)hipFree(h->comm->d_stats_all);
     delete h->comm;
@@ -237,13 +264,42 @@ extern "C" gh_status gh_run_partitioned(gh_handle h, int32_t iters, const int32_
         const size_t stats_bytes = sizeof(double) * (size_t)(2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
         for (int32_t t = 0; t < iters; ++t) {
             GH_TRY_ST(gh_step_begin_device_ids(h, d_ids ? d_ids + (size_t)t * h->S : nullptr));
+            // form D: new0 = pos + Fs of the own rows is complete -- its all-gather starts here, on the side stream when there
+            // is a second communicator (RCCL) or on the engine's (loopback: the host rendezvous blocks either way), and runs
+            // beside select -> keys -> merge + intersection -> statistics
+            const bool early = h->overlap && gh_step_rows_early(h);
+            const bool side = early && c->stream_b && (c->nccl_b || c->loop);
+            if (early && (side || c->loop)) {
+                const size_t block = sizeof(float) * (size_t)h->g_chunk * gh_rows_all_row_floats(h);
+                unsigned char *rows = reinterpret_cast<unsigned char *>(gh_rows_all_device(h));
+                if (side) {
+                    if (hipEventRecord(c->ev_fused, h->stream) != hipSuccess || hipStreamWaitEvent(c->stream_b, c->ev_fused, 0) != hipSuccess) { h->err = "form D: event hand-off failed"; return GH_ERR_HIP; }
+                }
+                GH_TRY_ST(gh_launch_pack_rows(h, side ? c->stream_b : h->stream));
+                GH_TRY_ST(comm_all_gather(h, rows + (size_t)c->rank * block, rows, block, "allgather_rows", side));
+                if (side && hipEventRecord(c->ev_rows, c->stream_b) != hipSuccess) { h->err = "form D: event record failed"; return GH_ERR_HIP; }
+            }
+            const bool rows_sent = early && (side || c->loop);
             if (h->S > 0 && h->k > 0) {
                 GH_TRY_ST(comm_all_gather(h, h->d_partial, c->d_gathered, key_bytes, "allgather_keys"));
                 GH_TRY_ST(gh_step_merge(h, c->d_gathered, c->world));
             } else {
                 GH_TRY_ST(gh_step_merge(h, h->d_partial, 1));   // spring forces only: nothing to merge
             }
-            if (h->d_gbuf) {   // form B
+            if (h->overlap) {   // form D: (the rows went out above, or go now)
+                const size_t block = sizeof(float) * (size_t)h->g_chunk * gh_rows_all_row_floats(h);
+                unsigned char *rows = reinterpret_cast<unsigned char *>(gh_rows_all_device(h));
+                if (!rows_sent) {   // a step without new0 (no fused kernel), or RCCL without a second communicator: form B's order
+                    GH_TRY_ST(gh_launch_pack_rows(h, h->stream));
+                    GH_TRY_ST(comm_all_gather(h, rows + (size_t)c->rank * block, rows, block, "allgather_rows"));
+                }
+                GH_TRY_ST(comm_all_gather(h, h->d_stats, h->d_stats_all, stats_bytes, "allgather_stats"));
+                if (early && side) {   // what of the early all-gather is still outstanding is this iteration's EXPOSED collective time
+                    gh_scope t(h, "allgather_rows_exposed");
+                    if (hipStreamWaitEvent(h->stream, c->ev_rows, 0) != hipSuccess) { h->err = "hipStreamWaitEvent failed"; return GH_ERR_HIP; }
+                }
+                GH_TRY_ST(gh_step_finish_overlap(h));
+            } else if (h->d_gbuf) {   // form B
                 GH_TRY_ST(comm_all_gather(h, h->d_gbuf + (size_t)c->rank * h->g_slot, h->d_gbuf, (size_t)h->g_slot, "allgather_slots"));
                 GH_TRY_ST(gh_step_finish_gathered(h));
             } else {           // form C

@@ -136,6 +136,12 @@ struct gh_engine {
                                       // (12 instead of 16 bytes per row at 3 components); gh_step_unpack_rows expands it into d_pos
     bool packed_exchange = false;     // ... in use (gh_set_packed_rows; default: from 2 M vertices on, where the saved quarter of
                                       // the all-gather outweighs the expansion kernel -- 30 us at 4 M vertices, 14 at 1 M)
+    // form D (gh_overlap_layout): the ranks' un-normalised rows new0 = pos + Fs are all-gathered EARLY, beside the KNN tail
+    bool overlap = false;
+    bool rows_early = false;          // this step: new0 of the own rows is in its block (the rows may travel right after step_begin)
+    float *d_rows_all = nullptr;      // (world, chunk, LD): d_new is block g_rank of it
+    float *d_rows_pk = nullptr;       // (world, chunk, D): the same without pad columns -- what travels when D < LD -- or null
+    double *d_stats_all = nullptr;    // (world, stats rows, LD): d_stats is block g_rank of it
     int32_t *d_qexact = nullptr;  // [0] = count, [1..] = queries outside the f16 range (scanned exactly)
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
     int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line
@@ -197,11 +203,16 @@ struct gh_scope {
     gh_engine *h;
     int slot = -1;
     hipEvent_t a = nullptr, b = nullptr;
-    gh_scope(gh_engine *h_, const char *name);
+    hipStream_t stream = nullptr;
+    gh_scope(gh_engine *h_, const char *name, hipStream_t on = nullptr /* null: the engine's stream */);
     ~gh_scope();
 };
 
 // api.hip / comm.hip
+extern "C" float *gh_rows_all_device(gh_handle h);
+extern "C" int32_t gh_rows_all_row_floats(gh_handle h);
+extern "C" int32_t gh_step_rows_early(gh_handle h);
+extern "C" gh_status gh_step_finish_overlap(gh_handle h);
 gh_status gh_upload_sample_stream(gh_engine *h, int32_t iters, const int32_t *sample_stream, const int32_t **d_ids);
 gh_status gh_step_begin_device_ids(gh_engine *h, const int32_t *dev_ids);
 void gh_comm_free(gh_engine *h);
@@ -264,6 +275,9 @@ gh_status gh_launch_unpack_rows(gh_engine *h);   // form C: the gathered packed 
 struct gh_long_args;
 gh_long_args gh_make_long_args(const gh_engine *h, bool coop_mid = false);   // common.h; coop_mid: fused kernels
 gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0);  // spring forces of the hub rows  // gathered slots of every rank -> all n rows of d_pos
+gh_status gh_launch_new0(gh_engine *h);                            // form D without the fused kernel: d_new = pos + Fs of the own rows
+gh_status gh_launch_pack_rows(gh_engine *h, hipStream_t stream);   // form D: own block of new0 -> its packed slot (on the given stream)
+gh_status gh_launch_patch_rows(gh_engine *h);                      // form D: touched rows of the gathered array += Fi; accumulators zeroed
 gh_status gh_launch_pad(gh_engine *h, const float *d_src_nD, float *d_dst_nLD);
 gh_status gh_launch_unpad(gh_engine *h, const float *d_src_nLD, float *d_dst_nD);
 gh_status gh_launch_sample(gh_engine *h);                  // device sampler -> d_sampled

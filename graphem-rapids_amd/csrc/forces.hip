@@ -131,7 +131,8 @@ template <int LD>
 __global__ __launch_bounds__(256) void integrate_kernel(
     const float *__restrict__ pos, const float *__restrict__ Fs, int64_t row_lo, int64_t rows,
     const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out,
-    double *__restrict__ blockstats) {
+    double *__restrict__ blockstats, int sum_first = 0 /* form D: new = fl(pos + Fs) + Fi, the rows themselves are already
+    travelling as pos + Fs (new0_kernel): statistics only, nothing stored */) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     double sx[LD], sxx[LD];
 #pragma unroll
@@ -146,11 +147,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(
         for (int d = 0; d < LD; ++d) {
             const float fi = touched ? (float)acc[x * LD + d] : 0.0f;
             const float tot = F[d] + fi;
-            nw[d] = px[d] + tot;
+            nw[d] = sum_first ? (px[d] + F[d]) + fi : px[d] + tot;
             sx[d] = (double)nw[d];
             sxx[d] = (double)nw[d] * (double)nw[d];
         }
-        gh_store_row<LD>(out, i, nw);
+        if (!sum_first) gh_store_row<LD>(out, i, nw);
     }
     __shared__ double red[4][2 * LD];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -169,14 +170,21 @@ __global__ __launch_bounds__(256) void integrate_kernel(
 // Any LD: new = pos + (Fs + Fi), one thread per element (statistics by column_stats_kernel).
 __global__ __launch_bounds__(256) void integrate_generic_kernel(
     const float *__restrict__ pos, const float *__restrict__ Fs, int LD, int64_t row_lo, int64_t rows,
-    const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out) {
+    const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out, int sum_first = 0) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= rows * LD) return;
     const int64_t x = row_lo + t / LD;
     const int64_t g = row_lo * LD + t;
     const float fi = tflag[x] != 0 ? (float)acc[g] : 0.0f;
     const float tot = Fs[t] + fi;
-    out[t] = pos[g] + tot;
+    out[t] = sum_first ? (pos[g] + Fs[t]) + fi : pos[g] + tot;
+}
+
+// Form D on an engine whose part 1 did not run the fused kernel: new0 = pos + Fs of the own rows, element by element.
+__global__ __launch_bounds__(256) void new0_kernel(const float *__restrict__ pos, const float *__restrict__ Fs, int64_t row_lo,
+                                                  int64_t count /* rows * LD */, int LD, float *__restrict__ out) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < count) out[t] = pos[row_lo * LD + t] + Fs[t];
 }
 
 // Midpoints of the edges [e_lo, e_lo + M) by gathering both endpoints (used when the edge
@@ -266,7 +274,10 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
                                                        const int32_t *__restrict__ tcount, int64_t row_lo,
                                                        int64_t rows, float *__restrict__ out_new,
                                                        double *__restrict__ stats, int skip_reduce,
-                                                       uint64_t *__restrict__ iter_bump /* replayed iterations: the device's iteration counter, or null */) {
+                                                       uint64_t *__restrict__ iter_bump /* replayed iterations: the device's iteration counter, or null */,
+                                                       int sum_first = 0 /* form D of a partitioned step (gh_overlap_layout): new0 is already
+                                                       travelling to the other ranks, which patch a touched row as fl(new0 + Fi) -- so does its
+                                                       owner: new = new0 + Fi (not pos + (Fs + Fi): one rounding apart), nothing stored here */) {
     __shared__ double red[4][2 * LD];
     if (iter_bump && blockIdx.x == 0 && threadIdx.x == 0) *iter_bump += 1;   // read by the set-up inside the NEXT launch (normalise)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -304,11 +315,11 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
         for (int d = 0; d < LD; ++d) {
             const float n0 = p[d] + f[d];
             const float tot = f[d] + (float)acc[x * LD + d];
-            nw[d] = p[d] + tot;
+            nw[d] = sum_first ? n0 + (float)acc[x * LD + d] : p[d] + tot;
             dx[d] += (double)nw[d] - (double)n0;
             dxx[d] += (double)nw[d] * (double)nw[d] - (double)n0 * (double)n0;
         }
-        gh_store_row<LD>(out_new, i, nw);
+        if (!sum_first) gh_store_row<LD>(out_new, i, nw);
     }
 #pragma unroll
     for (int d = 0; d < LD; ++d) {
@@ -465,8 +476,13 @@ __global__ __launch_bounds__(256) void normalise_kernel(const float *__restrict_
 // The same normalisation for ALL n rows from the gathered slots of every rank (one-collective
 // finish, include/graphem_hip.h): slot r = [chunk rows of new positions | that rank's statistics].
 // The per-rank statistics are added in rank order, so every rank derives the same mean / std.
+// Since round 5 rows and statistics are two strided arrays: form B passes both halves of its slots, form D
+// (gh_overlap_layout) the early all-gathered rows -- RS floats per row: LD, or D when they travelled without pad columns
+// -- and the late all-gathered statistics; skip_cleanup: form D's patch launch has zeroed the accumulators already.
 template <int LDT>
-__global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned char *__restrict__ gbuf, int64_t slot,
+__global__ __launch_bounds__(256) void normalise_gathered_kernel(const float *__restrict__ rows_base, int64_t rows_block /* floats between two ranks' blocks */,
+                                                                int RS, const double *__restrict__ stats_base, int64_t stats_block /* doubles */,
+                                                                int skip_cleanup,
                                                                 int64_t chunk, int world, int D, int LD, int64_t n,
                                                                 int nfix, float *__restrict__ pos,
                                                                 double *__restrict__ acc, int32_t *__restrict__ tflag,
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
     __shared__ __align__(16) unsigned char setup_lds[GH_SETUP_LDS_BYTES];
     const bool setup_block = (int)blockIdx.x < n_setup;  // the next iteration's KNN set-up, as in normalise_kernel
     const int nb = (int)blockIdx.x - n_setup;
-    if (!setup_block) {
+    if (!setup_block && !skip_cleanup) {
         const int64_t nt = (int64_t)(*tcount) * LD;
         for (int64_t t = nb * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)g_norm * blockDim.x) {
             const int64_t x = touched[t / LD];
@@ -491,7 +507,7 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
     // per-rank totals (sum and sum of squares incl. the correction rows), one thread per (rank, entry) ...
     for (int t = threadIdx.x; t < world * 2 * LD; t += blockDim.x) {
         const int r = t / (2 * LD), c = t % (2 * LD), base = c / LD, col = c % LD;
-        const double *st = reinterpret_cast<const double *>(gbuf + r * slot + chunk * LD * sizeof(float));
+        const double *st = stats_base + (int64_t)r * stats_block;
         double v = st[base * LD + col];
         for (int b = 0; b < nfix; ++b) v += st[(2 + 2 * b + base) * LD + col];
         part[t] = v;
@@ -521,8 +537,8 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
         if (t == 0) qexact[0] = 0;
         auto getp = [=](int64_t v, int d) {
             const int64_t r = v / chunk;
-            const float *rowsrc = reinterpret_cast<const float *>(gbuf + r * slot);
-            return (rowsrc[(v - r * chunk) * LD + d] - ms[d]) / ms[LD + d];
+            const float *rowsrc = rows_base + r * rows_block;
+            return (rowsrc[(v - r * chunk) * RS + d] - ms[d]) / ms[LD + d];
         };
         if constexpr (LDT > 0) {
             if (sa.tiles > 0) gh_setup_block<LDT>(sa, (int)blockIdx.x, getp, setup_lds);
@@ -538,7 +554,15 @@ __global__ __launch_bounds__(256) void normalise_gathered_kernel(const unsigned 
         const int64_t i = t * 4 / LD;
         const int d0 = (int)((t * 4) % LD);
         const int64_t r = i / chunk;
-        const float4 v = *reinterpret_cast<const float4 *>(gbuf + r * slot + ((i - r * chunk) * LD + d0) * sizeof(float));
+        const float *rp = rows_base + r * rows_block + (i - r * chunk) * RS + d0;
+        float4 v;
+        if (RS == LD) v = *reinterpret_cast<const float4 *>(rp);
+        else {   // rows without pad columns: what exists of this quarter row
+            v.x = d0 + 0 < D ? rp[0] : 0.0f;
+            v.y = d0 + 1 < D ? rp[1] : 0.0f;
+            v.z = d0 + 2 < D ? rp[2] : 0.0f;
+            v.w = d0 + 3 < D ? rp[3] : 0.0f;
+        }
         float4 o;
         o.x = d0 + 0 < D ? (v.x - ms[d0 + 0]) / ms[LD + d0 + 0] : 0.0f;
         o.y = d0 + 1 < D ? (v.y - ms[d0 + 1]) / ms[LD + d0 + 1] : 0.0f;
@@ -877,7 +901,7 @@ gh_status gh_launch_integrate(gh_engine *h) {
 #define GH_FIX_CASE(LL)                                                                                      \
     stats_fix_kernel<LL><<<dim3(gh_fix_blocks(LL)), dim3(256), 0, h->stream>>>(                                  \
         h->d_blockstats, h->n_vblocks, h->d_pos, h->d_Fs, h->d_acc, h->d_touched, h->d_tcount, h->part.row_lo, \
-        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0, h->graph_capturing ? h->d_iter : nullptr)
+        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0, h->graph_capturing ? h->d_iter : nullptr, h->rows_early ? 1 : 0)
         if (h->LD == 4) GH_FIX_CASE(4);
         else if (h->LD == 8) GH_FIX_CASE(8);
         else GH_FIX_CASE(16);
@@ -893,24 +917,28 @@ gh_status gh_launch_integrate(gh_engine *h) {
         return GH_OK;
     }
     const unsigned grid = grid_for(h->rows, 256);
+    // form D: the own block (d_new) holds new0 and is on its way to the other ranks: statistics of fl(new0 + Fi) only; a row
+    // stride without a templated kernel keeps the rows it sums in scratch
+    const int sf = h->overlap ? 1 : 0;
+    float *wide_out = sf ? h->d_tmpF : h->d_new;
     {
         gh_scope t(h, "integrate");
         switch (h->LD) {
             case 4:
                 integrate_kernel<4><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
-                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats);
+                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, sf);
                 break;
             case 8:
                 integrate_kernel<8><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
-                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats);
+                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, sf);
                 break;
             case 16:
                 integrate_kernel<16><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
-                                                                             h->d_acc, h->d_tflag, h->d_new, h->d_blockstats);
+                                                                             h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, sf);
                 break;
             default:
                 integrate_generic_kernel<<<dim3(grid_for(h->rows * h->LD, 256)), dim3(256), 0, h->stream>>>(
-                    h->d_pos, h->d_Fs, h->LD, h->part.row_lo, h->rows, h->d_acc, h->d_tflag, h->d_new);
+                    h->d_pos, h->d_Fs, h->LD, h->part.row_lo, h->rows, h->d_acc, h->d_tflag, wide_out, sf);
         }
         GH_LAUNCH_CHECK();
     }
@@ -919,7 +947,7 @@ gh_status gh_launch_integrate(gh_engine *h) {
         stats_reduce_kernel<<<dim3(2 * h->LD), dim3(256), 0, h->stream>>>(h->d_blockstats, h->nblocks_update, h->LD,
                                                                           h->d_stats, h->graph_capturing ? h->d_iter : nullptr);
     } else {
-        column_stats_kernel<<<dim3(h->D), dim3(256), 0, h->stream>>>(h->d_new, h->rows, h->D, h->LD, h->d_stats);
+        column_stats_kernel<<<dim3(h->D), dim3(256), 0, h->stream>>>(wide_out, h->rows, h->D, h->LD, h->d_stats);
     }
     GH_LAUNCH_CHECK();
     return GH_OK;
@@ -936,7 +964,8 @@ gh_status gh_launch_intersect(gh_engine *h) {
     const int64_t P = h->S * h->k;
     if (P == 0) return GH_OK;
     // a row partition accumulates only what lands on its own rows
-    const int32_t own_lo = h->rows != h->n ? (int32_t)h->part.row_lo : 0, own_hi = h->rows != h->n ? (int32_t)h->part.row_hi : 0x7FFFFFFF;
+    const bool own_only = h->rows != h->n && !h->overlap;   // (form D: every rank patches every touched row)
+    const int32_t own_lo = own_only ? (int32_t)h->part.row_lo : 0, own_hi = own_only ? (int32_t)h->part.row_hi : 0x7FFFFFFF;
     gh_scope t(h, "intersect");
 #define GH_INTER_ONE(DD, LL)                                                                                       \
     case DD:                                                                                                       \
@@ -1093,9 +1122,17 @@ gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
         extra = gh_setup_blocks(sa);
     }
     const size_t smem = sizeof(float) * 2 * h->LD + sizeof(double) * 2 * h->LD * (size_t)h->g_world;
+    // form B: both halves of the gathered slots; form D: the early-gathered rows (packed or not) and the late-gathered statistics
+    const float *rows_base = h->overlap ? (h->d_rows_pk ? h->d_rows_pk : h->d_rows_all) : reinterpret_cast<const float *>(h->d_gbuf);
+    const int RS = h->overlap && h->d_rows_pk ? h->D : h->LD;
+    const int64_t rows_block = h->overlap ? h->g_chunk * RS : h->g_slot / (int64_t)sizeof(float);
+    const double *stats_base = h->overlap ? h->d_stats_all : reinterpret_cast<const double *>(h->d_gbuf + h->g_chunk * h->LD * (int64_t)sizeof(float));
+    const int64_t stats_block = h->overlap ? (int64_t)(2 + 2 * gh_fix_blocks(h->LD)) * h->LD : h->g_slot / (int64_t)sizeof(double);
+    const int skip_cleanup = h->overlap && h->rows_early ? 1 : 0;
 #define GH_NORMG(LL)                                                                                              \
     normalise_gathered_kernel<LL><<<dim3(grid + extra), dim3(256), smem, h->stream>>>(                                   \
-        h->d_gbuf, h->g_slot, h->g_chunk, h->g_world, h->D, h->LD, h->n, gh_fix_blocks(h->LD), h->d_pos, h->d_acc,         \
+        rows_base, rows_block, RS, stats_base, stats_block, skip_cleanup,                                                  \
+        h->g_chunk, h->g_world, h->D, h->LD, h->n, gh_fix_blocks(h->LD), h->d_pos, h->d_acc,         \
         h->d_tflag, h->d_touched, h->d_tcount, (int)grid, (int)extra, sa, h->d_qexact)
     if (h->LD == 4) GH_NORMG(4);
     else if (h->LD == 8) GH_NORMG(8);
@@ -1112,6 +1149,55 @@ gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
         h->presetup_ids = h->d_sampled;
         h->presetup_iter = h->iter + 1;
     }
+    return GH_OK;
+}
+
+// ---- form D of a partitioned step (gh_overlap_layout) ----------------------------------------------------------------
+// The own block of new0 = pos + Fs without its pad columns -> its slot of the (world, chunk, D) array that travels.
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float *__restrict__ src /* (rows, LD) */, int64_t rows, int D, int LD,
+                                                       float *__restrict__ dst /* (rows, D) */) {
+    const int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x;
+    if (t >= rows * D) return;
+    dst[t] = src[(t / D) * LD + t % D];
+}
+gh_status gh_launch_new0(gh_engine *h) {
+    if (h->rows == 0) return GH_OK;
+    gh_scope t(h, "new0");
+    new0_kernel<<<dim3(grid_for(h->rows * h->LD, 256)), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows * h->LD, h->LD, h->d_new);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+gh_status gh_launch_pack_rows(gh_engine *h, hipStream_t stream) {
+    if (!h->d_rows_pk || h->rows == 0) return GH_OK;
+    // (chunk rows, not only the real ones: the block of a rank with fewer rows must not travel with stale bytes)
+    pack_rows_kernel<<<dim3(grid_for(h->g_chunk * h->D, 256)), dim3(256), 0, stream>>>(h->d_new, h->g_chunk, h->D, h->LD,
+                                                                                        h->d_rows_pk + (size_t)h->g_rank * h->g_chunk * h->D);
+    GH_LAUNCH_CHECK();
+    return GH_OK;
+}
+// After the all-gather of the new0 blocks: every row the intersection phase touched, on whichever rank it lives,
+// becomes fl(new0 + Fi) in the gathered array (the expression its owner's statistics used), and the accumulators are zeroed.
+__global__ __launch_bounds__(256) void patch_rows_kernel(float *__restrict__ rows /* (world * chunk, RS) */, int RS, int D, int LD,
+                                                        double *__restrict__ acc, int32_t *__restrict__ tflag,
+                                                        const int32_t *__restrict__ touched, const int32_t *__restrict__ tcount) {
+    const int64_t nt = (int64_t)(*tcount) * LD;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = touched[t / LD];
+        const int d = (int)(t % LD);
+        if (d < D) rows[x * RS + d] = rows[x * RS + d] + (float)acc[x * LD + d];
+        acc[x * LD + d] = 0.0;
+        if (d == 0) tflag[x] = 0;
+    }
+}
+gh_status gh_launch_patch_rows(gh_engine *h) {
+    const int64_t maxT = 4 * h->S * h->k * h->LD;
+    if (maxT == 0) return GH_OK;
+    gh_scope t(h, "patch_rows");
+    unsigned grid = grid_for(maxT, 256);
+    if (grid > 256) grid = 256;
+    patch_rows_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_rows_pk ? h->d_rows_pk : h->d_rows_all, h->d_rows_pk ? h->D : h->LD, h->D, h->LD,
+                                                               h->d_acc, h->d_tflag, h->d_touched, h->d_tcount);
+    GH_LAUNCH_CHECK();
     return GH_OK;
 }
 

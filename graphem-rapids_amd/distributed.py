@@ -21,6 +21,13 @@ most of the edges).  Every rank holds all n positions and the whole edge list.  
     gather  (RCCL)    in-place all-gather of the finished position blocks     chunk*D*4 B per rank
                       (without their pad columns when D < ld -- 12 instead of 16 B per row at D = 3 --, then
                       expanded into the position array by gh_step_unpack_rows; chunk*ld*4 B when D == ld)
+  finish="overlap" (round 5, form D; what bench.py --gpus N runs): the LAST collective of finish="gathered" moved to the front
+    part 1  (local)   as above; the fused kernel leaves new0 = pos + Fs of the own rows in this rank's block
+    gather  (RCCL, 2nd stream + 2nd group)   all-gather of the new0 blocks (chunk*D*4 B per rank) -- IN FLIGHT while
+    gather  (RCCL)    all-gather of the keys
+    part 2  (local)   merge; intersection forces of ALL rows on every rank; own corrections to the statistics
+    gather  (RCCL)    all-gather of the statistics
+    part 3  (local)   wait for the rows; touched rows := new0 + Fi; normalise ALL n rows (next set-up in the same launch)
   finish="gathered" (two collectives, every rank normalises all n rows -- 22-51 us per rank at 1 M vertices):
     gather  (RCCL)    in-place all-gather of slots [un-normalised rows | statistics]
     part 3  (local)   normalise ALL n rows from the gathered slots
@@ -140,6 +147,27 @@ class HipShardEngine:
         ptr = e.rows_packed_device_ptr()
         self.packed_blocks = device_view(ptr, (world, chunk * e.D), torch.float32, self.device, e) if ptr else None
 
+    def overlap_layout(self, world, rank, chunk):
+        """finish="overlap" (form D): new0 blocks gathered early into rows_all, statistics into stats_all."""
+        from .embedder_hip import device_view
+        e = self.eng
+        e.overlap_layout(world, rank, chunk)
+        self.world, self.rank, self.chunk = world, rank, chunk
+        rf = e.rows_all_row_floats()
+        self.rows_all = device_view(e.rows_all_device_ptr(), (world, chunk * rf), torch.float32, self.device, e)
+        self.stats_all = device_view(e.stats_all_device_ptr(), (world, e.stats_rows() * e.ld), torch.float64, self.device, e)
+        self.stats = self.stats_all[rank].view(e.stats_rows(), e.ld)
+        self.side = torch.cuda.Stream(self.device)
+
+    def step_rows_early(self):
+        return self.eng.step_rows_early()
+
+    def step_pack_rows(self, stream=None):
+        self.eng.step_pack_rows(None if stream is None else stream.cuda_stream)
+
+    def step_finish_overlap(self):
+        self.eng.step_finish_overlap()
+
     def step_unpack_rows(self):
         self.eng.step_unpack_rows()
 
@@ -213,11 +241,20 @@ class PartitionedLayout:
         # are pairwise different and replays partial_sort's heap for the others over all edges, identically on every rank
         self.engine = factory(self.n, self.D, edges, L_min, k_attr, k_inter, n_neighbors, min(sample_size, len(edges)),
                               seed, part, device_id, **({"knn_distance": "cdist"} if knn_distance == "cdist" else {}))
-        if finish not in ("own", "gathered"):
-            raise ValueError(f"finish must be 'own' or 'gathered', got {finish!r}")
+        if finish not in ("own", "gathered", "overlap"):
+            raise ValueError(f"finish must be 'own', 'gathered' or 'overlap', got {finish!r}")
         self.finish = finish
+        self.rows_group = None
+        self.exposed_events = []   # (before, after) CUDA events around the wait for the early all-gather (timing runs)
+        self.time_overlap = False
         if finish == "own":
             self.engine.rank_layout(self.world, self.rank, self.chunk)
+        elif finish == "overlap":
+            self.engine.overlap_layout(self.world, self.rank, self.chunk)
+            # the early all-gather is in flight beside the keys' and the statistics': a process group of its own
+            if self.world > 1 and dist.is_initialized():
+                ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+                self.rows_group = dist.new_group(ranks=ranks)
         else:
             self.engine.gather_layout(self.world, self.rank, self.chunk)
         self.K = n_neighbors + 1
@@ -286,6 +323,9 @@ class PartitionedLayout:
             return
         e = self.engine
         e.step_begin(sampled)
+        if self.finish == "overlap":
+            self._step_overlap(e)
+            return
         # output in concatenated form (world*S, K): accepted by both the RCCL and the gloo backend
         dist.all_gather_into_tensor(self.gathered.view(self.world * self.S, self.key_cols), e.partial, group=self.group)
         e.step_merge(self.gathered, self.world)
@@ -303,6 +343,40 @@ class PartitionedLayout:
         # in-place all-gather of the slots: rank r's new rows + statistics sit in row r of gbuf
         dist.all_gather_into_tensor(e.gbuf.view(-1), e.gbuf[self.rank], group=self.group)
         e.step_finish_gathered()
+
+    def _step_overlap(self, e):
+        """Form D: the all-gather of the new0 blocks goes out first -- on the engine's side stream and the rows' own process
+        group when there is a GPU, so that it is in flight beside everything up to the statistics."""
+        early = e.step_rows_early()
+        side = getattr(e, "side", None) if early else None
+        rows_group = self.rows_group if self.rows_group is not None else self.group
+
+        def send_rows(stream):
+            e.step_pack_rows(stream)
+            dist.all_gather_into_tensor(e.rows_all.view(-1), e.rows_all[self.rank], group=rows_group if stream is not None else self.group)
+
+        if early and side is not None:
+            side.wait_stream(torch.cuda.current_stream(side.device))   # the fused kernel's new0
+            with torch.cuda.stream(side):
+                send_rows(side)
+        elif early:
+            send_rows(None)
+        dist.all_gather_into_tensor(self.gathered.view(self.world * self.S, self.key_cols), e.partial, group=self.group)
+        e.step_merge(self.gathered, self.world)
+        if not early:   # no fused kernel in part 1: the rows travel with their intersection forces in them
+            send_rows(None)
+        dist.all_gather_into_tensor(e.stats_all.view(-1), e.stats.view(-1), group=self.group)
+        if early and side is not None:
+            cur = torch.cuda.current_stream(side.device)
+            if self.time_overlap:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(cur)
+                cur.wait_stream(side)
+                b.record(cur)
+                self.exposed_events.append((a, b))
+            else:
+                cur.wait_stream(side)
+        e.step_finish_overlap()
 
     def run(self, iters, sample_stream=None):
         if self.native:

@@ -29,6 +29,7 @@ class CpuShardEngine:
         self.stats = torch.zeros((2, self.ld), dtype=torch.float64)
         self.seed, self.iter = seed, 0
         self.gbuf = None
+        self.overlap = False
 
     def gather_layout(self, world, rank, chunk):
         """Slot = [chunk rows of new positions (ld floats each) | (2, ld) float64 statistics], as the HIP engine."""
@@ -42,6 +43,37 @@ class CpuShardEngine:
         assert world * chunk <= self.pos.shape[0]
         self.stats_all = torch.zeros((world, 2, self.ld), dtype=torch.float64)
         self.pos_blocks = self.pos[: world * chunk].view(world, chunk * self.ld)
+
+    def overlap_layout(self, world, rank, chunk):
+        """finish="overlap" (form D): new0 = pos + Fs blocks gathered early, statistics late (HipShardEngine.overlap_layout).
+        Rows travel without pad columns when D < ld and world > 1, like the HIP engine's."""
+        self.world, self.rank, self.chunk = world, rank, chunk
+        self.rf = self.D if (self.D < self.ld and world > 1) else self.ld
+        self.rows_all = torch.zeros((world, chunk * self.rf), dtype=torch.float32)
+        self.stats_all = torch.zeros((world, 2 * self.ld), dtype=torch.float64)
+        self.stats = self.stats_all[rank].view(2, self.ld)
+        self.overlap = True
+
+    def step_rows_early(self):
+        return True
+
+    def step_pack_rows(self, stream=None):
+        pass   # (step_begin wrote the own block in its travelling form)
+
+    def step_finish_overlap(self):
+        """Touched rows := fl(new0 + Fi) on every rank alike, then all n rows normalised from the ranks' statistics."""
+        n, D = self.n, self.D
+        rows = self.rows_all.numpy().reshape(self.world * self.chunk, self.rf)[:n, :D].copy()
+        t = self.touched
+        rows[t] = rows[t] + self.Fi_all[t]
+        tot = np.zeros((2, self.ld))
+        for r in range(self.world):
+            tot += self.stats_all[r].numpy().reshape(2, self.ld)
+        mean = tot[0, :D] / n
+        var = np.maximum((tot[1, :D] - tot[0, :D] * mean) / (n - 1), 0.0)
+        sd = np.sqrt(var).astype(np.float32) + np.float32(1e-6)
+        self.pos[:n, :D] = torch.from_numpy(((rows - mean.astype(np.float32)) / sd).astype(np.float32))
+        self.iter += 1
 
     def step_finish_own(self, stats_all):
         """The ranks' statistics added in rank order; own rows normalised into their block of pos."""
@@ -80,6 +112,10 @@ class CpuShardEngine:
         self.sampled = np.asarray(sampled, dtype=np.int32)
         p = self._p()
         self.Fs = oracle.spring_forces(p, self.edges, self.prm[0], self.prm[1])[self.row_lo:self.row_hi]
+        if self.overlap:   # form D: new0 of the own rows is in its block before anything else happens
+            blk = self.rows_all[self.rank].numpy().reshape(self.chunk, self.rf)
+            self.new0 = p[self.row_lo:self.row_hi] + self.Fs
+            blk[: self.row_hi - self.row_lo, : self.D] = self.new0
         mid = oracle.midpoints(p, self.edges)
         q = mid[self.sampled]
         loc = mid[self.own_ids]
@@ -123,7 +159,17 @@ class CpuShardEngine:
             g = gathered.numpy().transpose(1, 0, 2).reshape(self.S, -1)  # (S, world*K)
             g = np.sort(g, axis=1)[:, : self.k + 1]
             knn = (g[:, 1:] & 0xFFFFFFFF).astype(np.int32)               # drop column 0 (pt.py:421)
-        Fi = oracle.intersection_forces(p, self.edges, self.sampled, knn, self.prm[2])[self.row_lo:self.row_hi]
+        Fi_all = oracle.intersection_forces(p, self.edges, self.sampled, knn, self.prm[2])
+        if self.overlap:   # every rank keeps Fi of ALL rows; the own touched rows enter the statistics as fl(new0 + Fi)
+            self.Fi_all = Fi_all
+            self.touched = np.nonzero((Fi_all != 0).any(axis=1))[0]
+            new = self.new0 + Fi_all[self.row_lo:self.row_hi]
+            st = np.zeros((2, self.ld))
+            st[0, : self.D] = new.astype(np.float64).sum(0)
+            st[1, : self.D] = (new.astype(np.float64) ** 2).sum(0)
+            self.stats[:] = torch.from_numpy(st)
+            return
+        Fi = Fi_all[self.row_lo:self.row_hi]
         tot = self.Fs + Fi
         self.new = p[self.row_lo:self.row_hi] + tot
         st = np.zeros((2, self.ld))

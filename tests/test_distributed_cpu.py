@@ -56,7 +56,7 @@ def _case(n=403, D=3, deg=6, k=6, S=40, iters=3):
 
 
 @pytest.mark.parametrize("world,rule,finish", [(2, "hashed", "own"), (3, "hashed", "own"), (2, "range", "own"),
-                                               (3, "hashed", "gathered")])
+                                               (3, "hashed", "gathered"), (2, "hashed", "overlap"), (3, "hashed", "overlap")])
 def test_partitioned_layout_matches_single_rank_and_oracle(world, rule, finish, tmp_path):
     import oracle
     case = _case() + (rule, finish)

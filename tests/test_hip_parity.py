@@ -261,7 +261,7 @@ def test_device_sampler():
                                             (2, "hashed", 9001, 5),     # D without a templated spring kernel
                                             (3, "hashed", 20001, 16),
                                             (3, "hashed-hubs", 30011, 3)])  # rows with thousands of neighbours
-@pytest.mark.parametrize("finish", ["own", "gathered"])
+@pytest.mark.parametrize("finish", ["own", "gathered", "overlap"])
 def test_partitioned_engines_equal_single_engine(world, rule, n, D, finish):
     """The split step (gh_step_begin / gh_step_merge / gh_step_finish) with row partitions: `world`
     engines on ONE GPU, collectives emulated with device copies, must reproduce the unpartitioned
@@ -305,6 +305,8 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D, finish):
         shards.append(HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, part, 0))
         if finish == "own":
             shards[-1].rank_layout(world, r, chunk, packed=True)   # (the unpadded block exchange, on by default from 2 M vertices)
+        elif finish == "overlap":
+            shards[-1].overlap_layout(world, r, chunk)
         else:
             shards[-1].gather_layout(world, r, chunk)
         shards[-1].set_positions(pos)
@@ -312,6 +314,30 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D, finish):
     for t in range(3):
         for sh in shards:
             sh.step_begin(stream[t])
+        if finish == "overlap":
+            # form D: the new0 blocks travel FIRST (when the fused kernel made them), then keys, merge, statistics; every rank
+            # patches the touched rows and normalises all n rows
+            def exchange_rows():
+                for sh in shards:
+                    sh.step_pack_rows()
+                rows = torch.stack([sh.rows_all[r].clone() for r, sh in enumerate(shards)])
+                for sh in shards:
+                    sh.rows_all.copy_(rows)
+            early = shards[0].step_rows_early()
+            assert all(sh.step_rows_early() == early for sh in shards)
+            assert early      # (a rank without the fused kernel -- the 2001-vertex graph -- makes new0 with a launch of its own)
+            if early:
+                exchange_rows()
+            gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()
+            for sh in shards:
+                sh.step_merge(gathered, world)
+            if not early:
+                exchange_rows()
+            stats = torch.stack([sh.stats_all[r].clone() for r, sh in enumerate(shards)])
+            for sh in shards:
+                sh.stats_all.copy_(stats)
+                sh.step_finish_overlap()
+            continue
         gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()
         for sh in shards:
             sh.step_merge(gathered, world)
@@ -336,9 +362,12 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D, finish):
             sh.gbuf.copy_(slots)
             sh.step_finish_gathered()
     torch.cuda.synchronize()
+    # form D patches a touched row as fl(new0 + Fi) on every rank (its new0 is already travelling when Fi becomes known), the
+    # single engine computes pos + (Fs + Fi): one rounding apart on <= 4 S k rows per iteration (3.1e-6 after three iterations)
+    tol = 1e-5 if finish == "overlap" else 2e-6
     for sh in shards:
         got = sh.get_positions()
-        assert np.abs(got - ref).max() <= 2e-6
+        assert np.abs(got - ref).max() <= tol
         assert np.array_equal(got, shards[0].get_positions())
 
 
@@ -383,7 +412,7 @@ def test_rccl_driver_single_rank():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         got = {}
-        for native, finish in ((True, "own"), (False, "own"), (True, "gathered"), (False, "gathered")):
+        for native, finish in ((True, "own"), (False, "own"), (True, "gathered"), (False, "gathered"), (True, "overlap"), (False, "overlap")):
             # the loop in the C library over the library's own RCCL communicator / driven from Python; both finishes
             lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=9, rank=0, world=1, device_id=0, native=native,
                                     finish=finish)
@@ -399,13 +428,16 @@ def test_rccl_driver_single_rank():
     finally:
         dist.destroy_process_group()
     for key, val in got.items():
-        assert np.abs(val - ref).max() <= 2e-6, key
+        assert np.abs(val - ref).max() <= (1e-5 if key[1] == "overlap" else 2e-6), key
     assert np.array_equal(got[True, "own"], got[False, "own"])
     assert np.array_equal(got[True, "gathered"], got[False, "gathered"])
+    assert np.array_equal(got[True, "overlap"], got[False, "overlap"])
 
 
 @pytest.mark.parametrize("world,n,D,finish", [(2, 30011, 3, "own"), (3, 30011, 3, "own"), (4, 100003, 3, "own"), (3, 9001, 5, "own"),
-                                              (2, 20001, 16, "own"), (3, 30011, 3, "gathered"), (8, 100003, 3, "own")])
+                                              (2, 20001, 16, "own"), (3, 30011, 3, "gathered"), (8, 100003, 3, "own"),
+                                              (2, 30011, 3, "overlap"), (3, 30011, 3, "overlap"), (8, 100003, 3, "overlap"),
+                                              (3, 9001, 5, "overlap"), (2, 20001, 16, "overlap"), (3, 2001, 3, "overlap")])
 def test_native_partitioned_loop_on_the_loopback_backend(world, n, D, finish):
     """gh_run_partitioned (csrc/comm.hip): the whole multi-rank run inside the C library.  `world` engines on this one
     GPU, one host thread each, collectives by the in-process loopback backend (RCCL refuses two ranks on one device):
@@ -436,6 +468,8 @@ def test_native_partitioned_loop_on_the_loopback_backend(world, n, D, finish):
             e.rank_layout(world, r, chunk)
             if D < e.ld:   # the unpadded block exchange (default from 2 M vertices on): forced on for the even world sizes
                 e.set_packed_rows(world % 2 == 0)
+        elif finish == "overlap":   # form D: the new0 blocks on the side stream, first
+            e.overlap_layout(world, r, chunk)
         else:
             e.gather_layout(world, r, chunk)
         e.comm_init_loopback(group, r)
@@ -461,7 +495,7 @@ def test_native_partitioned_loop_on_the_loopback_backend(world, n, D, finish):
         e.comm_destroy()
         e.close()
     lib.gh_loopback_group_destroy(group)
-    assert np.abs(outs[0] - ref).max() <= 2e-6
+    assert np.abs(outs[0] - ref).max() <= (2e-5 if finish == "overlap" else 2e-6)   # (form D: touched rows one rounding apart, five iterations)
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
 

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void gather(const float4 *__restrict__ table, 
 int main(int argc, char **argv) {
     const int64_t rows = argc > 1 ? atoll(argv[1]) : 1000000;   // table rows (16 B each)
     const int64_t n = argc > 2 ? atoll(argv[2]) : 1000000;      // gathering threads (8 gathers each)
+    const int only = argc > 3 ? atoi(argv[3]) : -1;             // one cache policy only (counter passes: 0 = plain)
     std::vector<int> h((size_t)n * 8);
     std::mt19937_64 rng(1);
     for (auto &x : h) x = (int)(rng() % rows);
@@ -69,6 +70,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const char *names[] = {"plain", "nt", "sc0 sc1", "sc1", "sc0 sc1 nt", "sc0"};
     for (int mode = 0; mode < 6; ++mode) {
+        if (only >= 0 && mode != only) continue;
         float best = 1e9f;
         for (int rep = 0; rep < 6; ++rep) {
             CK(hipEventRecord(e0));
