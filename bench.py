@@ -542,7 +542,8 @@ def main():
             rows_total = per("allgather_rows")
             native = bool(getattr(lay, "native", False))
             if args.finish == "overlap":
-                rows_exposed = per("allgather_rows_exposed") if native else exposed_py
+                # (native loop without a second communicator -- no ncclCommSplit --: the rows went out on the engine's stream)
+                rows_exposed = (per("allgather_rows_exposed") if "allgather_rows_exposed" in kern else rows_total) if native else exposed_py
             else:
                 rows_exposed = rows_total
             out["rank0_us_per_step"] = {

@@ -204,7 +204,7 @@ extern "C" gh_status gh_comm_init_rccl(gh_handle h, int32_t world, int32_t rank,
     // form D: the early all-gather needs a communicator of its own to be in flight beside the keys' and the statistics'.
     // Without ncclCommSplit (or if it fails -- on every rank alike: it is a collective call) the rows go out on the engine's
     // stream after the merge, form B's order: correct, nothing hidden.
-    if (h->overlap && world > 1 && api->CommSplit) {
+    if (h->overlap && api->CommSplit) {   // (also at world 1: the rehearsal of the N > 1 path on a one-GPU box takes the same route)
         if (api->CommSplit(h->comm->nccl, 0, rank, &h->comm->nccl_b, nullptr) != ncclSuccess) h->comm->nccl_b = nullptr;
     }
     return GH_OK;

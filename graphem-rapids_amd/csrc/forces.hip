@@ -1169,6 +1169,7 @@ gh_status gh_launch_new0(gh_engine *h) {
 }
 gh_status gh_launch_pack_rows(gh_engine *h, hipStream_t stream) {
     if (!h->d_rows_pk || h->rows == 0) return GH_OK;
+    gh_scope t(h, "pack_rows", stream);
     // (chunk rows, not only the real ones: the block of a rank with fewer rows must not travel with stale bytes)
     pack_rows_kernel<<<dim3(grid_for(h->g_chunk * h->D, 256)), dim3(256), 0, stream>>>(h->d_new, h->g_chunk, h->D, h->LD,
                                                                                         h->d_rows_pk + (size_t)h->g_rank * h->g_chunk * h->D);

@@ -3,7 +3,12 @@ split step with the collectives replaced by device copies of its own data (same 
 timers give what every kernel costs.  This is what a rank computes between collectives -- the input of the scaling model
 in DESIGN.md section 6; the collectives themselves cannot be measured on a one-GPU box.
 
-  python tools/rank_compute_time.py [workload] [finish: own|gathered] > profiles/rNN/rank_compute_<workload>.json"""
+  python tools/rank_compute_time.py [workload] [finish: own|gathered|overlap] > profiles/rNN/rank_compute_<workload>.json
+
+finish=overlap (form D): `before_rows_us` = what runs before the rows' all-gather can start (thresholds, fused kernel),
+`beside_rows_us` = the kernels that run beside it (select, merge + intersection, corrections; + the two small collectives),
+`after_rows_us` = patch + normalisation of all n rows (+ next set-up); `side_stream_us` = the pack kernel in front of the
+all-gather on the side stream."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
@@ -17,11 +22,27 @@ for world in (1, 2, 4, 8):
     for rank in sorted({0, world // 2, world - 1}):
         chunk, lo, hi = partition_rows(n, world, rank)
         sh = HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 0, (lo, hi, 0, 0, 1), 0)
-        (sh.rank_layout if finish == "own" else sh.gather_layout)(world, rank, chunk)
+        {"own": sh.rank_layout, "gathered": sh.gather_layout, "overlap": sh.overlap_layout}[finish](world, rank, chunk)
         sh.set_positions(pos)
         gathered = torch.empty((world, S, k + 1), dtype=torch.int64, device="cuda")
 
+        def it_overlap():
+            sh.step_begin(None)
+            sh.step_pack_rows()
+            # stand-in for the early all-gather: every rank's block like this one's (as the form-B stand-in below: the statistics
+            # are world x this rank's sums, so the layout stays a layout; torch copies, not on the timers)
+            sh.rows_all.copy_(sh.rows_all[rank].expand_as(sh.rows_all).clone())
+            for w in range(world):
+                gathered[w].copy_(sh.partial)
+            sh.step_merge(gathered, world)
+            st = sh.stats_all[rank].clone()
+            for w in range(world):
+                sh.stats_all[w].copy_(st)                  # every rank's sums like this one's: the totals stay those of a layout
+            sh.step_finish_overlap()
+
         def it():
+            if finish == "overlap":
+                return it_overlap()
             sh.step_begin(None)
             for w in range(world):
                 gathered[w].copy_(sh.partial)              # stand-in for the all-gather of the keys
@@ -52,6 +73,15 @@ for world in (1, 2, 4, 8):
         tm = {a: round(1e3 * b[0] / b[1], 2) for a, b in sh.eng.timings().items()}
         rec = {"world": world, "rank": rank, "own_rows": hi - lo, "kernel_us": tm, "kernels_total_us": round(sum(tm.values()), 1),
                "bytes_sent_rows": (hi - lo) * (D if D < sh.ld else sh.ld) * 4 if world > 1 else 0}
+        if finish == "overlap":
+            grp = lambda names: round(sum(v for a, v in tm.items() if a in names), 1)
+            before = {"knn_tau", "knn_setup", "spring_scan", "spring_long", "spring_mid", "new0"}
+            after = {"patch_rows", "normalise_gathered"}
+            side = {"pack_rows"}
+            rec["before_rows_us"] = grp(before)
+            rec["after_rows_us"] = grp(after)
+            rec["side_stream_us"] = grp(side)
+            rec["beside_rows_us"] = round(sum(v for a, v in tm.items() if a not in before | after | side), 1)
         out["rows"].append(rec)
         print(f"world={world} rank {rank}: kernels {rec['kernels_total_us']} us", tm, file=sys.stderr, flush=True)
         sh.eng.close()
