@@ -674,7 +674,8 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
                                                           const float *__restrict__ cmin, int nchunks,
                                                           const uint64_t *__restrict__ cand, uint64_t *__restrict__ out_keys,
                                                           int nth_arg, inter_args ia,
-                                                          unsigned long long *__restrict__ stamps /* diagnostic (GRAPHEM_HIP_STAMPS), or null */) {
+                                                          unsigned long long *__restrict__ stamps /* diagnostic (GRAPHEM_HIP_STAMPS), or null */,
+                                                          int S_slots /* slot records that exist (S) */, int stamp_slots /* slots the stamp buffer holds */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];   // the LDS heap (HEAP == 2)
     __shared__ float cml[GH_CD_TILE];
     __shared__ uint32_t stage[GH_CD_BATCH * 64];   // value KEYS of the fetched chunks; 0xFFFFFFFF where the id is out of [K, P)
@@ -686,12 +687,13 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
     // sends such rows to the lane form)
     const bool nth_form = HEAP != 0 && nth_arg != 0;
     const int t = r0 + (int)blockIdx.x;
+    if (t >= r0 + R || t >= S_slots) return;   // (the grid always has cd_R workgroups: the last round's reach past the S slot records)
     // (slot records are read before the count is known: they exist for every t < S)
     const int nrare = all_rows ? all_rows : rr.hdr[0];
     const int64_t qi = all_rows ? t : rr.rare[1 + t];
     const int64_t P = all_rows ? E : (int64_t)rr.P[t];
     const int ct = all_rows ? 0 : rr.ct[t];
-    if (t >= min(nrare, r0 + R)) return;
+    if (t >= nrare) return;
     const float *v = vbuf + (int64_t)(t - r0) * vstride;
     const float *cm = cmin + (int64_t)(t - r0) * nchunks;
     const uint64_t *tl = cand + qi * GH_CAND_CAP + GH_CD_ALT;
@@ -700,7 +702,9 @@ __global__ __launch_bounds__(256) void cdist_replay_kernel(cdist_rows rr, int al
     const bool wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
     // diagnostic: 16 records per slot -- wall clock (100 MHz) at start, heap built, prefix done, tail done, sorted, end;
     // then batches, elements entered, chunks processed, P, tail length
-    if (stamps) stamps += (int64_t)t * 32;
+    // (the buffer is the fused launch's, shared with tools/stamp_probe.py: (n_vblocks + GH_STAMP_EXTRA) * 8 words -- a slot
+    // beyond it records nothing)
+    if (stamps) stamps = t < stamp_slots ? stamps + (int64_t)t * 32 : nullptr;
     int n_batches = 0, n_entered = 0, n_chunks = 0;
 #define GH_CD_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
     GH_CD_STAMP(0);
@@ -1159,7 +1163,8 @@ static gh_status cdist_replay_rounds(gh_engine *h, const cdist_args &a, const cd
         const inter_args ia = make_inter_args(h, fuse);
         const bool scalar_heap = h->K <= GH_CD_KS && !nth_form;
 #define GH_CREP(DD, HEAPv, INTv) cdist_replay_kernel<DD, HEAPv, INTv><<<dim3((unsigned)h->cd_R), dim3(256), smem, h->stream>>>( \
-        rr, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride, h->d_cd_cmin, h->cd_nchunks, h->d_cand, out_keys, nth_form, ia, h->d_stamps)
+        rr, all, r0, h->cd_R, h->E, h->K, h->d_cd_vbuf, vstride, h->d_cd_cmin, h->cd_nchunks, h->d_cand, out_keys, nth_form, ia, h->d_stamps, \
+        (int)h->S, (int)(((int64_t)h->n_vblocks + GH_STAMP_EXTRA) * 8 / 32))
 #define GH_CREP_D(DD) case DD: if (scalar_heap) GH_CREP(DD, 0, true); else GH_CREP(DD, 1, true); break;
         if (fuse) {
             switch (h->D) {

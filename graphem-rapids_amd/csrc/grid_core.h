@@ -6,7 +6,8 @@
 // the final decision are always taken in all D coordinates); what the projection costs is selectivity, and it costs
 // everything: on the 1 M-vertex bench state the shadow of the threshold ball holds more than the 8192 candidates a list
 // takes and every query falls back to the exhaustive search -- 85 ms per iteration at D = 6, S = 4096 against 1.6 ms for
-// the scan (profiles/r03/knn_method_sweep.log).  Hence D > 3 only with GRAPHEM_HIP_GRID_WIDE=1 (tests, measurements);
+// the scan (profiles/r03/knn_method_sweep.log).  Hence the grid is for D <= 3 only (gh_grid_path; the wide form and its
+// switch were removed in round 4);
 // the matrix-pipe scan is the search for wide rows at every S tried (up to 65536).  Included at the end of knn.hip (it
 // uses that file's K-smallest extraction).
 //

@@ -358,6 +358,12 @@ class GraphEmbedderHIP:
         idx = _native.knn_points(q, r, k, device_id=self.device.index)
         return torch.from_numpy(idx).to(self.device)
 
+    def _compute_knn_pykeops(self, query_points, reference_points, k, chunk_size=None):
+        """(n_query, k) nearest reference rows by the exact-difference squared distance, ties on the smaller index -- what
+        the reference's KeOps path computes (`((x_i - y_j) ** 2).sum(-1).argKmin(k)`, pt.py:485-541); here it is the same
+        kernel as _compute_knn_torch (gh_knn_points ranks on exactly that distance), KeOps itself is never imported."""
+        return self._compute_knn_torch(query_points, reference_points, k, chunk_size)
+
     def _compute_knn_chunked(self, query_points, reference_points, k):
         """Same result as _compute_knn_torch: there is one KNN implementation here (pt.py:426-483)."""
         return self._compute_knn_torch(query_points, reference_points, k)

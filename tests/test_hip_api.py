@@ -150,6 +150,20 @@ def test_point_knn_helpers():
         emb._compute_knn_chunked(q, ref, 21)
 
 
+def test_pykeops_named_method_is_the_exact_distance_knn():
+    """_compute_knn_pykeops (pt.py:485-541: argKmin of the exact-difference squared distance) under its reference name."""
+    import torch
+    import graphem_rapids_amd as gra
+    emb = gra.create_graphem(_rr(), n_components=3, verbose=False)
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((37, 3)).astype(np.float32)
+    r = rng.standard_normal((500, 3)).astype(np.float32)
+    got = emb._compute_knn_pykeops(torch.from_numpy(q), torch.from_numpy(r), 7, 16).cpu().numpy()
+    d2 = ((q[:, None, :].astype(np.float64) - r[None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(got, np.argsort(d2, axis=1, kind="stable")[:, :7])
+    assert emb._has_pykeops is False
+
+
 def test_factory_and_integration_properties():
     """Properties of the reference's integration tests (tests/test_integration.py:44-46, 136-138,
     169-174, 253-270): spread, per-dimension variance, parameter sensitivity, odd batch/sample sizes."""
