@@ -12,10 +12,16 @@
 //                   float, id) keys -- rounding is monotone, so the K smallest doubles are among the elements whose
 //                   rounded distance does not exceed the K-th smallest rounded distance; pass 2 collects those (K plus
 //                   the few that share the last float) and ranks them on (double distance, id).
+//                   From 131072 edges on (round 5) the two passes run over a FILTERED list instead of all E midpoints:
+//                   pass 1 over every stride-th midpoint gives an exclusive bound per query (MODE 1), f64_filter_kernel
+//                   -- reference-major: a workgroup holds 1024 midpoints in registers, all queries stream past, a
+//                   conservative packed-fp32 pre-check in front of the double chain -- parks what lies below it, and
+//                   MODE 2 ranks the parked midpoints (same doubles, same chain).  Rows identical to the full passes.
 //   intersection    f64_intersect_kernel: pt.py:638-774 per candidate pair, double atomics into a dense (n, D) array
 //   update          f64_sum_kernel / f64_centre_kernel / f64_scale_kernel: new = pos + (Fs + Fi); column means, then
 //                   centred sums of squares (two passes, fixed-order reductions), unbiased std + 1e-6, divide.
-// Per-iteration cost is dominated by the search: S * E double distances twice.
+// Per-iteration cost at a million vertices (rocprofv3, round 5): spring 320 us (8 M gathers of 24-byte rows), filter 320,
+// midpoints 85, thresholds 54, update 57, ranking 14, intersection 14: 0.88 ms (round 4, two full passes per query: 6.7 ms).
 #include "common.h"
 #include "engine.h"
 
@@ -29,6 +35,14 @@ struct gh_f64 {
     double *colstat = nullptr;    // (2, D): mean, std + 1e-6
     int32_t *rowptr = nullptr, *adj = nullptr, *edges = nullptr, *sampled = nullptr, *knn = nullptr;
     int32_t *fail = nullptr;      // a query whose boundary ties exceeded the pass-2 buffer (never seen; reported)
+    // filtered search (graphs from F64_FILTER_MIN_EDGES edges on): per query a bound from every `stride`-th midpoint, one
+    // reference-major pass over all midpoints that parks what passes it, the exact ranking over the parked ones
+    int64_t stride = 0;           // 0: the two full passes per query (small graphs)
+    double *sub = nullptr;        // (ceil(E / stride), D) every stride-th midpoint, contiguous (written beside mid)
+    double *tq = nullptr;         // (S) exclusive bound on the double distance: the float above the K-th smallest rounded-down subset distance
+    int32_t *cnt = nullptr;       // (S * F64_CNT_STRIDE) parked midpoints per query, one counter per 128-byte line (may exceed F64_CAND_CAP: then that query takes the full passes)
+    double *cand_d = nullptr;     // (S, F64_CAND_CAP) their squared distances ...
+    int32_t *cand_i = nullptr;    // ... and edge ids
     int nblocks = 0;
     double L_min = 1.0, k_attr = 0.2, k_inter = 0.5;   // the constructor's constants as doubles (gh_params holds floats)
 };
@@ -44,23 +58,46 @@ __global__ __launch_bounds__(256) void f64_spring_kernel(const double *__restric
     if (x >= n) return;
     double acc[F64_MAXD], diff[F64_MAXD];
     for (int d = 0; d < D; ++d) acc[d] = 0.0;
-    for (int j = rowptr[x]; j < rowptr[x + 1]; ++j) {
-        const int64_t y = adj[j];
+    const int jend = rowptr[x + 1];
+    double px[F64_MAXD];
+    for (int d = 0; d < D; ++d) px[d] = pos[x * D + d];
+    auto pull = [&](const double *py) __attribute__((always_inline)) {   // one neighbour, the reference's chain; forces added in list order
         double s = 0.0;
-        for (int d = 0; d < D; ++d) { diff[d] = pos[y * D + d] - pos[x * D + d]; s = fma(diff[d], diff[d], s); }
+        for (int d = 0; d < D; ++d) { diff[d] = py[d] - px[d]; s = fma(diff[d], diff[d], s); }
         const double dist = sqrt(s) + 1e-6;                 // pt.py:623
         const double fm = neg_k * (dist - L_min);           // pt.py:626
         for (int d = 0; d < D; ++d) acc[d] = acc[d] + fm * (diff[d] / dist);   // pt.py:629, 633-634
+    };
+    int j = rowptr[x];
+    if (D <= 4) {
+        // four neighbours' rows in flight per thread (one at a time: 362 us for 8 M gathers at a million vertices, a dependent
+        // memory round trip per neighbour; four: 321; eight: 379 -- the registers cost more waves than the loads win)
+        for (; j + 4 <= jend; j += 4) {
+            double py[4][4];
+            int64_t ys[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ys[u] = adj[j + u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                for (int d = 0; d < D; ++d) py[u][d] = pos[ys[u] * D + d];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pull(py[u]);
+        }
     }
+    for (; j < jend; ++j) pull(pos + (int64_t)adj[j] * D);
     for (int d = 0; d < D; ++d) F[x * D + d] = acc[d];
 }
 
-__global__ void f64_mid_kernel(const double *__restrict__ pos, const int32_t *__restrict__ edges, int64_t E, int D, double *__restrict__ mid) {
+__global__ void f64_mid_kernel(const double *__restrict__ pos, const int32_t *__restrict__ edges, int64_t E, int D, double *__restrict__ mid,
+                               int64_t stride = 0, double *__restrict__ sub = nullptr /* every stride-th midpoint once more, contiguous: the
+                               thresholds' subset (read by every query's workgroup: 1 MB in lines of its own instead of one line per midpoint) */) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= E * D) return;
     const int64_t e = t / D;
     const int d = (int)(t % D);
-    mid[t] = (pos[(int64_t)edges[2 * e] * D + d] + pos[(int64_t)edges[2 * e + 1] * D + d]) / 2.0;   // pt.py:785
+    const double v = (pos[(int64_t)edges[2 * e] * D + d] + pos[(int64_t)edges[2 * e + 1] * D + d]) / 2.0;   // pt.py:785
+    mid[t] = v;
+    if (sub && e % stride == 0) sub[(e / stride) * D + d] = v;
 }
 
 __global__ void f64_sample_kernel(int64_t E, int64_t S, uint64_t seed, uint64_t iter, int mode, int32_t *__restrict__ sampled) {
@@ -79,8 +116,20 @@ __device__ __forceinline__ uint64_t f64_min_u64(uint64_t a, uint64_t b) { return
 
 // One workgroup per query (file comment).  knn[q][0..k): ids of columns 1..k (column 0 dropped, pt.py:421).
 #define F64_POOL 1024
+#define F64_CAND_CAP 16384
+#define F64_CNT_STRIDE 32   /* one list counter per 128-byte line: adjacent counters serialise their returning atomics (3.2 ms of a 3.4 ms iteration at 400 K edges) */
+#define F64_FILTER_MIN_EDGES 131072
+// MODE 0: the search over all E midpoints (two passes).  MODE 1: pass 1 over every stride-th midpoint only -> tq[q], the
+// exclusive bound the filtered pass parks against (the K-th smallest of a subset is no smaller than the K-th smallest of
+// all, and rounding down is monotone: whatever ranks among the K smallest has a rounded distance <= the subset's K-th, i.e.
+// a distance below the next float); cnt[q] = 0.  MODE 2: both passes over the midpoints f64_filter_kernel parked for the
+// query -- the same doubles, computed by the same fma chain -- or, if they overflowed their list, over all E as MODE 0.
+template <int MODE>
 __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__ mid, int64_t E, int D, const int32_t *__restrict__ sampled,
-                                                     int K, int32_t *__restrict__ knn, int32_t *__restrict__ fail) {
+                                                     int K, int32_t *__restrict__ knn, int32_t *__restrict__ fail,
+                                                     int64_t stride, double *__restrict__ tq, int32_t *__restrict__ cnt,
+                                                     const double *__restrict__ cand_d, const int32_t *__restrict__ cand_i,
+                                                     const double *__restrict__ sub /* MODE 1: the compact subset */) {
     __shared__ double q[F64_MAXD];
     __shared__ uint64_t wmin[4];
     __shared__ double pool_d[F64_POOL];
@@ -97,8 +146,19 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
     // 15.6 K dependent memory round trips per scan at a million vertices, 99 of the engine's 100 ms per iteration.)  The
     // chain of one edge is the same fma chain in coordinate order as before.
     constexpr int F64_UNR = 8;
+    const int parked = MODE == 2 ? cnt[qi * F64_CNT_STRIDE] : 0;
+    const bool from_list = MODE == 2 && parked <= F64_CAND_CAP;
+    const int64_t step = MODE == 1 ? stride : 1;           // MODE 1: midpoints 0, stride, 2 stride, ... (`src` holds them contiguously)
+    const int64_t NE = MODE == 1 ? (E + stride - 1) / stride : E;
+    const double *src = MODE == 1 ? sub : mid;
     auto scan = [&](auto visit) __attribute__((always_inline)) {
-        for (int64_t e0 = threadIdx.x; e0 < E; e0 += 256 * F64_UNR) {
+        if (from_list) {
+            const double *ld = cand_d + qi * F64_CAND_CAP;
+            const int32_t *li = cand_i + qi * F64_CAND_CAP;
+            for (int i = threadIdx.x; i < parked; i += 256) visit((int64_t)li[i], ld[i]);
+            return;
+        }
+        for (int64_t e0 = threadIdx.x; e0 < NE; e0 += 256 * F64_UNR) {
             double s[F64_UNR];
 #pragma unroll
             for (int u = 0; u < F64_UNR; ++u) s[u] = 0.0;
@@ -107,7 +167,7 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
 #pragma unroll
                 for (int u = 0; u < F64_UNR; ++u) {
                     const int64_t e = e0 + (int64_t)u * 256;
-                    t[u] = e < E ? mid[e * D + d] : 0.0;
+                    t[u] = e < NE ? src[e * D + d] : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < F64_UNR; ++u) { const double df = q[d] - t[u]; s[u] = fma(df, df, s[u]); }
@@ -115,7 +175,7 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
 #pragma unroll
             for (int u = 0; u < F64_UNR; ++u) {
                 const int64_t e = e0 + (int64_t)u * 256;
-                if (e < E) visit(e, s[u]);
+                if (e < NE) visit(e * step, s[u]);
             }
         }
     };
@@ -175,6 +235,16 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
             }
         }
     }
+    if (MODE == 1) {
+        if (threadIdx.x == 0) {
+            const uint32_t vb = (uint32_t)(kth >> 32);
+            // not a finite bound (fewer than K subset midpoints, or distances that overflow): the query takes the full passes
+            const bool usable = vb < 0x7F800000u;
+            tq[qi] = usable ? (double)__uint_as_float(vb + 1u) : 0.0;
+            cnt[qi * F64_CNT_STRIDE] = usable ? 0 : F64_CAND_CAP + 1;
+        }
+        return;
+    }
     if (threadIdx.x == 0) thr = kth;
     __syncthreads();
     // pass 2: every edge whose rounded distance is <= that of the K-th key, with its double distance
@@ -195,6 +265,122 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
         int rank = 0;
         for (int j = 0; j < m; ++j) rank += (pool_d[j] < di || (pool_d[j] == di && pool_i[j] < ii)) ? 1 : 0;
         if (rank >= 1 && rank < K) knn[qi * (K - 1) + rank - 1] = ii;
+    }
+}
+
+// The filtered pass: a workgroup takes 256 * U consecutive midpoints into registers and runs every query past them (the
+// queries' coordinates and bounds staged through LDS, F64_QC at a time): squared distance by the fma chain in coordinate
+// order, as f64_knn_kernel computes it; what lies below the query's bound is parked with its distance.  Every midpoint is
+// read ONCE per iteration (96 MB at four million edges and three components) where the per-query passes read all of them
+// twice per query (49 GB).
+#define F64_QC 128
+typedef float f64_f2 __attribute__((ext_vector_type(2)));
+// PRE: a conservative pre-check in packed fp32 in front of the double chain (two midpoints per v_pk_* instruction, half the
+// double chain's issue slots).  With u = 2^-24, q and m rounded to float and the chain fl(sum of fl(q - m)^2) run in fp32:
+// |fl(qf_d - mf_d) - (q_d - m_d)| <= 2.01 u (|q_d| + |m_d|), so the float sum s32 of a pair whose exact-chain double
+// distance is s obeys  s32 <= (sqrt(s) + 2.01 u (|q| + |m|))^2 (1 + (D + 2) u).  A pair with s < bound therefore has
+// s32 <= b32 := (sqrt(bound) + 2.01 u (|q| + M))^2 (1 + (D + 2) u) rounded UP to float, M = the largest |m| of the workgroup's
+// own midpoints: whatever fails  s32 <= b32  cannot be below the bound, whatever passes gets the double chain (and is
+// parked only if THAT is below the bound).  Underflow in fp32 only makes s32 smaller (passes); a b32 that is not finite
+// lets everything pass.  (The expanded form |m|^2 - 2 q.m -- three packed fmas instead of six instructions -- was measured
+// too: its error term scales with (|q| + |m|)^2 instead of with the distance, more pairs pass, 337 against 318 us.)
+template <int DT, int U, bool PRE>
+__global__ __launch_bounds__(256) void f64_filter_kernel(const double *__restrict__ mid, int64_t E, int Drt, const int32_t *__restrict__ sampled,
+                                                        int64_t S, const double *__restrict__ tq, int32_t *__restrict__ cnt,
+                                                        double *__restrict__ cand_d, int32_t *__restrict__ cand_i) {
+    const int D = DT > 0 ? DT : Drt;
+    constexpr int DM = DT > 0 ? DT : F64_MAXD;
+    __shared__ double qs[F64_QC * DM];
+    __shared__ double qb[F64_QC];
+    __shared__ float qf[PRE ? F64_QC * DM : 1];
+    __shared__ float qb32[PRE ? F64_QC : 1];
+    __shared__ double wmax[4];
+    double m[U][DM];
+    const int64_t e0 = (int64_t)blockIdx.x * 256 * U + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t e = e0 + (int64_t)u * 256;
+        for (int d = 0; d < D; ++d) m[u][d] = e < E ? mid[e * D + d] : 0.0;
+    }
+    f64_f2 mf[PRE ? U / 2 : 1][DM];
+    double M = 0.0;
+    if constexpr (PRE) {
+        static_assert(U % 2 == 0, "the pre-check packs two midpoints per lane");
+#pragma unroll
+        for (int r = 0; r < U / 2; ++r)
+            for (int d = 0; d < D; ++d) mf[r][d] = (f64_f2){(float)m[2 * r][d], (float)m[2 * r + 1][d]};
+        double nm = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            double s = 0.0;
+            for (int d = 0; d < D; ++d) s = fma(m[u][d], m[u][d], s);
+            nm = fmax(nm, s);
+        }
+        nm = sqrt(nm) * (1.0 + 1e-15);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nm = fmax(nm, __shfl_xor(nm, off, 64));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = nm;
+        __syncthreads();
+        M = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    }
+    for (int64_t q0 = 0; q0 < S; q0 += F64_QC) {
+        const int nq = (int)min((int64_t)F64_QC, S - q0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < nq * D; t += 256) {
+            const double v = mid[(int64_t)sampled[q0 + t / D] * D + t % D];
+            qs[t] = v;
+            if constexpr (PRE) qf[t] = (float)v;
+        }
+        for (int t = threadIdx.x; t < nq; t += 256) qb[t] = cnt[(q0 + t) * F64_CNT_STRIDE] > F64_CAND_CAP ? -1.0 : tq[q0 + t];   // (a query on the full passes parks nothing)
+        __syncthreads();
+        if constexpr (PRE) {
+            for (int t = threadIdx.x; t < nq; t += 256) {
+                float b32 = -1.0f;
+                if (qb[t] >= 0.0) {
+                    double qn = 0.0;
+                    for (int d = 0; d < D; ++d) qn = fma(qs[t * D + d], qs[t * D + d], qn);
+                    const double u24 = 5.9604644775390625e-08;
+                    const double r = sqrt(qb[t]) + 2.01 * u24 * (sqrt(qn) * (1.0 + 1e-15) + M);
+                    const double b = r * r * (1.0 + (D + 2) * u24) * (1.0 + 1e-12);
+                    b32 = (float)b;
+                    if ((double)b32 < b) b32 = __uint_as_float(__float_as_uint(b32) + 1u);   // round up (b > 0)
+                    if (!(b < 1e37)) b32 = __builtin_inff();
+                }
+                qb32[t] = b32;
+            }
+            __syncthreads();
+        }
+#pragma unroll 4
+        for (int j = 0; j < nq; ++j) {
+            unsigned pass = (1u << U) - 1u;   // midpoints of this lane that take the double chain
+            if constexpr (PRE) {
+                const float b32 = qb32[j];
+                pass = 0u;
+#pragma unroll
+                for (int r = 0; r < U / 2; ++r) {
+                    f64_f2 acc = (f64_f2){0.0f, 0.0f};
+                    for (int d = 0; d < D; ++d) {
+                        const float qd = qf[j * D + d];
+                        const f64_f2 df = (f64_f2){qd, qd} - mf[r][d];
+                        acc = __builtin_elementwise_fma(df, df, acc);
+                    }
+                    pass |= (acc.x <= b32 ? 1u : 0u) << (2 * r);
+                    pass |= (acc.y <= b32 ? 1u : 0u) << (2 * r + 1);
+                }
+                if (pass == 0u) continue;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!((pass >> u) & 1u)) continue;
+                double s = 0.0;
+                for (int d = 0; d < D; ++d) { const double df = qs[j * D + d] - m[u][d]; s = fma(df, df, s); }
+                const int64_t e = e0 + (int64_t)u * 256;
+                if (s < qb[j] && e < E) {
+                    const int p = atomicAdd(&cnt[(q0 + j) * F64_CNT_STRIDE], 1);
+                    if (p < F64_CAND_CAP) { cand_d[(q0 + j) * F64_CAND_CAP + p] = s; cand_i[(q0 + j) * F64_CAND_CAP + p] = (int32_t)e; }
+                }
+            }
+        }
     }
 }
 
@@ -230,62 +416,87 @@ __global__ __launch_bounds__(256) void f64_intersect_kernel(const double *__rest
 }
 
 // new = pos + (Fs + Fi) (pt.py:796-799) and per-block column sums of it.
-__global__ __launch_bounds__(256) void f64_sum_kernel(const double *__restrict__ pos, const double *__restrict__ Fs, const double *__restrict__ Fi,
-                                                     int64_t n, int D, double *__restrict__ nw, double *__restrict__ part) {
-    __shared__ double red[4];
+// Update kernels.  Flat over the (n, D) arrays, T = gridDim.x * 256 threads with T a multiple of D (f64_update_blocks): a
+// thread's elements t, t + T, ... all belong to ONE column, so it keeps one running sum and every access is coalesced
+// (round 4 walked the arrays column by column, and every workgroup added up the 1024 partial sums of the launch before one
+// thread at a time: 107-112 us each for the two launches at a million vertices).  Sums are combined in a fixed order.
+__device__ __forceinline__ void f64_block_columns(double s, int D, double *scratch /* shared, 256 */, double *__restrict__ part_row) {
+    scratch[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < D) {   // column c: the threads whose global id is c modulo D, in ascending order
+        const int first = (int)(((int64_t)threadIdx.x - (int64_t)blockIdx.x * 256 % D + D) % D);
+        double tot = 0.0;
+        for (int t = first; t < 256; t += D) tot += scratch[t];
+        part_row[threadIdx.x] = tot;
+    }
+    __syncthreads();
+}
+// totals of the (nparts, D) partial sums -> out[0 .. D) (shared), the same on every workgroup: thread t adds rows t, t + 256,
+// ..., then a fixed tree
+__device__ __forceinline__ void f64_totals(const double *__restrict__ part, int nparts, int D, double *out, double *scratch) {
     for (int d = 0; d < D; ++d) {
         double s = 0.0;
-        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-            const double tot = Fs[i * D + d] + Fi[i * D + d];
-            const double v = pos[i * D + d] + tot;
-            nw[i * D + d] = v;
-            s += v;
+        for (int b = threadIdx.x; b < nparts; b += 256) s += part[(int64_t)b * D + d];
+        scratch[threadIdx.x] = s;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) scratch[threadIdx.x] += scratch[threadIdx.x + off];
+            __syncthreads();
         }
-        s = gh_wave_sum(s);
+        if (threadIdx.x == 0) out[d] = scratch[0];
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) part[(int64_t)blockIdx.x * D + d] = ((red[0] + red[1]) + red[2]) + red[3];
     }
+}
+__global__ __launch_bounds__(256) void f64_sum_kernel(const double *__restrict__ pos, const double *__restrict__ Fs, const double *__restrict__ Fi,
+                                                     int64_t n, int D, double *__restrict__ nw, double *__restrict__ part) {
+    __shared__ double scratch[256];
+    const int64_t T = (int64_t)gridDim.x * 256, total = n * D;
+    double s = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += T) {
+        const double tot = Fs[t] + Fi[t];          // pt.py:796-799
+        const double v = pos[t] + tot;
+        nw[t] = v;
+        s += v;
+    }
+    f64_block_columns(s, D, scratch, part + (int64_t)blockIdx.x * D);
 }
 // mean from the partial sums (fixed order), centre the rows, per-block sums of squares of the centred values (pt.py:802-803).
 __global__ __launch_bounds__(256) void f64_centre_kernel(double *__restrict__ nw, int64_t n, int D, const double *__restrict__ part_in, int nparts,
                                                         double *__restrict__ colstat, double *__restrict__ part_out) {
     __shared__ double mean[F64_MAXD];
-    __shared__ double red[4];
+    __shared__ double scratch[256];
+    f64_totals(part_in, nparts, D, mean, scratch);
     if ((int)threadIdx.x < D) {
-        double s = 0.0;
-        for (int b = 0; b < nparts; ++b) s += part_in[(int64_t)b * D + threadIdx.x];
-        mean[threadIdx.x] = s / (double)n;
+        mean[threadIdx.x] = mean[threadIdx.x] / (double)n;
         if (blockIdx.x == 0) colstat[threadIdx.x] = mean[threadIdx.x];
     }
     __syncthreads();
-    for (int d = 0; d < D; ++d) {
-        double s = 0.0;
-        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-            const double c = nw[i * D + d] - mean[d];
-            nw[i * D + d] = c;
-            s += c * c;
-        }
-        s = gh_wave_sum(s);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-        __syncthreads();
-        if (threadIdx.x == 0) part_out[(int64_t)blockIdx.x * D + d] = ((red[0] + red[1]) + red[2]) + red[3];
+    const int64_t T = (int64_t)gridDim.x * 256, total = n * D;
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const double mu = mean[t0 % D];
+    double s = 0.0;
+    for (int64_t t = t0; t < total; t += T) {
+        const double c = nw[t] - mu;
+        nw[t] = c;
+        s += c * c;
     }
+    f64_block_columns(s, D, scratch, part_out + (int64_t)blockIdx.x * D);
 }
 // unbiased std + 1e-6 (pt.py:803), divide (pt.py:804).
 __global__ __launch_bounds__(256) void f64_scale_kernel(const double *__restrict__ nw, int64_t n, int D, const double *__restrict__ part_in, int nparts,
                                                        double *__restrict__ colstat, double *__restrict__ pos) {
     __shared__ double sd[F64_MAXD];
+    __shared__ double scratch[256];
+    f64_totals(part_in, nparts, D, sd, scratch);
     if ((int)threadIdx.x < D) {
-        double s = 0.0;
-        for (int b = 0; b < nparts; ++b) s += part_in[(int64_t)b * D + threadIdx.x];
-        sd[threadIdx.x] = sqrt(s / (double)(n - 1)) + 1e-6;
+        sd[threadIdx.x] = sqrt(sd[threadIdx.x] / (double)(n - 1)) + 1e-6;
         if (blockIdx.x == 0) colstat[D + threadIdx.x] = sd[threadIdx.x];
     }
     __syncthreads();
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n * D; t += (int64_t)gridDim.x * blockDim.x) pos[t] = nw[t] / sd[t % D];
+    const int64_t T = (int64_t)gridDim.x * 256, total = n * D;
+    const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const double sdv = sd[t0 % D];
+    for (int64_t t = t0; t < total; t += T) pos[t] = nw[t] / sdv;
 }
 
 __global__ void f64_from_f32_kernel(const float *__restrict__ src, int64_t count, double *__restrict__ dst) {
@@ -312,7 +523,8 @@ gh_status f64_alloc(gh_engine *h, T **p, size_t count) {
 void f64_free(gh_engine *h) {
     gh_f64 *f = h->f64;
     if (!f) return;
-    void *ptrs[] = {f->pos, f->nw, f->Fs, f->Fi, f->mid, f->io, f->part, f->colstat, f->rowptr, f->adj, f->edges, f->sampled, f->knn, f->fail};
+    void *ptrs[] = {f->pos, f->nw, f->Fs, f->Fi, f->mid, f->io, f->part, f->colstat, f->rowptr, f->adj, f->edges, f->sampled, f->knn, f->fail,
+                    f->tq, f->cnt, f->cand_d, f->cand_i, f->sub};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete f;
     h->f64 = nullptr;
@@ -331,8 +543,29 @@ gh_status f64_knn(gh_engine *h, const int32_t *host_ids) {
     } else {
         f64_sample_kernel<<<dim3(f64_grid(h->S)), dim3(256), 0, h->stream>>>(h->E, h->S, h->prm.seed, h->iter, 1, f->sampled);
     }
-    f64_mid_kernel<<<dim3(f64_grid(h->E * h->D)), dim3(256), 0, h->stream>>>(f->pos, f->edges, h->E, h->D, f->mid);
-    f64_knn_kernel<<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(f->mid, h->E, h->D, f->sampled, h->K, f->knn, f->fail);
+    f64_mid_kernel<<<dim3(f64_grid(h->E * h->D)), dim3(256), 0, h->stream>>>(f->pos, f->edges, h->E, h->D, f->mid, f->stride, f->sub);
+    if (f->stride > 0) {
+        f64_knn_kernel<1><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(f->mid, h->E, h->D, f->sampled, h->K, f->knn, f->fail, f->stride, f->tq, f->cnt,
+                                                                             f->cand_d, f->cand_i, f->sub);
+#define F64_FILTER(DD, UU) f64_filter_kernel<DD, UU, (DD > 0 && UU % 2 == 0)><<<dim3((unsigned)((h->E + 256 * UU - 1) / (256 * UU))), dim3(256), 0, h->stream>>>( \
+        f->mid, h->E, h->D, f->sampled, h->S, f->tq, f->cnt, f->cand_d, f->cand_i)
+        switch (h->D) {
+            case 2: F64_FILTER(2, 4); break;
+            case 3: F64_FILTER(3, 4); break;
+            case 4: F64_FILTER(4, 4); break;
+            case 5: F64_FILTER(5, 2); break;
+            case 6: F64_FILTER(6, 2); break;
+            case 8: F64_FILTER(8, 2); break;
+            case 16: F64_FILTER(16, 2); break;
+            default: F64_FILTER(0, 1); break;
+        }
+#undef F64_FILTER
+        f64_knn_kernel<2><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(f->mid, h->E, h->D, f->sampled, h->K, f->knn, f->fail, f->stride, f->tq, f->cnt,
+                                                                             f->cand_d, f->cand_i, nullptr);
+    } else {
+        f64_knn_kernel<0><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(f->mid, h->E, h->D, f->sampled, h->K, f->knn, f->fail, 1, nullptr, nullptr,
+                                                                             nullptr, nullptr, nullptr);
+    }
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
@@ -413,7 +646,14 @@ extern "C" gh_status gh_create_f64(gh_handle *out, int device_id, int64_t n, int
         for (int64_t e = 0; e < E; ++e) adj[(size_t)cur[(size_t)edges[2 * e + 1]]++] = edges[2 * e];
     }
     const size_t nD = (size_t)n * D;
-    f->nblocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+    {   // update launches: T = nblocks * 256 threads with T a multiple of D (a thread then stays in one column)
+        int64_t g = 256, dd = D;
+        while (dd) { const int64_t r = g % dd; g = dd; dd = r; }      // gcd(256, D)
+        const int64_t m = D / g;                                      // nblocks must be a multiple of this
+        int64_t nb = std::min<int64_t>(2048, (n * D + 255) / 256);
+        nb = std::max<int64_t>(m, nb / m * m);
+        f->nblocks = (int)nb;
+    }
     gh_status st;
     if ((st = f64_alloc(h, &f->pos, nD)) || (st = f64_alloc(h, &f->nw, nD)) || (st = f64_alloc(h, &f->Fs, nD)) || (st = f64_alloc(h, &f->Fi, nD)) ||
         (st = f64_alloc(h, &f->io, nD)) || (st = f64_alloc(h, &f->mid, (size_t)E * D)) || (st = f64_alloc(h, &f->part, (size_t)2 * f->nblocks * D)) ||
@@ -421,6 +661,15 @@ extern "C" gh_status gh_create_f64(gh_handle *out, int device_id, int64_t n, int
         (st = f64_alloc(h, &f->edges, (size_t)std::max<int64_t>(2 * E, 1))) || (st = f64_alloc(h, &f->sampled, (size_t)std::max<int64_t>(h->S, 1))) ||
         (st = f64_alloc(h, &f->knn, (size_t)std::max<int64_t>(h->S * h->k, 1))) || (st = f64_alloc(h, &f->fail, 1)))
         return bail(st);
+    // the filtered search: from F64_FILTER_MIN_EDGES edges on, while the parked lists stay below 1 GiB.  stride: about 1024
+    // parked midpoints per query (the subset's K-th smallest sits near rank K * stride of all; every parked midpoint is a
+    // returning atomic on its query's counter)
+    if (E >= F64_FILTER_MIN_EDGES && h->S > 0 && h->k > 0 && (size_t)h->S * F64_CAND_CAP * 12 <= ((size_t)1 << 30)) {
+        f->stride = std::min<int64_t>(1024, std::max<int64_t>(16, 1024 / h->K));
+        if ((st = f64_alloc(h, &f->sub, (size_t)((E + f->stride - 1) / f->stride) * D)) || (st = f64_alloc(h, &f->tq, (size_t)h->S)) || (st = f64_alloc(h, &f->cnt, (size_t)h->S * F64_CNT_STRIDE)) ||
+            (st = f64_alloc(h, &f->cand_d, (size_t)h->S * F64_CAND_CAP)) || (st = f64_alloc(h, &f->cand_i, (size_t)h->S * F64_CAND_CAP)))
+            return bail(st);
+    }
     if (hipMemset(f->pos, 0, sizeof(double) * nD) != hipSuccess || hipMemset(f->fail, 0, sizeof(int32_t)) != hipSuccess ||
         hipMemcpy(f->rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(f->adj, adj.data(), sizeof(int32_t) * (size_t)(2 * E), hipMemcpyHostToDevice) != hipSuccess ||

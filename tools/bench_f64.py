@@ -1,4 +1,4 @@
-"""Iteration time of the float64 engine (csrc/f64.hip: plain one-kernel-per-phase code in double, brute-force KNN) on bench
+"""Iteration time of the float64 engine (csrc/f64.hip: plain one-kernel-per-phase code in double; the KNN through a filter from 131072 edges on) on bench
 workloads -- a correctness feature, timed once per round for the record.  python tools/bench_f64.py [workload ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
