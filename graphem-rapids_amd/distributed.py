@@ -14,14 +14,14 @@ most of the edges).  Every rank holds all n positions and the whole edge list.  
     gather  (RCCL)    all-gather of the keys                       S*(k+1)*8 B per rank
     part 2  (local)   merge keys -> global KNN; intersection forces (redundant on every rank,
                       O(S*k)); integrate own rows; own column sums
-  finish="own" (default; nothing passes over all n rows):
+  finish="own" (round 3-4; nothing passes over all n rows, three collectives in a row):
     gather  (RCCL)    all-gather of the ranks' column statistics          18*ld*8 B per rank
     part 3  (local)   normalise the OWN rows into their block of the position array; the per-rank sums
                       are added in rank order, so every rank derives the same mean / std
     gather  (RCCL)    in-place all-gather of the finished position blocks     chunk*D*4 B per rank
                       (without their pad columns when D < ld -- 12 instead of 16 B per row at D = 3 --, then
                       expanded into the position array by gh_step_unpack_rows; chunk*ld*4 B when D == ld)
-  finish="overlap" (round 5, form D; what bench.py --gpus N runs): the LAST collective of finish="gathered" moved to the front
+  finish="overlap" (default; round 5, form D): the LAST collective of finish="gathered" moved to the front
     part 1  (local)   as above; the fused kernel leaves new0 = pos + Fs of the own rows in this rank's block
     gather  (RCCL, 2nd stream + 2nd group)   all-gather of the new0 blocks (chunk*D*4 B per rank) -- IN FLIGHT while
     gather  (RCCL)    all-gather of the keys
@@ -215,7 +215,7 @@ class HipShardEngine:
 class PartitionedLayout:
     def __init__(self, n, D, edges, L_min=1.0, k_attr=0.2, k_inter=0.5, n_neighbors=10, sample_size=256, seed=0,
                  rank=None, world=None, device_id=0, engine_factory=None, group=None, edge_ownership="auto", native=False,
-                 finish="own", knn_distance="exact"):
+                 finish="overlap", knn_distance="exact"):
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.group = group

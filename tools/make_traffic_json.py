@@ -1,7 +1,7 @@
 """Per-launch HBM-side traffic of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE,
 TCC counters), with the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md spelled out.
 Usage: make_traffic_json.py <profile dir made by tools/profile_round.sh> <workload> [kernel substring]"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
 root, workload = sys.argv[1], sys.argv[2]
 kernel = sys.argv[3] if len(sys.argv) > 3 else "spring_scan"
 vals = collections.defaultdict(list)
@@ -14,6 +14,7 @@ mean = {k: (lambda x: sum(x[len(x) // 2:]) / len(x[len(x) // 2:]))(v) for k, v i
 fetch_kb, write_kb = mean.get("FETCH_SIZE", 0.0), mean.get("WRITE_SIZE", 0.0)
 out = {
     "workload": workload, "kernel": kernel,
+    "commit": os.environ.get("GRAPHEM_COMMIT"),   # the commit the profiled tree was built from (handed in by the caller: the GPU box has no .git)
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), mean per launch; tools/profile_round.sh",
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "traffic_bytes_uncorrected": (fetch_kb + write_kb) * 1024.0,
