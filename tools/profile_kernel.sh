@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p "$ROOT/$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace" -- \
-    python3 "$ROOT/bench.py" --workload "$WL" $EXTRA --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-parity-mode > "$ROOT/$OUT/bench_under_rocprof.json" 2> "$ROOT/$OUT/bench_under_rocprof.err"
+    python3 "$ROOT/bench.py" --workload "$WL" $EXTRA --steps 30 --warmup 5 --repeats 1 --no-cpu-baseline --no-parity-mode --no-public-api > "$ROOT/$OUT/bench_under_rocprof.json" 2> "$ROOT/$OUT/bench_under_rocprof.err"
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 600 rocprofv3 --pmc $c --output-format csv -d "$ROOT/$OUT/pmc_$c" -- \
         python3 "$ROOT/tools/run_knn_only.py" "$WL" 8 run $EXTRA > /dev/null 2>&1
