@@ -29,7 +29,7 @@ SYMBOLS = [
     "gh_create_f64", "gh_set_positions_f64", "gh_get_positions_f64", "gh_positions_device_f64", "gh_spring_forces_f64",
     "gh_intersection_forces_f64", "gh_trlan_sweep", "gh_knn_ivf_config", "gh_knn_ivf_list_sizes",
     "gh_torch_randperm_prefix", "gh_torch_randperm_isa", "gh_run_torch_sampled", "gh_set_cdist_replay", "gh_sampler_stats",
-    "gh_overlap_layout", "gh_rows_all_device", "gh_rows_all_row_floats", "gh_stats_all_device", "gh_step_rows_early",
+    "gh_overlap_layout", "gh_rows_all_device", "gh_rows_all_row_floats", "gh_stats_all_device", "gh_stats_all_block_doubles", "gh_step_rows_early",
     "gh_step_pack_rows", "gh_step_finish_overlap",
 ]
 
@@ -111,6 +111,8 @@ def load():
     L.gh_rows_all_row_floats.restype = i32
     L.gh_stats_all_device.argtypes = [vp]
     L.gh_stats_all_device.restype = vp
+    L.gh_stats_all_block_doubles.argtypes = [vp]
+    L.gh_stats_all_block_doubles.restype = i64
     L.gh_step_rows_early.argtypes = [vp]
     L.gh_step_rows_early.restype = i32
     L.gh_step_pack_rows.argtypes = [vp, vp, i32]
@@ -423,6 +425,9 @@ class Engine:
 
     def stats_all_device_ptr(self):
         return self.lib.gh_stats_all_device(self.handle)
+
+    def stats_all_block_doubles(self):
+        return int(self.lib.gh_stats_all_block_doubles(self.handle))
 
     def step_rows_early(self):
         return bool(self.lib.gh_step_rows_early(self.handle))

@@ -1101,16 +1101,21 @@ extern "C" gh_status gh_overlap_layout(gh_handle h, int32_t world, int32_t rank,
         return GH_ERR_INVALID;
     }
     if (h->d_gbuf || h->g_world) { h->err = "rank / gather layout already set"; return GH_ERR_INVALID; }
+    if (h->LD > 16) { h->err = "gh_overlap_layout: up to 16 components (use gh_rank_layout / gh_gather_layout beyond)"; return GH_ERR_INVALID; }
     const size_t R = (size_t)(2 + 2 * gh_fix_blocks(h->LD));
+    // a rank's block of the late all-gather: statistics rows, 16 bytes for the patch count, the patch records
+    h->patch_cap = std::max<int64_t>(1, std::min<int64_t>(4 * h->S * h->k, chunk));
+    h->stats_block = (int64_t)(R * h->LD) + 2 + ((int64_t)h->patch_cap * (1 + h->LD) * 4 + 7) / 8;
+    h->stats_block = (h->stats_block + 1) / 2 * 2;   // 16-byte multiples
     GH_HIP(hipStreamSynchronize(h->stream));
     GH_TRY(dev_alloc(h, &h->d_rows_all, (size_t)world * chunk * h->LD, true));
-    GH_TRY(dev_alloc(h, &h->d_stats_all, (size_t)world * R * h->LD, true));
+    GH_TRY(dev_alloc(h, &h->d_stats_all, (size_t)world * (size_t)h->stats_block, true));
     if (h->D < h->LD && world > 1) GH_TRY(dev_alloc(h, &h->d_rows_pk, (size_t)world * chunk * h->D, true));
     GH_HIP(hipStreamSynchronize(h->stream));
     h->d_new_own = h->d_new;
     h->d_stats_own = h->d_stats;
     h->d_new = h->d_rows_all + (size_t)rank * chunk * h->LD;
-    h->d_stats = h->d_stats_all + (size_t)rank * R * h->LD;
+    h->d_stats = h->d_stats_all + (size_t)rank * (size_t)h->stats_block;
     h->g_chunk = chunk; h->g_world = world; h->g_rank = rank;
     h->overlap = true;
     return GH_OK;
@@ -1118,6 +1123,7 @@ extern "C" gh_status gh_overlap_layout(gh_handle h, int32_t world, int32_t rank,
 extern "C" float *gh_rows_all_device(gh_handle h) { return !h || !h->overlap ? nullptr : h->d_rows_pk ? h->d_rows_pk : h->d_rows_all; }
 extern "C" int32_t gh_rows_all_row_floats(gh_handle h) { return !h || !h->overlap ? 0 : h->d_rows_pk ? h->D : h->LD; }
 extern "C" double *gh_stats_all_device(gh_handle h) { return h && h->overlap ? h->d_stats_all : nullptr; }
+extern "C" int64_t gh_stats_all_block_doubles(gh_handle h) { return h && h->overlap ? h->stats_block : 0; }
 extern "C" int32_t gh_step_rows_early(gh_handle h) { return h && h->overlap && h->rows_early ? 1 : 0; }
 extern "C" gh_status gh_step_pack_rows(gh_handle h, void *hip_stream, int32_t use_engine_stream) {
     GH_TRY(check_handle(h));
@@ -1127,7 +1133,7 @@ extern "C" gh_status gh_step_pack_rows(gh_handle h, void *hip_stream, int32_t us
 extern "C" gh_status gh_step_finish_overlap(gh_handle h) {
     GH_TRY(check_handle(h));
     if (!h->overlap) { h->err = "gh_overlap_layout has not been called"; return GH_ERR_INVALID; }
-    if (h->rows_early) GH_TRY(gh_launch_patch_rows(h));   // (a late step's rows travelled with their intersection forces in them)
+    GH_TRY(gh_launch_patch_rows(h));
     GH_TRY(gh_launch_normalise_gathered(h, h->last_step_own_ids ? (h->S >= h->E ? 2 : 1) : -1));
     h->rows_early = false;
     h->iter += 1;

@@ -293,7 +293,7 @@ extern "C" gh_status gh_run_partitioned(gh_handle h, int32_t iters, const int32_
                     GH_TRY_ST(gh_launch_pack_rows(h, h->stream));
                     GH_TRY_ST(comm_all_gather(h, rows + (size_t)c->rank * block, rows, block, "allgather_rows"));
                 }
-                GH_TRY_ST(comm_all_gather(h, h->d_stats, h->d_stats_all, stats_bytes, "allgather_stats"));
+                GH_TRY_ST(comm_all_gather(h, h->d_stats, h->d_stats_all, sizeof(double) * (size_t)h->stats_block, "allgather_stats"));   // statistics + patch list
                 if (early && side) {   // what of the early all-gather is still outstanding is this iteration's EXPOSED collective time
                     gh_scope t(h, "allgather_rows_exposed");
                     if (hipStreamWaitEvent(h->stream, c->ev_rows, 0) != hipSuccess) { h->err = "hipStreamWaitEvent failed"; return GH_ERR_HIP; }

@@ -141,7 +141,11 @@ struct gh_engine {
     bool rows_early = false;          // this step: new0 of the own rows is in its block (the rows may travel right after step_begin)
     float *d_rows_all = nullptr;      // (world, chunk, LD): d_new is block g_rank of it
     float *d_rows_pk = nullptr;       // (world, chunk, D): the same without pad columns -- what travels when D < LD -- or null
-    double *d_stats_all = nullptr;    // (world, stats rows, LD): d_stats is block g_rank of it
+    double *d_stats_all = nullptr;    // (world, stats_block) doubles: per rank its statistics rows, then its PATCH LIST -- an int32 count (16 bytes
+                                      // reserved) and patch_cap records (row as int32 bits, LD floats): the own rows the intersection phase touched, as
+                                      // finished by their owner, pos + (Fs + Fi); d_stats is block g_rank of it
+    int64_t stats_block = 0;          // doubles per rank in d_stats_all
+    int64_t patch_cap = 0;            // records per rank: min(4 S k, chunk)
     int32_t *d_qexact = nullptr;  // [0] = count, [1..] = queries outside the f16 range (scanned exactly)
     uint64_t *d_cand = nullptr;   // (S, GH_CAND_CAP)
     int32_t *d_cnt = nullptr;     // (S * GH_CNT_STRIDE) one counter per 128-byte line
@@ -275,6 +279,8 @@ gh_status gh_launch_unpack_rows(gh_engine *h);   // form C: the gathered packed 
 struct gh_long_args;
 gh_long_args gh_make_long_args(const gh_engine *h, bool coop_mid = false);   // common.h; coop_mid: fused kernels
 gh_status gh_launch_spring_long(gh_engine *h, float *outF, int64_t f_row0);  // spring forces of the hub rows  // gathered slots of every rank -> all n rows of d_pos
+inline int32_t *gh_patch_count(gh_engine *h) { return reinterpret_cast<int32_t *>(h->d_stats + (size_t)(2 + 2 * gh_fix_blocks(h->LD)) * h->LD); }
+inline float *gh_patch_records(gh_engine *h) { return reinterpret_cast<float *>(gh_patch_count(h) + 4); }
 gh_status gh_launch_new0(gh_engine *h);                            // form D without the fused kernel: d_new = pos + Fs of the own rows
 gh_status gh_launch_pack_rows(gh_engine *h, hipStream_t stream);   // form D: own block of new0 -> its packed slot (on the given stream)
 gh_status gh_launch_patch_rows(gh_engine *h);                      // form D: touched rows of the gathered array += Fi; accumulators zeroed

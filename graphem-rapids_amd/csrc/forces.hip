@@ -125,14 +125,29 @@ __global__ __launch_bounds__(256) void long_sum_kernel(const float *__restrict__
     }
 }
 
+// Form D of a partitioned step: the finished value of an own row the intersection phase touched, pos + (Fs + Fi), goes
+// into the rank's patch list -- (row, LD floats) records behind the statistics, all-gathered with them -- because the row
+// itself left as pos + Fs before Fi was known.  One returning atomic per touched own row (a few thousand per iteration).
+template <int LD>
+__device__ __forceinline__ void gh_patch_append(int32_t *count, float *rows, int cap, int64_t x, const float (&nw)[LD]) {
+    const int slot = atomicAdd(count, 1);
+    if (slot < cap) {
+        float *rec = rows + (int64_t)slot * (1 + LD);
+        rec[0] = __int_as_float((int)x);
+#pragma unroll
+        for (int d = 0; d < LD; ++d) rec[1 + d] = nw[d];
+    }
+}
+
 // Combine (pt.py:796-799): new = pos + (F_spring + F_inter) for the own rows, plus the
 // per-workgroup column sums / sums of squares in fp64.  Streaming, one thread per row.
 template <int LD>
 __global__ __launch_bounds__(256) void integrate_kernel(
     const float *__restrict__ pos, const float *__restrict__ Fs, int64_t row_lo, int64_t rows,
     const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out,
-    double *__restrict__ blockstats, int sum_first = 0 /* form D: new = fl(pos + Fs) + Fi, the rows themselves are already
-    travelling as pos + Fs (new0_kernel): statistics only, nothing stored */) {
+    double *__restrict__ blockstats, int32_t *__restrict__ patch_count = nullptr /* form D: the rows are already travelling as
+    pos + Fs (new0_kernel); a touched row's value goes into the rank's patch list (gh_patch_append) instead of `out` */,
+    float *__restrict__ patch_rows = nullptr, int patch_cap = 0) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     double sx[LD], sxx[LD];
 #pragma unroll
@@ -147,11 +162,12 @@ __global__ __launch_bounds__(256) void integrate_kernel(
         for (int d = 0; d < LD; ++d) {
             const float fi = touched ? (float)acc[x * LD + d] : 0.0f;
             const float tot = F[d] + fi;
-            nw[d] = sum_first ? (px[d] + F[d]) + fi : px[d] + tot;
+            nw[d] = px[d] + tot;
             sx[d] = (double)nw[d];
             sxx[d] = (double)nw[d] * (double)nw[d];
         }
-        if (!sum_first) gh_store_row<LD>(out, i, nw);
+        if (!patch_count) gh_store_row<LD>(out, i, nw);
+        else if (touched) gh_patch_append<LD>(patch_count, patch_rows, patch_cap, x, nw);
     }
     __shared__ double red[4][2 * LD];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -170,14 +186,14 @@ __global__ __launch_bounds__(256) void integrate_kernel(
 // Any LD: new = pos + (Fs + Fi), one thread per element (statistics by column_stats_kernel).
 __global__ __launch_bounds__(256) void integrate_generic_kernel(
     const float *__restrict__ pos, const float *__restrict__ Fs, int LD, int64_t row_lo, int64_t rows,
-    const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out, int sum_first = 0) {
+    const double *__restrict__ acc, const int32_t *__restrict__ tflag, float *__restrict__ out) {
     const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= rows * LD) return;
     const int64_t x = row_lo + t / LD;
     const int64_t g = row_lo * LD + t;
     const float fi = tflag[x] != 0 ? (float)acc[g] : 0.0f;
     const float tot = Fs[t] + fi;
-    out[t] = sum_first ? (pos[g] + Fs[t]) + fi : pos[g] + tot;
+    out[t] = pos[g] + tot;
 }
 
 // Form D on an engine whose part 1 did not run the fused kernel: new0 = pos + Fs of the own rows, element by element.
@@ -275,9 +291,10 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
                                                        int64_t rows, float *__restrict__ out_new,
                                                        double *__restrict__ stats, int skip_reduce,
                                                        uint64_t *__restrict__ iter_bump /* replayed iterations: the device's iteration counter, or null */,
-                                                       int sum_first = 0 /* form D of a partitioned step (gh_overlap_layout): new0 is already
-                                                       travelling to the other ranks, which patch a touched row as fl(new0 + Fi) -- so does its
-                                                       owner: new = new0 + Fi (not pos + (Fs + Fi): one rounding apart), nothing stored here */) {
+                                                       int32_t *__restrict__ patch_count = nullptr /* form D of a partitioned step
+                                                       (gh_overlap_layout): new0 is already travelling to the other ranks; the corrected
+                                                       rows go into the rank's patch list instead of out_new */,
+                                                       float *__restrict__ patch_rows = nullptr, int patch_cap = 0) {
     __shared__ double red[4][2 * LD];
     if (iter_bump && blockIdx.x == 0 && threadIdx.x == 0) *iter_bump += 1;   // read by the set-up inside the NEXT launch (normalise)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -315,11 +332,12 @@ __global__ __launch_bounds__(256) void stats_fix_kernel(const double *__restrict
         for (int d = 0; d < LD; ++d) {
             const float n0 = p[d] + f[d];
             const float tot = f[d] + (float)acc[x * LD + d];
-            nw[d] = sum_first ? n0 + (float)acc[x * LD + d] : p[d] + tot;
+            nw[d] = p[d] + tot;
             dx[d] += (double)nw[d] - (double)n0;
             dxx[d] += (double)nw[d] * (double)nw[d] - (double)n0 * (double)n0;
         }
-        if (!sum_first) gh_store_row<LD>(out_new, i, nw);
+        if (!patch_count) gh_store_row<LD>(out_new, i, nw);
+        else gh_patch_append<LD>(patch_count, patch_rows, patch_cap, x, nw);
     }
 #pragma unroll
     for (int d = 0; d < LD; ++d) {
@@ -901,7 +919,8 @@ gh_status gh_launch_integrate(gh_engine *h) {
 #define GH_FIX_CASE(LL)                                                                                      \
     stats_fix_kernel<LL><<<dim3(gh_fix_blocks(LL)), dim3(256), 0, h->stream>>>(                                  \
         h->d_blockstats, h->n_vblocks, h->d_pos, h->d_Fs, h->d_acc, h->d_touched, h->d_tcount, h->part.row_lo, \
-        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0, h->graph_capturing ? h->d_iter : nullptr, h->rows_early ? 1 : 0)
+        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0, h->graph_capturing ? h->d_iter : nullptr, h->overlap ? gh_patch_count(h) : nullptr, \
+        h->overlap ? gh_patch_records(h) : nullptr, (int)h->patch_cap)
         if (h->LD == 4) GH_FIX_CASE(4);
         else if (h->LD == 8) GH_FIX_CASE(8);
         else GH_FIX_CASE(16);
@@ -917,28 +936,30 @@ gh_status gh_launch_integrate(gh_engine *h) {
         return GH_OK;
     }
     const unsigned grid = grid_for(h->rows, 256);
-    // form D: the own block (d_new) holds new0 and is on its way to the other ranks: statistics of fl(new0 + Fi) only; a row
-    // stride without a templated kernel keeps the rows it sums in scratch
-    const int sf = h->overlap ? 1 : 0;
-    float *wide_out = sf ? h->d_tmpF : h->d_new;
+    // form D: the own block (d_new) holds new0 and is on its way to the other ranks: statistics as always, the touched rows'
+    // values into the patch list (row strides of 4, 8, 16 floats: gh_overlap_layout refuses the others)
+    int32_t *pc = h->overlap ? gh_patch_count(h) : nullptr;
+    float *pr = h->overlap ? gh_patch_records(h) : nullptr;
+    const int pcap = (int)h->patch_cap;
+    float *wide_out = h->d_new;
     {
         gh_scope t(h, "integrate");
         switch (h->LD) {
             case 4:
                 integrate_kernel<4><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
-                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, sf);
+                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, pc, pr, pcap);
                 break;
             case 8:
                 integrate_kernel<8><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
-                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, sf);
+                                                                            h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, pc, pr, pcap);
                 break;
             case 16:
                 integrate_kernel<16><<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_pos, h->d_Fs, h->part.row_lo, h->rows,
-                                                                             h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, sf);
+                                                                             h->d_acc, h->d_tflag, h->d_new, h->d_blockstats, pc, pr, pcap);
                 break;
             default:
                 integrate_generic_kernel<<<dim3(grid_for(h->rows * h->LD, 256)), dim3(256), 0, h->stream>>>(
-                    h->d_pos, h->d_Fs, h->LD, h->part.row_lo, h->rows, h->d_acc, h->d_tflag, wide_out, sf);
+                    h->d_pos, h->d_Fs, h->LD, h->part.row_lo, h->rows, h->d_acc, h->d_tflag, wide_out);
         }
         GH_LAUNCH_CHECK();
     }
@@ -964,7 +985,7 @@ gh_status gh_launch_intersect(gh_engine *h) {
     const int64_t P = h->S * h->k;
     if (P == 0) return GH_OK;
     // a row partition accumulates only what lands on its own rows
-    const bool own_only = h->rows != h->n && !h->overlap;   // (form D: every rank patches every touched row)
+    const bool own_only = h->rows != h->n;
     const int32_t own_lo = own_only ? (int32_t)h->part.row_lo : 0, own_hi = own_only ? (int32_t)h->part.row_hi : 0x7FFFFFFF;
     gh_scope t(h, "intersect");
 #define GH_INTER_ONE(DD, LL)                                                                                       \
@@ -1127,7 +1148,7 @@ gh_status gh_launch_normalise_gathered(gh_engine *h, int next_mode) {
     const int RS = h->overlap && h->d_rows_pk ? h->D : h->LD;
     const int64_t rows_block = h->overlap ? h->g_chunk * RS : h->g_slot / (int64_t)sizeof(float);
     const double *stats_base = h->overlap ? h->d_stats_all : reinterpret_cast<const double *>(h->d_gbuf + h->g_chunk * h->LD * (int64_t)sizeof(float));
-    const int64_t stats_block = h->overlap ? (int64_t)(2 + 2 * gh_fix_blocks(h->LD)) * h->LD : h->g_slot / (int64_t)sizeof(double);
+    const int64_t stats_block = h->overlap ? h->stats_block : h->g_slot / (int64_t)sizeof(double);
     const int skip_cleanup = h->overlap && h->rows_early ? 1 : 0;
 #define GH_NORMG(LL)                                                                                              \
     normalise_gathered_kernel<LL><<<dim3(grid + extra), dim3(256), smem, h->stream>>>(                                   \
@@ -1176,28 +1197,46 @@ gh_status gh_launch_pack_rows(gh_engine *h, hipStream_t stream) {
     GH_LAUNCH_CHECK();
     return GH_OK;
 }
-// After the all-gather of the new0 blocks: every row the intersection phase touched, on whichever rank it lives,
-// becomes fl(new0 + Fi) in the gathered array (the expression its owner's statistics used), and the accumulators are zeroed.
+// After both all-gathers: every rank's patch list -- the rows its intersection phase touched, as their owner finished them
+// (pos + (Fs + Fi), the single engine's expression) -- is written over those rows of the gathered new0 array; the own
+// accumulators are zeroed and the own list is emptied for the next iteration.
 __global__ __launch_bounds__(256) void patch_rows_kernel(float *__restrict__ rows /* (world * chunk, RS) */, int RS, int D, int LD,
+                                                        double *__restrict__ stats_all, int64_t stats_block, int stat_doubles,
+                                                        int world, int rank, int cap,
                                                         double *__restrict__ acc, int32_t *__restrict__ tflag,
                                                         const int32_t *__restrict__ touched, const int32_t *__restrict__ tcount) {
+    const int64_t T = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int r = 0; r < world; ++r) {
+        const int32_t *hdr = reinterpret_cast<const int32_t *>(stats_all + (int64_t)r * stats_block + stat_doubles);
+        const float *rec = reinterpret_cast<const float *>(hdr + 4);
+        const int64_t cnt = min(hdr[0], cap);
+        for (int64_t t = t0; t < cnt * D; t += T) {
+            const int64_t j = t / D;
+            const int d = (int)(t % D);
+            const int64_t x = __float_as_int(rec[j * (1 + LD)]);
+            rows[x * RS + d] = rec[j * (1 + LD) + 1 + d];
+        }
+    }
     const int64_t nt = (int64_t)(*tcount) * LD;
-    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < nt; t += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t t = t0; t < nt; t += T) {
         const int64_t x = touched[t / LD];
         const int d = (int)(t % LD);
-        if (d < D) rows[x * RS + d] = rows[x * RS + d] + (float)acc[x * LD + d];
         acc[x * LD + d] = 0.0;
         if (d == 0) tflag[x] = 0;
     }
 }
+// (the own list's counter: emptied by a one-thread launch BEHIND the patch launch -- every workgroup of that one reads it)
+__global__ void patch_reset_kernel(int32_t *count) { *count = 0; }
 gh_status gh_launch_patch_rows(gh_engine *h) {
-    const int64_t maxT = 4 * h->S * h->k * h->LD;
-    if (maxT == 0) return GH_OK;
     gh_scope t(h, "patch_rows");
+    const int64_t maxT = std::max<int64_t>(4 * h->S * h->k * h->LD, 256);
     unsigned grid = grid_for(maxT, 256);
     if (grid > 256) grid = 256;
+    const int stat_doubles = (2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
     patch_rows_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_rows_pk ? h->d_rows_pk : h->d_rows_all, h->d_rows_pk ? h->D : h->LD, h->D, h->LD,
+                                                               h->d_stats_all, h->stats_block, stat_doubles, h->g_world, h->g_rank, (int)h->patch_cap,
                                                                h->d_acc, h->d_tflag, h->d_touched, h->d_tcount);
+    patch_reset_kernel<<<dim3(1), dim3(1), 0, h->stream>>>(gh_patch_count(h));
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

@@ -255,8 +255,7 @@ inline inter_args make_inter_args(gh_engine *h, bool on) {
     if (on) {
         ia = inter_args{h->d_pos, h->d_edges, h->d_sampled_cur, h->D, h->LD, h->k, h->prm.k_inter,
                         h->d_acc, h->d_tflag, h->d_touched, h->d_tcount, h->d_iscratch};
-        // (form D, gh_overlap_layout: every rank patches every touched row itself -- all contributions everywhere)
-        if (h->rows != h->n && !h->overlap) { ia.own_lo = (int32_t)h->part.row_lo; ia.own_hi = (int32_t)h->part.row_hi; }
+        if (h->rows != h->n) { ia.own_lo = (int32_t)h->part.row_lo; ia.own_hi = (int32_t)h->part.row_hi; }
     }
     return ia;
 }

@@ -25,9 +25,11 @@ most of the edges).  Every rank holds all n positions and the whole edge list.  
     part 1  (local)   as above; the fused kernel leaves new0 = pos + Fs of the own rows in this rank's block
     gather  (RCCL, 2nd stream + 2nd group)   all-gather of the new0 blocks (chunk*D*4 B per rank) -- IN FLIGHT while
     gather  (RCCL)    all-gather of the keys
-    part 2  (local)   merge; intersection forces of ALL rows on every rank; own corrections to the statistics
-    gather  (RCCL)    all-gather of the statistics
-    part 3  (local)   wait for the rows; touched rows := new0 + Fi; normalise ALL n rows (next set-up in the same launch)
+    part 2  (local)   merge; intersection forces; own corrections to the statistics; the finished values of the own touched
+                      rows (pos + (Fs + Fi), <= 4*S*k of them) into the rank's patch list, behind its statistics
+    gather  (RCCL)    all-gather of statistics + patch lists                    ~ (18*ld*8 + min(4*S*k, chunk)*(1+ld)*4) B per rank
+    part 3  (local)   wait for the rows; every rank's patch list over the gathered rows; normalise ALL n rows (next set-up in
+                      the same launch)
   finish="gathered" (two collectives, every rank normalises all n rows -- 22-51 us per rank at 1 M vertices):
     gather  (RCCL)    in-place all-gather of slots [un-normalised rows | statistics]
     part 3  (local)   normalise ALL n rows from the gathered slots
@@ -155,8 +157,9 @@ class HipShardEngine:
         self.world, self.rank, self.chunk = world, rank, chunk
         rf = e.rows_all_row_floats()
         self.rows_all = device_view(e.rows_all_device_ptr(), (world, chunk * rf), torch.float32, self.device, e)
-        self.stats_all = device_view(e.stats_all_device_ptr(), (world, e.stats_rows() * e.ld), torch.float64, self.device, e)
-        self.stats = self.stats_all[rank].view(e.stats_rows(), e.ld)
+        # a rank's block: its statistics rows, then its patch list (the own rows the intersection phase touched, finished)
+        self.stats_all = device_view(e.stats_all_device_ptr(), (world, e.stats_all_block_doubles()), torch.float64, self.device, e)
+        self.stats = self.stats_all[rank]
         self.side = torch.cuda.Stream(self.device)
 
     def step_rows_early(self):

@@ -289,28 +289,31 @@ gh_status gh_step_finish_gathered(gh_handle h);
  * off after gh_rank_layout.  gh_rows_packed_device() is NULL while it is not in use (D == ld, world == 1, switched off):
  * the caller then all-gathers the position blocks in place. */
 gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk);
-/* Part 3, form D (round 5; the default of bench.py --gpus N): form B's finish -- every rank normalises ALL n rows from the
- * ranks' gathered un-normalised rows, no collective after the normalisation -- with the big collective moved to the FRONT of
- * the KNN tail.  The fused spring+scan kernel of part 1 leaves new0 = pos + Fs of the own rows in block `rank` of a
- * (world, chunk, ld) array; when gh_step_rows_early() says so after gh_step_begin, the caller starts the all-gather of
- * those blocks at once, on a second stream / communicator, and runs select -> all-gather of the keys -> gh_step_merge
- * (merge, intersection -- every rank accumulates the contributions to ALL rows --, corrections of the own touched rows to
- * the statistics) -> all-gather of the statistics beside it.  gh_step_finish_overlap (enqueued behind BOTH collectives)
- * then patches every touched row of the gathered array, wherever it lives, as fl(new0 + Fi) -- the expression its owner's
- * statistics used; one rounding away from the single engine's pos + (Fs + Fi) -- and normalises all n rows into the
- * position array (the next iteration's KNN set-up rides in that launch).  What travels:
+/* Part 3, form D (round 5; the default of bench.py --gpus N and of distributed.PartitionedLayout): form B's finish -- every
+ * rank normalises ALL n rows from the ranks' gathered un-normalised rows, no collective after the normalisation -- with the
+ * big collective moved to the FRONT of the KNN tail.  Part 1 leaves new0 = pos + Fs of the own rows in block `rank` of a
+ * (world, chunk, ld) array (the fused spring+scan kernel writes it; a rank too small for that kernel makes it with a launch
+ * of its own, so every rank sends at the same point: gh_step_rows_early() is 1 after every gh_step_begin); the caller
+ * starts the all-gather of those blocks at once, on a second stream / communicator, and runs select -> all-gather of the
+ * keys -> gh_step_merge -> all-gather of the statistics beside it.  Only the <= 4 S k rows the intersection phase touches
+ * differ from new0 afterwards: gh_step_merge puts the finished value of every OWN touched row -- pos + (Fs + Fi), the single
+ * engine's expression -- into the rank's PATCH LIST, which sits behind its statistics and travels with them.
+ * gh_step_finish_overlap (enqueued behind BOTH collectives) writes every rank's patch list over those rows of the gathered
+ * array and normalises all n rows into the position array (the next iteration's KNN set-up rides in that launch).  Results:
+ * what forms B / C give (the single engine's up to the order in which the ranks' statistics are added).  What travels:
  *   gh_rows_all_device()      (world, chunk, gh_rows_all_row_floats()) floats, block r = rank r's rows: WITHOUT pad columns
  *                             when n_components < ld and world > 1 (row_floats = n_components; the own block is put there
  *                             by gh_step_pack_rows on the stream given -- call it on the side stream before the all-gather;
  *                             a no-op otherwise), else the (world, chunk, ld) array itself;
- *   gh_stats_all_device()     (world, gh_stats_rows, ld) doubles, block r = rank r's statistics (= gh_stats_partial_device()).
- * A rank whose part 1 does not run the fused kernel (too few own edges) writes new0 with a launch of its own, so that every
- * rank sends at the same point of the iteration: gh_step_rows_early() is 1 after every gh_step_begin of a form-D engine
- * (callers written against 0 -- rows after gh_step_merge, form B's order -- stay correct: nothing is patched then). */
+ *   gh_stats_all_device()     (world, gh_stats_all_block_doubles()) doubles, block r = rank r's statistics rows
+ *                             (= gh_stats_partial_device(), gh_stats_rows * ld doubles), then 16 bytes holding its patch
+ *                             count (int32) and min(4 S k, chunk) records of (row as int32, ld floats).
+ * Up to 16 components. */
 gh_status gh_overlap_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk);
 float *gh_rows_all_device(gh_handle h);
 int32_t gh_rows_all_row_floats(gh_handle h);
 double *gh_stats_all_device(gh_handle h);
+int64_t gh_stats_all_block_doubles(gh_handle h);
 int32_t gh_step_rows_early(gh_handle h);
 gh_status gh_step_pack_rows(gh_handle h, void *hip_stream, int32_t use_engine_stream);
 gh_status gh_step_finish_overlap(gh_handle h);

@@ -45,13 +45,16 @@ class CpuShardEngine:
         self.pos_blocks = self.pos[: world * chunk].view(world, chunk * self.ld)
 
     def overlap_layout(self, world, rank, chunk):
-        """finish="overlap" (form D): new0 = pos + Fs blocks gathered early, statistics late (HipShardEngine.overlap_layout).
-        Rows travel without pad columns when D < ld and world > 1, like the HIP engine's."""
+        """finish="overlap" (form D): new0 = pos + Fs blocks gathered early; statistics + patch list late
+        (HipShardEngine.overlap_layout).  Rows travel without pad columns when D < ld and world > 1, like the HIP engine's.
+        A rank's late block: (2, ld) statistics, a count, then up to `cap` records (row, D values) -- the own rows the
+        intersection phase touched, finished as pos + (Fs + Fi)."""
         self.world, self.rank, self.chunk = world, rank, chunk
         self.rf = self.D if (self.D < self.ld and world > 1) else self.ld
         self.rows_all = torch.zeros((world, chunk * self.rf), dtype=torch.float32)
-        self.stats_all = torch.zeros((world, 2 * self.ld), dtype=torch.float64)
-        self.stats = self.stats_all[rank].view(2, self.ld)
+        self.cap = max(1, min(4 * self.S * self.k, chunk))
+        self.stats_all = torch.zeros((world, 2 * self.ld + 1 + self.cap * (1 + self.D)), dtype=torch.float64)
+        self.stats = self.stats_all[rank]
         self.overlap = True
 
     def step_rows_early(self):
@@ -61,14 +64,16 @@ class CpuShardEngine:
         pass   # (step_begin wrote the own block in its travelling form)
 
     def step_finish_overlap(self):
-        """Touched rows := fl(new0 + Fi) on every rank alike, then all n rows normalised from the ranks' statistics."""
+        """Every rank's patch list over the gathered new0 rows, then all n rows normalised from the ranks' statistics."""
         n, D = self.n, self.D
         rows = self.rows_all.numpy().reshape(self.world * self.chunk, self.rf)[:n, :D].copy()
-        t = self.touched
-        rows[t] = rows[t] + self.Fi_all[t]
         tot = np.zeros((2, self.ld))
         for r in range(self.world):
-            tot += self.stats_all[r].numpy().reshape(2, self.ld)
+            blk = self.stats_all[r].numpy()
+            tot += blk[: 2 * self.ld].reshape(2, self.ld)
+            cnt = int(blk[2 * self.ld])
+            rec = blk[2 * self.ld + 1: 2 * self.ld + 1 + cnt * (1 + D)].reshape(cnt, 1 + D)
+            rows[rec[:, 0].astype(np.int64)] = rec[:, 1:].astype(np.float32)
         mean = tot[0, :D] / n
         var = np.maximum((tot[1, :D] - tot[0, :D] * mean) / (n - 1), 0.0)
         sd = np.sqrt(var).astype(np.float32) + np.float32(1e-6)
@@ -160,16 +165,20 @@ class CpuShardEngine:
             g = np.sort(g, axis=1)[:, : self.k + 1]
             knn = (g[:, 1:] & 0xFFFFFFFF).astype(np.int32)               # drop column 0 (pt.py:421)
         Fi_all = oracle.intersection_forces(p, self.edges, self.sampled, knn, self.prm[2])
-        if self.overlap:   # every rank keeps Fi of ALL rows; the own touched rows enter the statistics as fl(new0 + Fi)
-            self.Fi_all = Fi_all
-            self.touched = np.nonzero((Fi_all != 0).any(axis=1))[0]
-            new = self.new0 + Fi_all[self.row_lo:self.row_hi]
+        Fi = Fi_all[self.row_lo:self.row_hi]
+        if self.overlap:   # the own rows' finished values pos + (Fs + Fi): statistics, and the touched ones into the patch list
+            new = p[self.row_lo:self.row_hi] + (self.Fs + Fi)
             st = np.zeros((2, self.ld))
             st[0, : self.D] = new.astype(np.float64).sum(0)
             st[1, : self.D] = (new.astype(np.float64) ** 2).sum(0)
-            self.stats[:] = torch.from_numpy(st)
+            own_touched = np.nonzero((Fi != 0).any(axis=1))[0]
+            assert len(own_touched) <= self.cap
+            blk = self.stats.numpy()
+            blk[: 2 * self.ld] = st.reshape(-1)
+            blk[2 * self.ld] = len(own_touched)
+            rec = np.concatenate([(own_touched + self.row_lo)[:, None].astype(np.float64), new[own_touched].astype(np.float64)], axis=1)
+            blk[2 * self.ld + 1: 2 * self.ld + 1 + rec.size] = rec.reshape(-1)
             return
-        Fi = Fi_all[self.row_lo:self.row_hi]
         tot = self.Fs + Fi
         self.new = p[self.row_lo:self.row_hi] + tot
         st = np.zeros((2, self.ld))

@@ -315,8 +315,8 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D, finish):
         for sh in shards:
             sh.step_begin(stream[t])
         if finish == "overlap":
-            # form D: the new0 blocks travel FIRST (when the fused kernel made them), then keys, merge, statistics; every rank
-            # patches the touched rows and normalises all n rows
+            # form D: the new0 blocks travel FIRST, then keys, merge, statistics + patch lists (the owners' finished touched
+            # rows); every rank writes the patch lists over the gathered rows and normalises all n rows
             def exchange_rows():
                 for sh in shards:
                     sh.step_pack_rows()
@@ -362,9 +362,7 @@ def test_partitioned_engines_equal_single_engine(world, rule, n, D, finish):
             sh.gbuf.copy_(slots)
             sh.step_finish_gathered()
     torch.cuda.synchronize()
-    # form D patches a touched row as fl(new0 + Fi) on every rank (its new0 is already travelling when Fi becomes known), the
-    # single engine computes pos + (Fs + Fi): one rounding apart on <= 4 S k rows per iteration (3.1e-6 after three iterations)
-    tol = 1e-5 if finish == "overlap" else 2e-6
+    tol = 2e-6
     for sh in shards:
         got = sh.get_positions()
         assert np.abs(got - ref).max() <= tol
@@ -428,7 +426,7 @@ def test_rccl_driver_single_rank():
     finally:
         dist.destroy_process_group()
     for key, val in got.items():
-        assert np.abs(val - ref).max() <= (1e-5 if key[1] == "overlap" else 2e-6), key
+        assert np.abs(val - ref).max() <= 2e-6, key
     assert np.array_equal(got[True, "own"], got[False, "own"])
     assert np.array_equal(got[True, "gathered"], got[False, "gathered"])
     assert np.array_equal(got[True, "overlap"], got[False, "overlap"])
@@ -495,7 +493,7 @@ def test_native_partitioned_loop_on_the_loopback_backend(world, n, D, finish):
         e.comm_destroy()
         e.close()
     lib.gh_loopback_group_destroy(group)
-    assert np.abs(outs[0] - ref).max() <= (2e-5 if finish == "overlap" else 2e-6)   # (form D: touched rows one rounding apart, five iterations)
+    assert np.abs(outs[0] - ref).max() <= 2e-6
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
 
