@@ -141,7 +141,7 @@ struct gh_engine {
     bool rows_early = false;          // this step: new0 of the own rows is in its block (the rows may travel right after step_begin)
     float *d_rows_all = nullptr;      // (world, chunk, LD): d_new is block g_rank of it
     float *d_rows_pk = nullptr;       // (world, chunk, D): the same without pad columns -- what travels when D < LD -- or null
-    double *d_stats_all = nullptr;    // (world, stats_block) doubles: per rank its statistics rows, then its PATCH LIST -- an int32 count (16 bytes
+    double *d_stats_all = nullptr;    // (world, stats_block) doubles: per rank its statistics rows, then its PATCH LIST -- two int32 counters used by alternate iterations (16 bytes
                                       // reserved) and patch_cap records (row as int32 bits, LD floats): the own rows the intersection phase touched, as
                                       // finished by their owner, pos + (Fs + Fi); d_stats is block g_rank of it
     int64_t stats_block = 0;          // doubles per rank in d_stats_all

@@ -919,7 +919,7 @@ gh_status gh_launch_integrate(gh_engine *h) {
 #define GH_FIX_CASE(LL)                                                                                      \
     stats_fix_kernel<LL><<<dim3(gh_fix_blocks(LL)), dim3(256), 0, h->stream>>>(                                  \
         h->d_blockstats, h->n_vblocks, h->d_pos, h->d_Fs, h->d_acc, h->d_touched, h->d_tcount, h->part.row_lo, \
-        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0, h->graph_capturing ? h->d_iter : nullptr, h->overlap ? gh_patch_count(h) : nullptr, \
+        h->rows, h->d_new, h->d_stats, h->stats_reduced ? 1 : 0, h->graph_capturing ? h->d_iter : nullptr, h->overlap ? gh_patch_count(h) + (h->iter & 1) : nullptr, \
         h->overlap ? gh_patch_records(h) : nullptr, (int)h->patch_cap)
         if (h->LD == 4) GH_FIX_CASE(4);
         else if (h->LD == 8) GH_FIX_CASE(8);
@@ -938,7 +938,7 @@ gh_status gh_launch_integrate(gh_engine *h) {
     const unsigned grid = grid_for(h->rows, 256);
     // form D: the own block (d_new) holds new0 and is on its way to the other ranks: statistics as always, the touched rows'
     // values into the patch list (row strides of 4, 8, 16 floats: gh_overlap_layout refuses the others)
-    int32_t *pc = h->overlap ? gh_patch_count(h) : nullptr;
+    int32_t *pc = h->overlap ? gh_patch_count(h) + (h->iter & 1) : nullptr;   // (two counters, alternate iterations: patch_rows_kernel)
     float *pr = h->overlap ? gh_patch_records(h) : nullptr;
     const int pcap = (int)h->patch_cap;
     float *wide_out = h->d_new;
@@ -1198,25 +1198,28 @@ gh_status gh_launch_pack_rows(gh_engine *h, hipStream_t stream) {
     return GH_OK;
 }
 // After both all-gathers: every rank's patch list -- the rows its intersection phase touched, as their owner finished them
-// (pos + (Fs + Fi), the single engine's expression) -- is written over those rows of the gathered new0 array; the own
-// accumulators are zeroed and the own list is emptied for the next iteration.
+// (pos + (Fs + Fi), the single engine's expression) -- is written over those rows of the gathered new0 array (blockIdx.y =
+// the rank whose list); the own accumulators are zeroed.  The list has TWO counters, used by alternate iterations: this
+// launch reads counter `par` of every rank and zeroes the own OTHER one for the next iteration (no launch of its own, no
+// counter that is read and reset in one launch).
 __global__ __launch_bounds__(256) void patch_rows_kernel(float *__restrict__ rows /* (world * chunk, RS) */, int RS, int D, int LD,
                                                         double *__restrict__ stats_all, int64_t stats_block, int stat_doubles,
-                                                        int world, int rank, int cap,
+                                                        int rank, int cap, int par,
                                                         double *__restrict__ acc, int32_t *__restrict__ tflag,
                                                         const int32_t *__restrict__ touched, const int32_t *__restrict__ tcount) {
     const int64_t T = (int64_t)gridDim.x * blockDim.x, t0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    for (int r = 0; r < world; ++r) {
-        const int32_t *hdr = reinterpret_cast<const int32_t *>(stats_all + (int64_t)r * stats_block + stat_doubles);
-        const float *rec = reinterpret_cast<const float *>(hdr + 4);
-        const int64_t cnt = min(hdr[0], cap);
-        for (int64_t t = t0; t < cnt * D; t += T) {
-            const int64_t j = t / D;
-            const int d = (int)(t % D);
-            const int64_t x = __float_as_int(rec[j * (1 + LD)]);
-            rows[x * RS + d] = rec[j * (1 + LD) + 1 + d];
-        }
+    const int r = blockIdx.y;
+    int32_t *hdr = reinterpret_cast<int32_t *>(stats_all + (int64_t)r * stats_block + stat_doubles);
+    const float *rec = reinterpret_cast<const float *>(hdr + 4);
+    const int64_t cnt = min(hdr[par], cap);
+    for (int64_t t = t0; t < cnt * D; t += T) {
+        const int64_t j = t / D;
+        const int d = (int)(t % D);
+        const int64_t x = __float_as_int(rec[j * (1 + LD)]);
+        rows[x * RS + d] = rec[j * (1 + LD) + 1 + d];
     }
+    if (r != rank) return;
+    if (t0 == 0) hdr[par ^ 1] = 0;
     const int64_t nt = (int64_t)(*tcount) * LD;
     for (int64_t t = t0; t < nt; t += T) {
         const int64_t x = touched[t / LD];
@@ -1225,18 +1228,15 @@ __global__ __launch_bounds__(256) void patch_rows_kernel(float *__restrict__ row
         if (d == 0) tflag[x] = 0;
     }
 }
-// (the own list's counter: emptied by a one-thread launch BEHIND the patch launch -- every workgroup of that one reads it)
-__global__ void patch_reset_kernel(int32_t *count) { *count = 0; }
 gh_status gh_launch_patch_rows(gh_engine *h) {
     gh_scope t(h, "patch_rows");
     const int64_t maxT = std::max<int64_t>(4 * h->S * h->k * h->LD, 256);
     unsigned grid = grid_for(maxT, 256);
-    if (grid > 256) grid = 256;
+    if (grid > 64) grid = 64;
     const int stat_doubles = (2 + 2 * gh_fix_blocks(h->LD)) * h->LD;
-    patch_rows_kernel<<<dim3(grid), dim3(256), 0, h->stream>>>(h->d_rows_pk ? h->d_rows_pk : h->d_rows_all, h->d_rows_pk ? h->D : h->LD, h->D, h->LD,
-                                                               h->d_stats_all, h->stats_block, stat_doubles, h->g_world, h->g_rank, (int)h->patch_cap,
-                                                               h->d_acc, h->d_tflag, h->d_touched, h->d_tcount);
-    patch_reset_kernel<<<dim3(1), dim3(1), 0, h->stream>>>(gh_patch_count(h));
+    patch_rows_kernel<<<dim3(grid, (unsigned)h->g_world), dim3(256), 0, h->stream>>>(
+        h->d_rows_pk ? h->d_rows_pk : h->d_rows_all, h->d_rows_pk ? h->D : h->LD, h->D, h->LD, h->d_stats_all, h->stats_block, stat_doubles,
+        h->g_rank, (int)h->patch_cap, (int)(h->iter & 1), h->d_acc, h->d_tflag, h->d_touched, h->d_tcount);
     GH_LAUNCH_CHECK();
     return GH_OK;
 }

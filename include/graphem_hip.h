@@ -306,8 +306,9 @@ gh_status gh_rank_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk
  *                             by gh_step_pack_rows on the stream given -- call it on the side stream before the all-gather;
  *                             a no-op otherwise), else the (world, chunk, ld) array itself;
  *   gh_stats_all_device()     (world, gh_stats_all_block_doubles()) doubles, block r = rank r's statistics rows
- *                             (= gh_stats_partial_device(), gh_stats_rows * ld doubles), then 16 bytes holding its patch
- *                             count (int32) and min(4 S k, chunk) records of (row as int32, ld floats).
+ *                             (= gh_stats_partial_device(), gh_stats_rows * ld doubles), then 16 bytes holding its two patch
+ *                             counters (int32; iteration t uses counter t & 1, the other is zeroed meanwhile) and
+ *                             min(4 S k, chunk) records of (row as int32, ld floats).
  * Up to 16 components. */
 gh_status gh_overlap_layout(gh_handle h, int32_t world, int32_t rank, int64_t chunk);
 float *gh_rows_all_device(gh_handle h);
