@@ -13,17 +13,22 @@
 //                   rounded distance does not exceed the K-th smallest rounded distance; pass 2 collects those (K plus
 //                   the few that share the last float) and ranks them on (double distance, id).
 //                   From 131072 edges on (round 5) the two passes run over a FILTERED list instead of all E midpoints:
-//                   pass 1 over every stride-th midpoint gives an exclusive bound per query (MODE 1), f64_filter_kernel
-//                   -- reference-major: a workgroup holds 1024 midpoints in registers, all queries stream past, a
-//                   conservative packed-fp32 pre-check in front of the double chain -- parks what lies below it, and
-//                   MODE 2 ranks the parked midpoints (same doubles, same chain).  Rows identical to the full passes.
+//                   pass 1 over every stride-th midpoint gives an exclusive bound per query (MODE 1); a reference-major
+//                   pass parks what lies below it -- two and three components: f64_filter_mf_kernel, the fp32 engine's
+//                   split-f16 matrix-pipe pre-filter on the float-rounded midpoints with a threshold that provably covers
+//                   every pair whose DOUBLE distance is below the bound, then the double chain on what passes; other
+//                   dimensions: f64_filter_kernel, a packed-fp32 pre-check in front of the double chain --; MODE 2 ranks
+//                   the parked midpoints (same doubles, same chain).  Rows identical to the full passes.
+//   gathers         two to four components: the positions once more with 32-byte rows (f64_pad4_kernel) for the spring
+//                   and midpoint kernels -- a neighbour's row is two 16-byte loads from one sector (321 -> 136 us).
 //   intersection    f64_intersect_kernel: pt.py:638-774 per candidate pair, double atomics into a dense (n, D) array
 //   update          f64_sum_kernel / f64_centre_kernel / f64_scale_kernel: new = pos + (Fs + Fi); column means, then
 //                   centred sums of squares (two passes, fixed-order reductions), unbiased std + 1e-6, divide.
-// Per-iteration cost at a million vertices (rocprofv3, round 5): spring 320 us (8 M gathers of 24-byte rows), filter 320,
-// midpoints 85, thresholds 54, update 57, ranking 14, intersection 14: 0.88 ms (round 4, two full passes per query: 6.7 ms).
+// Per-iteration cost at a million vertices (rocprofv3, round 5): spring 136 us, filter 134, midpoints 90, thresholds 61,
+// update 57, padded copy ~15, ranking 14, intersection 14: 0.52 ms (round 4, two full passes per query: 6.7 ms).
 #include "common.h"
 #include "engine.h"
+#include "scan_core.h"   // the split-f16 matrix-pipe pre-filter of the fp32 engine (gh_mf_query_row / gh_mf_ref_col): reused by the filtered search
 
 #include <algorithm>
 #include <new>
@@ -31,6 +36,7 @@
 
 struct gh_f64 {
     double *pos = nullptr, *nw = nullptr, *Fs = nullptr, *Fi = nullptr, *mid = nullptr, *io = nullptr;
+    double2 *pos4 = nullptr;      // (n, 2) double2 = (n, 4) doubles: the positions with 32-byte rows (2..4 components; rebuilt every step)
     double *part = nullptr;       // (blocks, D) partial sums of the reductions
     double *colstat = nullptr;    // (2, D): mean, std + 1e-6
     int32_t *rowptr = nullptr, *adj = nullptr, *edges = nullptr, *sampled = nullptr, *knn = nullptr;
@@ -39,6 +45,9 @@ struct gh_f64 {
     // reference-major pass over all midpoints that parks what passes it, the exact ranking over the parked ones
     int64_t stride = 0;           // 0: the two full passes per query (small graphs)
     double *sub = nullptr;        // (ceil(E / stride), D) every stride-th midpoint, contiguous (written beside mid)
+    gh_h8 *qA = nullptr;          // (S, 2) the queries' A-operand rows of the matrix-pipe pre-filter (2 or 3 components)
+    double *pmax = nullptr;       // (ceil(n / 256)) per-block maxima of |coordinate| over the positions (f64_pad4_kernel)
+    double *qaux = nullptr;       // (S, 2) sqrt of that bound (-1: the query takes the full passes), |q|: for the filter's fp32 pre-check
     double *tq = nullptr;         // (S) exclusive bound on the double distance: the float above the K-th smallest rounded-down subset distance
     int32_t *cnt = nullptr;       // (S * F64_CNT_STRIDE) parked midpoints per query, one counter per 128-byte line (may exceed F64_CAND_CAP: then that query takes the full passes)
     double *cand_d = nullptr;     // (S, F64_CAND_CAP) their squared distances ...
@@ -88,6 +97,85 @@ __global__ __launch_bounds__(256) void f64_spring_kernel(const double *__restric
     for (int d = 0; d < D; ++d) F[x * D + d] = acc[d];
 }
 
+// Two to four components: the positions once more as (n, 4) doubles (32-byte rows, pad 0), so that a neighbour's row is two
+// 16-byte loads from one 32-byte sector instead of D separate 8-byte loads from a 24-byte row that straddles sectors (the
+// spring kernel's 8 M gathers at a million vertices: 321 us with the (n, D) rows).  Same arithmetic, same order.
+// (also the block's largest |coordinate| -> pmax[blockIdx.x]: the matrix-pipe pre-filter's bound on the midpoints' norms)
+__global__ __launch_bounds__(256) void f64_pad4_kernel(const double *__restrict__ pos, int64_t n, int D, double2 *__restrict__ pos4,
+                                                      double *__restrict__ pmax) {
+    __shared__ double red[4];
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (i < n) {
+        for (int d = 0; d < D; ++d) v[d] = pos[i * D + d];
+        pos4[2 * i] = make_double2(v[0], v[1]);
+        pos4[2 * i + 1] = make_double2(v[2], v[3]);
+    }
+    double m = fmax(fmax(fabs(v[0]), fabs(v[1])), fmax(fabs(v[2]), fabs(v[3])));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0 && pmax) pmax[blockIdx.x] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+template <int DT>
+__global__ __launch_bounds__(256) void f64_spring4_kernel(const double2 *__restrict__ pos4, const int32_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ adj, int64_t n, double L_min, double neg_k,
+                                                         double *__restrict__ F) {
+    const int64_t x = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    double acc[DT], diff[DT], px[4];
+    { const double2 a = pos4[2 * x], b = pos4[2 * x + 1]; px[0] = a.x; px[1] = a.y; px[2] = b.x; px[3] = b.y; }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) acc[d] = 0.0;
+    auto pull = [&](const double2 &a, const double2 &b) __attribute__((always_inline)) {
+        const double py[4] = {a.x, a.y, b.x, b.y};
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) { diff[d] = py[d] - px[d]; s = fma(diff[d], diff[d], s); }
+        const double dist = sqrt(s) + 1e-6;                 // pt.py:623
+        const double fm = neg_k * (dist - L_min);           // pt.py:626
+#pragma unroll
+        for (int d = 0; d < DT; ++d) acc[d] = acc[d] + fm * (diff[d] / dist);   // pt.py:629, 633-634
+    };
+    int j = rowptr[x];
+    const int jend = rowptr[x + 1];
+    for (; j + 4 <= jend; j += 4) {
+        int64_t ys[4];
+        double2 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ys[u] = adj[j + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = pos4[2 * ys[u]]; if (DT > 2) b[u] = pos4[2 * ys[u] + 1]; else b[u] = make_double2(0.0, 0.0); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pull(a[u], b[u]);
+    }
+    for (; j < jend; ++j) {
+        const int64_t y = adj[j];
+        pull(pos4[2 * y], DT > 2 ? pos4[2 * y + 1] : make_double2(0.0, 0.0));
+    }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) F[x * DT + d] = acc[d];
+}
+// midpoints from the padded rows, one thread per edge
+template <int DT>
+__global__ __launch_bounds__(256) void f64_mid4_kernel(const double2 *__restrict__ pos4, const int32_t *__restrict__ edges, int64_t E,
+                                                      double *__restrict__ mid, int64_t stride, double *__restrict__ sub) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int2 uv = reinterpret_cast<const int2 *>(edges)[e];
+    const double2 ua = pos4[2 * (int64_t)uv.x], va = pos4[2 * (int64_t)uv.y];
+    double2 ub = make_double2(0.0, 0.0), vb = ub;
+    if (DT > 2) { ub = pos4[2 * (int64_t)uv.x + 1]; vb = pos4[2 * (int64_t)uv.y + 1]; }
+    const double pu[4] = {ua.x, ua.y, ub.x, ub.y}, pv[4] = {va.x, va.y, vb.x, vb.y};
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        const double v = (pu[d] + pv[d]) / 2.0;   // pt.py:785
+        mid[e * DT + d] = v;
+        if (sub && e % stride == 0) sub[(e / stride) * DT + d] = v;
+    }
+}
+
 __global__ void f64_mid_kernel(const double *__restrict__ pos, const int32_t *__restrict__ edges, int64_t E, int D, double *__restrict__ mid,
                                int64_t stride = 0, double *__restrict__ sub = nullptr /* every stride-th midpoint once more, contiguous: the
                                thresholds' subset (read by every query's workgroup: 1 MB in lines of its own instead of one line per midpoint) */) {
@@ -129,8 +217,12 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
                                                      int K, int32_t *__restrict__ knn, int32_t *__restrict__ fail,
                                                      int64_t stride, double *__restrict__ tq, int32_t *__restrict__ cnt,
                                                      const double *__restrict__ cand_d, const int32_t *__restrict__ cand_i,
-                                                     const double *__restrict__ sub /* MODE 1: the compact subset */) {
+                                                     const double *__restrict__ sub /* MODE 1: the compact subset */,
+                                                     double *__restrict__ qaux = nullptr /* MODE 1: (S, 2) sqrt of the bound (-1: none), |q| */,
+                                                     gh_h8 *__restrict__ qA = nullptr /* MODE 1, D <= 3: the query's A-operand row of the matrix-pipe
+                                                     pre-filter (f64_filter_mf_kernel) */, const double *__restrict__ pmax = nullptr, int npmax = 0) {
     __shared__ double q[F64_MAXD];
+    __shared__ double s_pm[4];
     __shared__ uint64_t wmin[4];
     __shared__ double pool_d[F64_POOL];
     __shared__ int32_t pool_i[F64_POOL];
@@ -236,12 +328,53 @@ __global__ __launch_bounds__(256) void f64_knn_kernel(const double *__restrict__
         }
     }
     if (MODE == 1) {
+        if (qA && D <= 3) {   // the largest |coordinate| of any position, by all threads
+            double pm = 0.0;
+            for (int b = threadIdx.x; b < npmax; b += 256) pm = fmax(pm, pmax[b]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) pm = fmax(pm, __shfl_xor(pm, off, 64));
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) s_pm[threadIdx.x >> 6] = pm;
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
             const uint32_t vb = (uint32_t)(kth >> 32);
             // not a finite bound (fewer than K subset midpoints, or distances that overflow): the query takes the full passes
             const bool usable = vb < 0x7F800000u;
-            tq[qi] = usable ? (double)__uint_as_float(vb + 1u) : 0.0;
+            const double bound = usable ? (double)__uint_as_float(vb + 1u) : 0.0;
+            tq[qi] = bound;
             cnt[qi * F64_CNT_STRIDE] = usable ? 0 : F64_CAND_CAP + 1;
+            bool mf_ok = false;
+            if (qaux) {   // what the filter's fp32 pre-check needs of this query, once instead of once per workgroup
+                double qn = 0.0;
+                for (int d = 0; d < D; ++d) qn = fma(q[d], q[d], qn);
+                const double qnorm = sqrt(qn) * (1.0 + 1e-15);
+                if (qA && D <= 3) {
+                    // the matrix-pipe form: threshold b32 of the fp32 difference chain (derivation at f64_filter_kernel) with
+                    // M = sqrt(D) * the largest |coordinate| of any position (a midpoint's norm is at most its endpoints')
+                    const double M = fmax(fmax(s_pm[0], s_pm[1]), fmax(s_pm[2], s_pm[3])) * sqrt((double)D) * (1.0 + 1e-15);
+                    _Float16 row[16];
+                    float qf3[3] = {(float)q[0], (float)q[1], D > 2 ? (float)q[2] : 0.0f};
+                    float b32 = -1.0f;
+                    if (usable) {
+                        const double u24 = 5.9604644775390625e-08;
+                        const double r = sqrt(bound) * (1.0 + 1e-15) + 2.01 * u24 * (qnorm + M);
+                        const double b = r * r * (1.0 + (D + 2) * u24) * (1.0 + 1e-12);
+                        b32 = (float)b;
+                        if ((double)b32 < b) b32 = __uint_as_float(__float_as_uint(b32) + 1u);
+                        if (!(b < 1e30)) b32 = __builtin_inff();
+                    }
+                    mf_ok = usable && gh_mf_query_row(qf3, 3, b32, row);   // false: outside the f16 range -> a never-pass row
+                    if (!usable) { for (int k = 0; k < 16; ++k) row[k] = (_Float16)0.0f; row[12] = (_Float16)GH_MF_NEVER; }
+                    gh_h8 lo, hi;
+                    for (int k = 0; k < 8; ++k) { lo[k] = row[k]; hi[k] = row[8 + k]; }
+                    qA[2 * qi] = lo;
+                    qA[2 * qi + 1] = hi;
+                    if (usable && !mf_ok) cnt[qi * F64_CNT_STRIDE] = F64_CAND_CAP + 1;   // out of the f16 range: the full passes
+                }
+                qaux[2 * qi] = (usable && (mf_ok || !(qA && D <= 3))) ? sqrt(bound) * (1.0 + 1e-15) : -1.0;
+                qaux[2 * qi + 1] = qnorm;
+            }
         }
         return;
     }
@@ -381,6 +514,189 @@ __global__ __launch_bounds__(256) void f64_filter_kernel(const double *__restric
                 }
             }
         }
+    }
+}
+
+// The same pass for two or three components (the common case), written for its inner loop: ALL queries' float records
+// (x, y, z, b32) sit in LDS as one 16-byte read per query, the next one requested before the current one is used; nothing in
+// double is staged (the rare pair that passes the pre-check fetches its query's doubles from memory); the bound's square
+// root and |q| come from the threshold launch (qaux), so a workgroup spends three flops per query on its b32, not two square
+// roots; two midpoints per lane (tiles of 512: 7800 workgroups at a million vertices, four rounds of the chip instead of 2.2).
+#define F64_F3_MAXS 2048
+template <int DT, int U>
+__global__ __launch_bounds__(256) void f64_filter3_kernel(const double *__restrict__ mid, int64_t E, const int32_t *__restrict__ sampled, int S,
+                                                         const double *__restrict__ tq, const double *__restrict__ qaux,
+                                                         int32_t *__restrict__ cnt, double *__restrict__ cand_d, int32_t *__restrict__ cand_i) {
+    static_assert(DT == 2 || DT == 3, "two or three components");
+    static_assert(U % 2 == 0, "the pre-check packs two midpoints per lane");
+    __shared__ float4 qf4[F64_F3_MAXS];
+    __shared__ double wmax[4];
+    double m[U][3];
+    const int64_t e0 = (int64_t)blockIdx.x * 256 * U + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t e = e0 + (int64_t)u * 256;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) m[u][d] = (d < DT && e < E) ? mid[e * DT + d] : 0.0;
+    }
+    f64_f2 mf[U / 2][3];
+    double nm = 0.0;
+#pragma unroll
+    for (int r = 0; r < U / 2; ++r)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) mf[r][d] = (f64_f2){(float)m[2 * r][d], (float)m[2 * r + 1][d]};
+#pragma unroll
+    for (int u = 0; u < U; ++u) nm = fmax(nm, fma(m[u][2], m[u][2], fma(m[u][1], m[u][1], m[u][0] * m[u][0])));
+    nm = sqrt(nm) * (1.0 + 1e-15);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) nm = fmax(nm, __shfl_xor(nm, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = nm;
+    __syncthreads();
+    const double M = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+    for (int t = threadIdx.x; t < S; t += 256) {
+        const int64_t qe = sampled[t];
+        float4 rec;
+        rec.x = (float)mid[qe * DT];
+        rec.y = (float)mid[qe * DT + 1];
+        rec.z = DT > 2 ? (float)mid[qe * DT + 2] : 0.0f;
+        float b32 = -1.0f;
+        const double sb = qaux[2 * t];
+        if (sb >= 0.0) {   // (derivation: f64_filter_kernel)
+            const double u24 = 5.9604644775390625e-08;
+            const double r = sb + 2.01 * u24 * (qaux[2 * t + 1] + M);
+            const double b = r * r * (1.0 + (DT + 2) * u24) * (1.0 + 1e-12);
+            b32 = (float)b;
+            if ((double)b32 < b) b32 = __uint_as_float(__float_as_uint(b32) + 1u);
+            if (!(b < 1e37)) b32 = __builtin_inff();
+        }
+        rec.w = b32;
+        qf4[t] = rec;
+    }
+    __syncthreads();
+    float4 nxt = qf4[0];
+    for (int j = 0; j < S; ++j) {
+        const float4 q = nxt;
+        nxt = qf4[j + 1 < S ? j + 1 : j];
+        unsigned pass = 0u;
+#pragma unroll
+        for (int r = 0; r < U / 2; ++r) {
+            const f64_f2 dx = (f64_f2){q.x, q.x} - mf[r][0], dy = (f64_f2){q.y, q.y} - mf[r][1], dz = (f64_f2){q.z, q.z} - mf[r][2];
+            f64_f2 acc = __builtin_elementwise_fma(dx, dx, (f64_f2){0.0f, 0.0f});
+            acc = __builtin_elementwise_fma(dy, dy, acc);
+            if (DT > 2) acc = __builtin_elementwise_fma(dz, dz, acc);
+            pass |= (acc.x <= q.w ? 1u : 0u) << (2 * r);
+            pass |= (acc.y <= q.w ? 1u : 0u) << (2 * r + 1);
+        }
+        if (pass == 0u) continue;
+        const int64_t qe = sampled[j];
+        const double bound = tq[j];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!((pass >> u) & 1u)) continue;
+            double sd = 0.0;
+#pragma unroll
+            for (int d = 0; d < DT; ++d) { const double df = mid[qe * DT + d] - m[u][d]; sd = fma(df, df, sd); }
+            const int64_t e = e0 + (int64_t)u * 256;
+            if (sd < bound && e < E) {
+                const int p = atomicAdd(&cnt[(int64_t)j * F64_CNT_STRIDE], 1);
+                if (p < F64_CAND_CAP) { cand_d[(int64_t)j * F64_CAND_CAP + p] = sd; cand_i[(int64_t)j * F64_CAND_CAP + p] = (int32_t)e; }
+            }
+        }
+    }
+}
+
+// The filtered pass for two or three components on the MATRIX PIPE: the fp32 engine's split-f16 pre-filter (scan_core.h:
+// F = C0_j - 2 q.m_j - T <= 0 for every pair whose fp32 difference-chain distance is <= the row's threshold, 1024 pairs per
+// v_mfma_f32_32x32x16_f16) run on the float-rounded midpoints with the threshold b32 of f64_filter_kernel's derivation
+// (every pair whose DOUBLE distance is below the query's bound has an fp32 chain value <= b32): what passes takes the double
+// chain and is parked if that is below the bound.  A wave owns 4 column blocks of 32 midpoints (B operands in registers),
+// the queries' A rows -- built once per query by the threshold launch -- stream past from LDS; a lane owns one midpoint
+// column and 16 query rows of every 32x32 result.  Midpoints outside the f16 range (|coordinate| > 128) are scanned in
+// double against every query by the workgroup; queries outside it take the full passes (their rows never pass).
+#define F64_MF_QG 256
+template <int DT>
+__global__ __launch_bounds__(256) void f64_filter_mf_kernel(const double *__restrict__ mid, int64_t E, const int32_t *__restrict__ sampled, int S,
+                                                           const double *__restrict__ tq, const double *__restrict__ qaux,
+                                                           const gh_h8 *__restrict__ qA, int32_t *__restrict__ cnt,
+                                                           double *__restrict__ cand_d, int32_t *__restrict__ cand_i) {
+    constexpr int NB = 4, TILE = 512;
+    __shared__ gh_h8 qa[2 * F64_MF_QG];
+    __shared__ uint16_t badlist[TILE];
+    __shared__ int nbad;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = lane & 31, hsel = lane >> 5;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE;
+    if (threadIdx.x == 0) nbad = 0;
+    __syncthreads();
+    gh_h8 B[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = w * (32 * NB) + b * 32 + col;
+        const int64_t e = tile0 + j;
+        const bool valid = e < E;
+        float mv[3] = {0.0f, 0.0f, 0.0f};
+        if (valid) {
+#pragma unroll
+            for (int d = 0; d < DT; ++d) mv[d] = (float)mid[e * DT + d];
+        }
+        if (!gh_mf_ref_col(mv, valid, hsel, B[b]) && hsel == 0) badlist[atomicAdd(&nbad, 1)] = (uint16_t)j;
+    }
+    auto park = [&](int s, int j) {   // the double chain of pair (query s, midpoint j of the tile), as f64_knn_kernel computes it
+        if (qaux[2 * s] < 0.0) return;   // a query on the full passes parks nothing
+        const int64_t e = tile0 + j, qe = sampled[s];
+        double sd = 0.0;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) { const double df = mid[qe * DT + d] - mid[e * DT + d]; sd = fma(df, df, sd); }
+        if (sd < tq[s]) {
+            const int p = atomicAdd(&cnt[(int64_t)s * F64_CNT_STRIDE], 1);
+            if (p < F64_CAND_CAP) { cand_d[(int64_t)s * F64_CAND_CAP + p] = sd; cand_i[(int64_t)s * F64_CAND_CAP + p] = (int32_t)e; }
+        }
+    };
+    const int nvalid = (int)min((int64_t)TILE, E - tile0);
+    for (int s_lo = 0; s_lo < S; s_lo += F64_MF_QG) {
+        const int nq = min(S - s_lo, F64_MF_QG);
+        __syncthreads();   // the previous group's rows are still being read
+        for (int t = threadIdx.x; t < 2 * F64_MF_QG; t += 256) {
+            const _Float16 z = (_Float16)0.0f;
+            gh_h8 v = (t & 1) ? (gh_h8){z, z, z, z, (_Float16)GH_MF_NEVER, z, z, z} : (gh_h8){z, z, z, z, z, z, z, z};   // padding row: never passes
+            if (t < 2 * nq) v = qA[2 * s_lo + t];
+            qa[t] = v;
+        }
+        __syncthreads();
+        const int nqb = (nq + 31) / 32;
+        const gh_f16x zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int qb = 0; qb < nqb; ++qb) {
+            const gh_h8 a = qa[2 * (qb * 32 + col) + hsel];
+            gh_f16x f = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[0], zero, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                gh_f16x fn = zero;
+                if (b + 1 < NB) fn = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, B[b + 1], zero, 0, 0, 0);
+                int mn = min(__float_as_int(f[0]), __float_as_int(f[1]));
+#pragma unroll
+                for (int i = 2; i < 16; ++i) mn = min(mn, __float_as_int(f[i]));
+                asm volatile("" : "+v"(mn));
+                if (mn <= 0) {   // rare: result row (i & 3) + 8 (i >> 2) + 4 * half, column = this lane's midpoint
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) m = __builtin_amdgcn_alignbit(m, __float_as_uint(f[i]), 31);
+                    const int j = w * (32 * NB) + b * 32 + col;
+                    if (j < nvalid) {
+                        while (m) {
+                            const int bit = 31 - __builtin_clz(m);
+                            m &= ~(1u << bit);
+                            const int i = 15 - bit;
+                            const int sq = qb * 32 + (i & 3) + 8 * (i >> 2) + 4 * hsel;
+                            if (sq < nq) park(s_lo + sq, j);
+                        }
+                    }
+                }
+                f = fn;
+            }
+        }
+        // midpoints outside the f16 range: every query of the group, one pair per thread and step
+        const int nb_ = nbad;
+        for (int p = threadIdx.x; p < nb_ * nq; p += 256) park(s_lo + p % nq, badlist[p / nq]);
     }
 }
 
@@ -524,13 +840,21 @@ void f64_free(gh_engine *h) {
     gh_f64 *f = h->f64;
     if (!f) return;
     void *ptrs[] = {f->pos, f->nw, f->Fs, f->Fi, f->mid, f->io, f->part, f->colstat, f->rowptr, f->adj, f->edges, f->sampled, f->knn, f->fail,
-                    f->tq, f->cnt, f->cand_d, f->cand_i, f->sub};
+                    f->tq, f->cnt, f->cand_d, f->cand_i, f->sub, f->qaux, f->qA, f->pmax, f->pos4};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     delete f;
     h->f64 = nullptr;
 }
 
-gh_status f64_knn(gh_engine *h, const int32_t *host_ids) {
+// (n, 4) copy of the positions for the gathering kernels (2..4 components)
+void f64_refresh_pos4(gh_engine *h) {
+    gh_f64 *f = h->f64;
+    if (f->pos4) f64_pad4_kernel<<<dim3(f64_grid(h->n)), dim3(256), 0, h->stream>>>(f->pos, h->n, h->D, f->pos4, f->pmax);
+}
+template <typename K2, typename K3, typename K4>
+void f64_by_dim(int D, K2 k2, K3 k3, K4 k4) { if (D == 2) k2(); else if (D == 3) k3(); else k4(); }
+
+gh_status f64_knn(gh_engine *h, const int32_t *host_ids, bool pos4_fresh = false) {
     gh_f64 *f = h->f64;
     if ((int64_t)h->K > h->E) { h->err = "selected index k out of range"; return GH_ERR_K_TOO_LARGE; }
     if (h->S >= h->E) {
@@ -543,15 +867,24 @@ gh_status f64_knn(gh_engine *h, const int32_t *host_ids) {
     } else {
         f64_sample_kernel<<<dim3(f64_grid(h->S)), dim3(256), 0, h->stream>>>(h->E, h->S, h->prm.seed, h->iter, 1, f->sampled);
     }
-    f64_mid_kernel<<<dim3(f64_grid(h->E * h->D)), dim3(256), 0, h->stream>>>(f->pos, f->edges, h->E, h->D, f->mid, f->stride, f->sub);
+    if (f->pos4) {
+        if (!pos4_fresh) f64_refresh_pos4(h);
+#define F64_MID4(DD) f64_mid4_kernel<DD><<<dim3(f64_grid(h->E)), dim3(256), 0, h->stream>>>(f->pos4, f->edges, h->E, f->mid, std::max<int64_t>(f->stride, 1), f->stride > 0 ? f->sub : nullptr)
+        f64_by_dim(h->D, [&] { F64_MID4(2); }, [&] { F64_MID4(3); }, [&] { F64_MID4(4); });
+#undef F64_MID4
+    } else {
+        f64_mid_kernel<<<dim3(f64_grid(h->E * h->D)), dim3(256), 0, h->stream>>>(f->pos, f->edges, h->E, h->D, f->mid, f->stride, f->sub);
+    }
     if (f->stride > 0) {
         f64_knn_kernel<1><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(f->mid, h->E, h->D, f->sampled, h->K, f->knn, f->fail, f->stride, f->tq, f->cnt,
-                                                                             f->cand_d, f->cand_i, f->sub);
+                                                                             f->cand_d, f->cand_i, f->sub, f->qaux, (h->D == 2 || h->D == 3) ? f->qA : nullptr, f->pmax, (int)f64_grid(h->n));
 #define F64_FILTER(DD, UU) f64_filter_kernel<DD, UU, (DD > 0 && UU % 2 == 0)><<<dim3((unsigned)((h->E + 256 * UU - 1) / (256 * UU))), dim3(256), 0, h->stream>>>( \
         f->mid, h->E, h->D, f->sampled, h->S, f->tq, f->cnt, f->cand_d, f->cand_i)
+#define F64_FILTER3(DD) f64_filter_mf_kernel<DD><<<dim3((unsigned)((h->E + 511) / 512)), dim3(256), 0, h->stream>>>( \
+        f->mid, h->E, f->sampled, (int)h->S, f->tq, f->qaux, f->qA, f->cnt, f->cand_d, f->cand_i)
         switch (h->D) {
-            case 2: F64_FILTER(2, 4); break;
-            case 3: F64_FILTER(3, 4); break;
+            case 2: F64_FILTER3(2); break;
+            case 3: F64_FILTER3(3); break;
             case 4: F64_FILTER(4, 4); break;
             case 5: F64_FILTER(5, 2); break;
             case 6: F64_FILTER(6, 2); break;
@@ -560,6 +893,7 @@ gh_status f64_knn(gh_engine *h, const int32_t *host_ids) {
             default: F64_FILTER(0, 1); break;
         }
 #undef F64_FILTER
+#undef F64_FILTER3
         f64_knn_kernel<2><<<dim3((unsigned)h->S), dim3(256), 0, h->stream>>>(f->mid, h->E, h->D, f->sampled, h->K, f->knn, f->fail, f->stride, f->tq, f->cnt,
                                                                              f->cand_d, f->cand_i, nullptr);
     } else {
@@ -570,13 +904,26 @@ gh_status f64_knn(gh_engine *h, const int32_t *host_ids) {
     return GH_OK;
 }
 
+// spring forces of the current positions -> f->Fs (refreshes the padded copy of the positions)
+void f64_launch_spring(gh_engine *h) {
+    gh_f64 *f = h->f64;
+    if (f->pos4) {
+        f64_refresh_pos4(h);
+#define F64_SPR4(DD) f64_spring4_kernel<DD><<<dim3(f64_grid(h->n)), dim3(256), 0, h->stream>>>(f->pos4, f->rowptr, f->adj, h->n, f->L_min, -f->k_attr, f->Fs)
+        f64_by_dim(h->D, [&] { F64_SPR4(2); }, [&] { F64_SPR4(3); }, [&] { F64_SPR4(4); });
+#undef F64_SPR4
+    } else {
+        f64_spring_kernel<<<dim3(f64_grid(h->n)), dim3(256), 0, h->stream>>>(f->pos, h->D, f->rowptr, f->adj, h->n, f->L_min, -f->k_attr, f->Fs);
+    }
+}
+
 gh_status f64_step(gh_engine *h, const int32_t *host_ids) {
     gh_f64 *f = h->f64;
     const size_t bytes = sizeof(double) * (size_t)h->n * h->D;
-    f64_spring_kernel<<<dim3(f64_grid(h->n)), dim3(256), 0, h->stream>>>(f->pos, h->D, f->rowptr, f->adj, h->n, f->L_min, -f->k_attr, f->Fs);
+    f64_launch_spring(h);
     GH_HIP(hipMemsetAsync(f->Fi, 0, bytes, h->stream));
     if (h->S > 0 && h->k > 0) {
-        GH_TRY_ST(f64_knn(h, host_ids));
+        GH_TRY_ST(f64_knn(h, host_ids, true));
         f64_intersect_kernel<<<dim3(f64_grid(h->S * h->k)), dim3(256), 0, h->stream>>>(f->pos, h->D, f->edges, f->sampled, f->knn, h->S, h->k,
                                                                                       f->k_inter, f->Fi);
     }
@@ -666,10 +1013,11 @@ extern "C" gh_status gh_create_f64(gh_handle *out, int device_id, int64_t n, int
     // returning atomic on its query's counter)
     if (E >= F64_FILTER_MIN_EDGES && h->S > 0 && h->k > 0 && (size_t)h->S * F64_CAND_CAP * 12 <= ((size_t)1 << 30)) {
         f->stride = std::min<int64_t>(1024, std::max<int64_t>(16, 1024 / h->K));
-        if ((st = f64_alloc(h, &f->sub, (size_t)((E + f->stride - 1) / f->stride) * D)) || (st = f64_alloc(h, &f->tq, (size_t)h->S)) || (st = f64_alloc(h, &f->cnt, (size_t)h->S * F64_CNT_STRIDE)) ||
+        if ((st = f64_alloc(h, &f->sub, (size_t)((E + f->stride - 1) / f->stride) * D)) || (st = f64_alloc(h, &f->tq, (size_t)h->S)) || (st = f64_alloc(h, &f->qaux, (size_t)2 * h->S)) || (st = f64_alloc(h, &f->qA, (size_t)2 * h->S)) ||  (st = f64_alloc(h, &f->cnt, (size_t)h->S * F64_CNT_STRIDE)) ||
             (st = f64_alloc(h, &f->cand_d, (size_t)h->S * F64_CAND_CAP)) || (st = f64_alloc(h, &f->cand_i, (size_t)h->S * F64_CAND_CAP)))
             return bail(st);
     }
+    if (D >= 2 && D <= 4 && ((st = f64_alloc(h, &f->pos4, (size_t)2 * n)) || (st = f64_alloc(h, &f->pmax, (size_t)f64_grid(n))))) return bail(st);
     if (hipMemset(f->pos, 0, sizeof(double) * nD) != hipSuccess || hipMemset(f->fail, 0, sizeof(int32_t)) != hipSuccess ||
         hipMemcpy(f->rowptr, rowptr.data(), sizeof(int32_t) * rowptr.size(), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(f->adj, adj.data(), sizeof(int32_t) * (size_t)(2 * E), hipMemcpyHostToDevice) != hipSuccess ||
@@ -741,7 +1089,7 @@ extern "C" gh_status gh_spring_forces_f64(gh_handle h, double *F) {
     GH_TRY_ST(f64_check(h));
     if (!F) { h->err = "F is NULL"; return GH_ERR_INVALID; }
     gh_f64 *f = h->f64;
-    f64_spring_kernel<<<dim3(f64_grid(h->n)), dim3(256), 0, h->stream>>>(f->pos, h->D, f->rowptr, f->adj, h->n, f->L_min, -f->k_attr, f->Fs);
+    f64_launch_spring(h);
     GH_LAUNCH_CHECK();
     return f64_download(h, f->Fs, F);
 }

@@ -116,14 +116,16 @@ def test_float64_search_against_numpy_with_one_stripe_holding_the_best():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("D,k,S,kind", [(3, 10, 64, "gauss"), (2, 5, 32, "gauss"), (5, 16, 48, "gauss"), (16, 32, 16, "gauss"),
-                                        (7, 10, 16, "gauss"), (3, 10, 32, "collapsed"), (3, 10, 24, "clones")])
+                                        (7, 10, 16, "gauss"), (3, 10, 32, "collapsed"), (3, 10, 24, "clones"), (4, 10, 32, "gauss"),
+                                        (1, 5, 16, "gauss"), (2, 10, 32, "collapsed"), (3, 10, 16, "far")])
 def test_float64_filtered_search_equals_a_numpy_brute_force(D, k, S, kind):
     """From 131072 edges on the float64 engine searches through a filter (csrc/f64.hip: per query an exclusive bound from
     every stride-th midpoint, one reference-major pass over all midpoints that parks what lies below it, the exact
     (double distance, id) ranking over the parked ones).  Rows against a float64 brute force in numpy over all midpoints
     (ties on the smaller id, column 0 dropped, pt.py:421) -- on a Gaussian cloud, on a cloud collapsed to 1e-9 around a
     far point (float keys of many distances coincide), and with every position shared by 64 vertices (ties in every
-    row; parked lists overflow and the query falls back to the full passes)."""
+    row; parked lists overflow and the query falls back to the full passes), and on a cloud outside the f16 range of the
+    matrix-pipe pre-filter (two and three components: such midpoints are scanned in double, such queries take the full passes)."""
     import graphem_rapids_amd as gra
     from graphem_rapids_amd import _native
     rng = np.random.default_rng(D * 100 + k)
@@ -135,6 +137,9 @@ def test_float64_filtered_search_equals_a_numpy_brute_force(D, k, S, kind):
         pos = rng.standard_normal((n, D))
     elif kind == "collapsed":
         pos = rng.standard_normal((n, D)) * 1e-9 + 5.0
+    elif kind == "far":      # a cloud beyond the f16 range of the matrix-pipe pre-filter (|coordinate| > 128) plus a few near points
+        pos = rng.standard_normal((n, D)) * 40.0 + 300.0
+        pos[: n // 20] = rng.standard_normal((n // 20, D))
     else:
         pos = np.repeat(rng.standard_normal((n // 64, D)), 64, axis=0)
     eng = _native.Engine(n, D, edges, 1.0, 0.2, 0.5, k, S, dtype="float64")
