@@ -460,3 +460,30 @@ def test_public_run_layout_draws_like_the_reference_loop():
     assert torch.equal(after, torch.get_rng_state())
     b._engine.run(70, ids)
     assert np.array_equal(out, b.get_positions())
+
+
+def test_bench_line_contract_on_a_small_workload():
+    """bench.py end to end (the driver's command on the quick workload): ONE JSON line with the contract's fields, the
+    roofline and cpu_baseline objects, and this round's sub-records (parity_mode with its own roofline, public_api)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                          "--workload", "rr20k"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_cold", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_mode", "public_api"):
+        assert key in d, key
+    assert d["steps"] == 5 and d["warmup"] == 2 and d["n_gpus"] == 1 and d["config"]["workload"] == "rr20k"
+    assert d["config"]["reference_identical"] is False and d["parity_mode"]["reference_identical"] is True
+    for rf in (d["roofline"], d["parity_mode"]["roofline"]):
+        assert rf["bound"] == "hbm" and 0 < rf["frac"] < 1 and abs(rf["achieved"] / rf["peak"] - rf["frac"]) < 1e-9
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 1.0) < 1e-6
+    for case in d["public_api"]["cases"].values():
+        assert case["torch"]["reference_identical"] is True and case["device"]["reference_identical"] is False
+        assert case["torch"]["ms_per_iteration"] > 0 and case["device"]["ms_per_iteration"] > 0
