@@ -407,6 +407,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # Rehearsal of the N > 1 code path on a box with ONE GPU (tests, development): GRAPHEM_BENCH_REHEARSAL=gloo puts every
+    # rank on cuda:0 and runs the collectives over gloo (RCCL refuses two ranks on one device).  Exercises everything of a
+    # multi-rank run but RCCL; its timings mean nothing.
+    rehearsal = os.environ.get("GRAPHEM_BENCH_REHEARSAL") == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from graphem_rapids_amd import _native
@@ -425,7 +431,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         lay = PartitionedLayout(n, D, edges, 1.0, 0.2, 0.5, k, S, seed=0, rank=rank, world=world,
                                 device_id=local_rank, native=args.loop == "native", knn_distance=args.knn_distance, finish=args.finish)
         lay.set_positions(pos)
@@ -525,7 +534,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "graph": WORKLOADS[args.workload][0], "n_vertices": n,
                        "n_edges": E, "n_components": D, "n_neighbors": k, "sample_size": S,
-                       "sampler": args.sampler, "knn": args.knn, "knn_distance": args.knn_distance, "parallelism": f"rows/{world}" + ("+rccl" if use_dist else ""),
+                       "sampler": args.sampler, "knn": args.knn, "knn_distance": args.knn_distance,
+                       "parallelism": f"rows/{world}" + (("+gloo-rehearsal-on-one-gpu" if rehearsal else "+rccl") if use_dist else ""),
                        # speed mode (knn_distance='exact', device sampler): exact-difference distances, ties on the smaller id --
                        # 252-256 of 256 neighbour rows equal the reference's at 1 M vertices; the mode whose rows ARE the
                        # reference's on every vertex is the `parity_mode` record of this line (reference_identical: true)

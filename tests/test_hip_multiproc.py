@@ -68,3 +68,27 @@ def test_processes_on_one_gpu_equal_the_single_engine(world, finish, knn_distanc
     assert np.abs(outs[0] - ref).max() <= 4e-6   # (five iterations from the 0.1-sigma start: the statistics' summation order, amplified)
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+
+
+@pytest.mark.parametrize("finish", ["overlap", "own"])
+def test_bench_multi_rank_code_path_on_one_gpu(finish):
+    """bench.py as the driver launches it for N > 1 -- torch.distributed.run, one rank per process, barrier + max-over-ranks
+    timing, rank 0's JSON line with rank0_us_per_step -- rehearsed with two ranks on this one GPU over gloo
+    (GRAPHEM_BENCH_REHEARSAL=gloo: every rank on cuda:0).  The numbers mean nothing; the code path must run and report."""
+    import json
+    import subprocess
+    env = dict(os.environ, GRAPHEM_BENCH_REHEARSAL="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+           "--workload", "rr100k", "--finish", finish]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["config"]["finish"] == finish
+    assert d["config"]["parallelism"].startswith("rows/2")
+    r0 = d["rank0_us_per_step"]
+    assert r0["kernels"] > 0 and r0["finish"] == finish
+    if finish == "overlap":
+        assert r0["rows_allgather_exposed"] is not None
