@@ -517,94 +517,6 @@ __global__ __launch_bounds__(256) void f64_filter_kernel(const double *__restric
     }
 }
 
-// The same pass for two or three components (the common case), written for its inner loop: ALL queries' float records
-// (x, y, z, b32) sit in LDS as one 16-byte read per query, the next one requested before the current one is used; nothing in
-// double is staged (the rare pair that passes the pre-check fetches its query's doubles from memory); the bound's square
-// root and |q| come from the threshold launch (qaux), so a workgroup spends three flops per query on its b32, not two square
-// roots; two midpoints per lane (tiles of 512: 7800 workgroups at a million vertices, four rounds of the chip instead of 2.2).
-#define F64_F3_MAXS 2048
-template <int DT, int U>
-__global__ __launch_bounds__(256) void f64_filter3_kernel(const double *__restrict__ mid, int64_t E, const int32_t *__restrict__ sampled, int S,
-                                                         const double *__restrict__ tq, const double *__restrict__ qaux,
-                                                         int32_t *__restrict__ cnt, double *__restrict__ cand_d, int32_t *__restrict__ cand_i) {
-    static_assert(DT == 2 || DT == 3, "two or three components");
-    static_assert(U % 2 == 0, "the pre-check packs two midpoints per lane");
-    __shared__ float4 qf4[F64_F3_MAXS];
-    __shared__ double wmax[4];
-    double m[U][3];
-    const int64_t e0 = (int64_t)blockIdx.x * 256 * U + threadIdx.x;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t e = e0 + (int64_t)u * 256;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) m[u][d] = (d < DT && e < E) ? mid[e * DT + d] : 0.0;
-    }
-    f64_f2 mf[U / 2][3];
-    double nm = 0.0;
-#pragma unroll
-    for (int r = 0; r < U / 2; ++r)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) mf[r][d] = (f64_f2){(float)m[2 * r][d], (float)m[2 * r + 1][d]};
-#pragma unroll
-    for (int u = 0; u < U; ++u) nm = fmax(nm, fma(m[u][2], m[u][2], fma(m[u][1], m[u][1], m[u][0] * m[u][0])));
-    nm = sqrt(nm) * (1.0 + 1e-15);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nm = fmax(nm, __shfl_xor(nm, off, 64));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = nm;
-    __syncthreads();
-    const double M = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
-    for (int t = threadIdx.x; t < S; t += 256) {
-        const int64_t qe = sampled[t];
-        float4 rec;
-        rec.x = (float)mid[qe * DT];
-        rec.y = (float)mid[qe * DT + 1];
-        rec.z = DT > 2 ? (float)mid[qe * DT + 2] : 0.0f;
-        float b32 = -1.0f;
-        const double sb = qaux[2 * t];
-        if (sb >= 0.0) {   // (derivation: f64_filter_kernel)
-            const double u24 = 5.9604644775390625e-08;
-            const double r = sb + 2.01 * u24 * (qaux[2 * t + 1] + M);
-            const double b = r * r * (1.0 + (DT + 2) * u24) * (1.0 + 1e-12);
-            b32 = (float)b;
-            if ((double)b32 < b) b32 = __uint_as_float(__float_as_uint(b32) + 1u);
-            if (!(b < 1e37)) b32 = __builtin_inff();
-        }
-        rec.w = b32;
-        qf4[t] = rec;
-    }
-    __syncthreads();
-    float4 nxt = qf4[0];
-    for (int j = 0; j < S; ++j) {
-        const float4 q = nxt;
-        nxt = qf4[j + 1 < S ? j + 1 : j];
-        unsigned pass = 0u;
-#pragma unroll
-        for (int r = 0; r < U / 2; ++r) {
-            const f64_f2 dx = (f64_f2){q.x, q.x} - mf[r][0], dy = (f64_f2){q.y, q.y} - mf[r][1], dz = (f64_f2){q.z, q.z} - mf[r][2];
-            f64_f2 acc = __builtin_elementwise_fma(dx, dx, (f64_f2){0.0f, 0.0f});
-            acc = __builtin_elementwise_fma(dy, dy, acc);
-            if (DT > 2) acc = __builtin_elementwise_fma(dz, dz, acc);
-            pass |= (acc.x <= q.w ? 1u : 0u) << (2 * r);
-            pass |= (acc.y <= q.w ? 1u : 0u) << (2 * r + 1);
-        }
-        if (pass == 0u) continue;
-        const int64_t qe = sampled[j];
-        const double bound = tq[j];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!((pass >> u) & 1u)) continue;
-            double sd = 0.0;
-#pragma unroll
-            for (int d = 0; d < DT; ++d) { const double df = mid[qe * DT + d] - m[u][d]; sd = fma(df, df, sd); }
-            const int64_t e = e0 + (int64_t)u * 256;
-            if (sd < bound && e < E) {
-                const int p = atomicAdd(&cnt[(int64_t)j * F64_CNT_STRIDE], 1);
-                if (p < F64_CAND_CAP) { cand_d[(int64_t)j * F64_CAND_CAP + p] = sd; cand_i[(int64_t)j * F64_CAND_CAP + p] = (int32_t)e; }
-            }
-        }
-    }
-}
-
 // The filtered pass for two or three components on the MATRIX PIPE: the fp32 engine's split-f16 pre-filter (scan_core.h:
 // F = C0_j - 2 q.m_j - T <= 0 for every pair whose fp32 difference-chain distance is <= the row's threshold, 1024 pairs per
 // v_mfma_f32_32x32x16_f16) run on the float-rounded midpoints with the threshold b32 of f64_filter_kernel's derivation
