@@ -773,10 +773,12 @@ def test_random_fused_configurations(seed):
     eng.close()
 
 
+@pytest.mark.parametrize("finish", ["gathered", "overlap"])
 @pytest.mark.parametrize("seed", range(6))
-def test_random_partitioned_configurations(seed):
+def test_random_partitioned_configurations(seed, finish):
     """Fuzz of the multi-rank split step on one GPU: random world size, graph (uneven degrees, sometimes a hub),
-    dimension, neighbour count; device sampler on every rank (ids must agree) for two of the three iterations."""
+    dimension, neighbour count; device sampler on every rank (ids must agree) for two of the three iterations; form B
+    (one collective of slots) and form D (rows early, statistics + patch lists late)."""
     import torch
     from graphem_rapids_amd import _native
     from graphem_rapids_amd.distributed import HipShardEngine, partition_rows
@@ -804,15 +806,27 @@ def test_random_partitioned_configurations(seed):
     for r in range(world):
         chunk, lo, hi = partition_rows(n, world, r)
         sh = HipShardEngine(n, D, edges, 1.0, 0.2, 0.5, k, S, 7, (lo, hi, 0, 0, _native.EDGES_HASHED), 0)
-        sh.gather_layout(world, r, chunk)
+        (sh.gather_layout if finish == "gathered" else sh.overlap_layout)(world, r, chunk)
         sh.set_positions(pos)
         shards.append(sh)
     for t in range(3):
         for sh in shards:
             sh.step_begin(first if t == 0 else None)
+        if finish == "overlap":
+            for sh in shards:
+                sh.step_pack_rows()
+            rows = torch.stack([sh.rows_all[r].clone() for r, sh in enumerate(shards)])
+            for sh in shards:
+                sh.rows_all.copy_(rows)
         gathered = torch.stack([sh.partial.clone() for sh in shards]).contiguous()
         for sh in shards:
             sh.step_merge(gathered, world)
+        if finish == "overlap":
+            stats = torch.stack([sh.stats_all[r].clone() for r, sh in enumerate(shards)])
+            for sh in shards:
+                sh.stats_all.copy_(stats)
+                sh.step_finish_overlap()
+            continue
         slots = torch.stack([sh.gbuf[r].clone() for r, sh in enumerate(shards)])
         for sh in shards:
             sh.gbuf.copy_(slots)
