@@ -41,26 +41,33 @@ __attribute__((target("avx2"))) void regen_avx2(uint32_t *p) {
     p[N - 1] = p[M - 1] ^ twist(p[N - 1], p[0]);
 }
 
-__attribute__((target("avx512f"))) inline void blk_avx512(uint32_t *p, int j, int off) {
-    // five ALU operations per 16 words: the bit select (a & UMASK) | (b & LMASK) is one vpternlogd, the conditional
-    // MATRIX_A one test-into-mask + masked xor (nine with and / or / negate / and).  Measured neutral: 229 against 235 us per
-    // 4 M words on the GPU box's host, 0.057 ns per word either way -- the three loads (one of them across a line boundary)
-    // and the store of a 16-word step set the pace, not its arithmetic
-    const __m512i um = _mm512_set1_epi32((int)UMASK), ma = _mm512_set1_epi32((int)MATRIX_A), one = _mm512_set1_epi32(1);
-    const __m512i a = _mm512_loadu_si512(p + j), b = _mm512_loadu_si512(p + j + 1), m = _mm512_loadu_si512(p + j + off);
-    const __m512i y = _mm512_ternarylogic_epi32(um, a, b, 0xCA);            // um ? a : b, bit by bit
-    __m512i r = _mm512_xor_si512(m, _mm512_srli_epi32(y, 1));
-    const __mmask16 odd = _mm512_test_epi32_mask(b, one);
-    r = _mm512_mask_xor_epi32(r, odd, r, ma);
-    _mm512_storeu_si512(p + j, r);
-}
 __attribute__((target("avx512f"))) void regen_avx512(uint32_t *p) {
-    int j = 0;
-    for (; j + 16 <= N - M; j += 16) blk_avx512(p, j, M);
-    for (; j < N - M; ++j) p[j] = p[j + M] ^ twist(p[j], p[j + 1]);
-    for (; j + 16 <= N - 1; j += 16) blk_avx512(p, j, M - N);
-    for (; j < N - 1; ++j) p[j] = p[j + M - N] ^ twist(p[j], p[j + 1]);
-    p[N - 1] = p[M - 1] ^ twist(p[N - 1], p[0]);
+    // 39 full vectors, no scalar remainder: word j takes  m_j = old p[j + 397] (j < 227) or new p[j - 227],  a_j = old p[j],
+    // b_j = old p[j + 1] (new p[0] for j = 623).  a is an ALIGNED load carried over from the step before (the state is 64-byte
+    // aligned), b = the same register shifted by one word with the next vector's first word (valignd): two loads per step
+    // instead of three, none of the a / b loads across a line boundary.  Vector 14 (words 224 .. 239) straddles the two
+    // ranges of m: a blend of both loads.  (The slack words behind the state are read, never used.)  The bit select
+    // (a & UMASK) | (b & LMASK) is one vpternlogd, the conditional MATRIX_A a test-into-mask + masked xor.  On the GPU box's
+    // host: 0.038 ns per word -- 153 us for the 4 M draws torch.randperm(4 M) spends -- against 0.057 with three loads per
+    // step (229 us; the five-instead-of-nine ALU operations alone changed nothing: the loads set the pace).
+    const __m512i um = _mm512_set1_epi32((int)UMASK), ma = _mm512_set1_epi32((int)MATRIX_A), one = _mm512_set1_epi32(1);
+    __m512i a = _mm512_load_si512(p);
+    for (int v = 0; v < 39; ++v) {
+        const int j = 16 * v;
+        __m512i an = _mm512_load_si512(p + j + 16);                       // old words j + 16 .. j + 31 (v = 38: slack)
+        if (v == 38) an = _mm512_set1_epi32((int)p[0]);                  // word 623's partner is the NEW word 0
+        const __m512i b = _mm512_alignr_epi32(an, a, 1);
+        __m512i m;
+        if (v < 14) m = _mm512_loadu_si512(p + j + M);
+        else if (v > 14) m = _mm512_loadu_si512(p + j + M - N);
+        else m = _mm512_mask_blend_epi32((__mmask16)0xFFF8, _mm512_loadu_si512(p + j + M), _mm512_loadu_si512(p + j + M - N + 0));
+        const __m512i y = _mm512_ternarylogic_epi32(um, a, b, 0xCA);        // um ? a : b, bit by bit
+        __m512i r = _mm512_xor_si512(m, _mm512_srli_epi32(y, 1));
+        const __mmask16 odd = _mm512_test_epi32_mask(b, one);
+        r = _mm512_mask_xor_epi32(r, odd, r, ma);
+        _mm512_store_si512(p + j, r);
+        a = an;
+    }
 }
 
 using regen_fn = void (*)(uint32_t *);

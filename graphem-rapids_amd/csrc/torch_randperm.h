@@ -14,7 +14,7 @@
 #define GH_TORCH_RNG_STATE_BYTES 5056
 
 struct gh_mt19937 {
-    uint32_t s[624 + 16];   // (+ slack: the vector loops read s[j + 1 ..] a few words past their last element)
+    alignas(64) uint32_t s[624 + 16];   // 64-byte aligned (the AVX-512 twist loads whole lines); + slack: the vector loops read a few words past the last element
     int32_t left;
     uint32_t next;
     int32_t seeded;
