@@ -103,21 +103,30 @@ def cpu_baseline(n, D, k, S, edges, pos, budget_s=24.0):
     samples = [rng.permutation(len(edges))[:S].astype(np.int32) for _ in range(5)]
 
     def timed(step, share):
-        p, done, t_total = pos.copy(), 0, 0.0
+        # a leg whose iteration is cheap against its share runs one untimed iteration first (page faults, cold caches, the
+        # OpenMP team's start: 5 iterations of 25 ms are too few to hide them); a slow leg (seconds per iteration) counts it
+        p = pos.copy()
+        t0 = time.perf_counter()
+        p = step(p, samples[0])
+        t_first = time.perf_counter() - t0
+        warm = t_first < share / 8
+        done, t_total = (0, 0.0) if warm else (1, t_first)
+        i = 1
         while done < len(samples) and (done == 0 or t_total + t_total / done < share):
             t0 = time.perf_counter()
-            p = step(p, samples[done])
+            p = step(p, samples[i % len(samples)])
             t_total += time.perf_counter() - t0
             done += 1
-        return {"value": done / t_total, "ms_per_iter": 1e3 * t_total / done, "iterations": done}
+            i += 1
+        return {"value": done / t_total, "ms_per_iter": 1e3 * t_total / done, "iterations": done, "warmup_iterations": 1 if warm else 0}
 
     omp = oracle.OmpStepper(n, edges)
     legs = {}
     all_threads = oracle.num_threads()
     best_omp = None
-    for nt in sorted({all_threads, max(1, all_threads // 2), min(all_threads, 64), min(all_threads, 32)}, reverse=True):
+    for nt in sorted({all_threads, max(1, all_threads // 2), min(all_threads, 96), min(all_threads, 64), min(all_threads, 32), min(all_threads, 16)}, reverse=True):
         oracle.set_threads(nt)   # memory-bound phases on a multi-socket host: the best team is not always the largest
-        leg = dict(timed(lambda p, s: omp.step(p, s, k), budget_s / 9), cores=nt,
+        leg = dict(timed(lambda p, s: omp.step(p, s, k), budget_s / 12), cores=nt,
                    what="oracle/graphem_oracle.c go_step_omp: every phase OpenMP; best of several team sizes")
         if best_omp is None or leg["value"] > best_omp["value"]:
             best_omp = leg
@@ -191,6 +200,31 @@ def cold_pass(run, sync, args):
     run(args.steps)
     sync()
     return 1e3 * (time.perf_counter() - t0) / args.steps
+
+
+def cpu_baseline_pinned(args):
+    """cpu_baseline() in a child process whose OpenMP threads are PINNED (OMP_PROC_BIND=close, OMP_PLACES=cores, unless the
+    caller's environment says otherwise).  Unpinned, the OpenMP port's memory-bound phases lose half their rate to thread
+    migration on the GPU box's 2-socket host and the figure moves 21-35 it/s from box to box (rr1m, same box, back to back:
+    25.3 / 23.8 unpinned, 25.3 spread over cores, 36.2 spread over hardware threads, 48.1 close over cores --
+    tools/cpu_baseline_probe.py).  A child, because libgomp reads the placement when it is loaded (torch loads it) and because
+    pinning this process would pin the host sampler's thread onto the enqueuing thread's core."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("OMP_PROC_BIND", "close")
+    env.setdefault("OMP_PLACES", "cores")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload]
+    if args.dim:
+        cmd += ["--dim", str(args.dim)]
+    if args.sample_size:
+        cmd += ["--sample-size", str(args.sample_size)]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
+    line = next((ln for ln in reversed(out.stdout.splitlines()) if ln.startswith("{")), None)
+    if out.returncode != 0 or line is None:
+        raise RuntimeError(f"cpu baseline child failed ({out.returncode}): {out.stderr[-500:]}")
+    rec = json.loads(line)
+    rec["omp_env"] = {"OMP_PROC_BIND": env["OMP_PROC_BIND"], "OMP_PLACES": env["OMP_PLACES"]}
+    return rec
 
 
 def parity_mode(args, n, D, k, S, edges, pos, device_id):
@@ -372,6 +406,7 @@ def main():
     ap.add_argument("--workload", default="rr1m", choices=sorted(WORKLOADS))
     ap.add_argument("--sampler", default="device", choices=["device", "host"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)   # the child process of cpu_baseline_pinned()
     ap.add_argument("--no-parity-mode", action="store_true", help="skip the parity_mode sub-record (the same steps with knn_distance='cdist')")
     ap.add_argument("--no-public-api", action="store_true", help="skip the public_api sub-record (wall clock around create_graphem(...).run_layout(K))")
     ap.add_argument("--sample-size", type=int, default=None, help="override the workload's number of sampled midpoints")
@@ -395,6 +430,16 @@ def main():
                          "collectives in a row, the rows last.  gathered = form B")
     ap.add_argument("--repeats", type=int, default=3, help="timed passes of --steps iterations; the median is reported")
     args = ap.parse_args()
+
+    if args.cpu_baseline_only:   # child of cpu_baseline_pinned(): no GPU, no torch.distributed; one JSON line
+        n, D, k, S, edges, pos = make_workload(args.workload)
+        if args.dim:
+            D = args.dim
+            pos = (np.random.default_rng(0).standard_normal((n, D)) * 0.1).astype(np.float32)
+        if args.sample_size:
+            S = min(args.sample_size, len(edges))
+        print(json.dumps(cpu_baseline(n, D, k, S, edges, pos)))
+        return
 
     # `python bench.py --gpus N` without a launcher: start the N ranks here, as children, BEFORE anything of this process
     # touches a GPU (a process that has initialised HIP must not be replaced or re-executed; torch is not even imported yet)
@@ -572,7 +617,7 @@ def main():
         if world == 1 and not use_dist and not args.no_public_api:
             out["public_api"] = public_api(args, local_rank)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n, D, k, S, edges, pos)
+            out["cpu_baseline"] = cpu_baseline_pinned(args)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if use_dist:
