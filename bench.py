@@ -297,9 +297,11 @@ def public_api(args, device_id):
             torch.randperm(E)
         rp_ms = 1e3 * (time.perf_counter() - t0) / 3
         st = torch.get_rng_state().numpy().copy()
-        t0 = time.perf_counter()
-        _native.torch_randperm_prefix(st, E, S, 20)
-        draw_us = 1e6 * (time.perf_counter() - t0) / 20
+        draw_us = float("inf")
+        for _ in range(3):   # (the fastest of three: a descheduled millisecond on a shared host reads as 3 ms per draw)
+            t0 = time.perf_counter()
+            _native.torch_randperm_prefix(st, E, S, 20)
+            draw_us = min(draw_us, 1e6 * (time.perf_counter() - t0) / 20)
         rec = {"n_vertices": n, "n_edges": E, "torch_randperm_ms": rp_ms, "host_draw_us_per_iteration": draw_us}
         for sampler in ("torch", "device"):
             t0 = time.perf_counter()
