@@ -74,9 +74,9 @@ def test_partitioned_layout_matches_single_rank_and_oracle(world, rule, finish, 
         assert np.array_equal(auto, np.load(tmp_path / f"auto_w{world}_r0.npy"))  # every rank holds the same positions
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world,finish", [(2, "own"), (3, "own"), (2, "overlap")])
 @pytest.mark.parametrize("kind", ["gauss", "lattice"])
-def test_parity_mode_on_row_partitions(world, kind, tmp_path):
+def test_parity_mode_on_row_partitions(world, finish, kind, tmp_path):
     """knn_distance='cdist' on row partitions: every rank sends its k + 2 best cdist keys and a flag, the merge decides the
     rows without a tie and hands the others to partial_sort's replay over all edges -- the rows must be the reference's
     (oracle.knn_midpoints_aten: torch.cdist + torch.topk, pt.py:580-583) on every rank, ties included (the lattice case
@@ -86,7 +86,7 @@ def test_parity_mode_on_row_partitions(world, kind, tmp_path):
     n, D, edges, pos, stream, k, S = _case(n=1203, deg=8, k=6, S=48, iters=1 if kind == "lattice" else 2)
     if kind == "lattice":
         pos = (np.random.default_rng(5).integers(-5, 6, size=(n, D)) / 4.0).astype(np.float32)
-    case = (n, D, edges, pos, stream, k, S, "hashed", "own", "cdist")
+    case = (n, D, edges, pos, stream, k, S, "hashed", finish, "cdist")
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
     ref = pos
     for t in range(len(stream)):

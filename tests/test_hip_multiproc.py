@@ -45,7 +45,7 @@ def _worker(rank, world, port, finish, knn_distance, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,finish,knn_distance", [(2, "overlap", "exact"), (3, "overlap", "exact"), (2, "own", "exact"),
+@pytest.mark.parametrize("world,finish,knn_distance", [(2, "overlap", "exact"), (3, "overlap", "exact"), (4, "overlap", "exact"), (2, "own", "exact"),
                                                         (2, "gathered", "exact"), (2, "overlap", "cdist")])
 def test_processes_on_one_gpu_equal_the_single_engine(world, finish, knn_distance, tmp_path):
     import torch.multiprocessing as mp
