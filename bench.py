@@ -473,6 +473,10 @@ def main():
 
     use_dist = world > 1 or args.dist
     if use_dist:
+        # a multi-rank run that stalls (a collective some rank never enters) would sit until the launcher's limit: after 20
+        # minutes every rank prints where it is and leaves, so that the log of a failed scaling run says why
+        import faulthandler
+        faulthandler.dump_traceback_later(1200, exit=True)
         import torch.distributed as dist
         from graphem_rapids_amd.distributed import PartitionedLayout
         if world == 1:
@@ -623,7 +627,9 @@ def main():
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if use_dist:
+        import faulthandler
         import torch.distributed as dist
+        faulthandler.cancel_dump_traceback_later()
         dist.destroy_process_group()
 
 
